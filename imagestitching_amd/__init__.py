@@ -1,0 +1,9 @@
+"""imagestitching_amd — MI355X-native strip stitcher (the Canvas-2D concatenation path of Iamctb/ImageStitching).
+
+Everything that touches pixels is hand-written HIP behind the C-ABI in include/imagestitch.h
+(imagestitching_amd/libimagestitch.so).  Importing this package fails if that library has not been built.
+"""
+from ._lib import (FILTER_BILINEAR, FILTER_NEAREST, HORIZONTAL, VERTICAL, StitchError, last_error)  # noqa: F401
+from .stitch import DEFAULT_OPTS, Stitcher, StitchJob, StitchPlan, plan, stitch  # noqa: F401
+
+__all__ = ["stitch", "plan", "Stitcher", "StitchJob", "StitchPlan", "StitchError", "DEFAULT_OPTS"]

@@ -1,0 +1,120 @@
+"""ctypes binding of libimagestitch.so (the C-ABI in include/imagestitch.h).
+
+There is no Python or CPU fallback: if the shared library (HIP kernels + C-ABI) is missing, import fails loudly.
+Build it with `make -C imagestitching_amd/csrc` or `python -c "import __graft_entry__ as g; g.build()"`.
+"""
+import ctypes as C
+import os
+
+# torch ships its own libamdhip64.so (SONAME libamdhip64.so.7).  It must be in the process BEFORE libimagestitch.so is
+# loaded so that both resolve to ONE HIP runtime; loading the system runtime first and torch's second gives two HSA
+# runtimes in one process and the second one finds no GPU.
+import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libimagestitch.so")
+
+VERTICAL, HORIZONTAL = 0, 1
+MODE_MIN, MODE_MAX, MODE_ORIGINAL = 0, 1, 2
+PLATFORM_OTHER, PLATFORM_IOS, PLATFORM_ANDROID = 0, 1, 2
+FILTER_NEAREST, FILTER_BILINEAR = 0, 1
+
+IST_OK, IST_NOTHING_TO_DO = 0, 1
+ERROR_NAMES = {-1: "IST_E_INVALID", -2: "IST_E_SIZE_UNAVAILABLE", -3: "IST_E_OUTPUT_SIZE", -4: "IST_E_NO_CONTEXT",
+               -5: "IST_E_NO_DEVICE", -6: "IST_E_DECODE", -7: "IST_E_UNSUPPORTED", -8: "IST_E_NOMEM", -9: "IST_E_HIP"}
+
+
+class ImageDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("orientation", C.c_int32),
+                ("bmp_width", C.c_int32), ("bmp_height", C.c_int32), ("opaque", C.c_int32),
+                ("file_size", C.c_int64)]
+
+
+class Limits(C.Structure):
+    _fields_ = [("platform", C.c_int32), ("reserved", C.c_int32), ("max_side", C.c_double),
+                ("max_pixels", C.c_double), ("max_super_sample", C.c_double)]
+
+
+class Rect(C.Structure):
+    _fields_ = [("image", C.c_int32), ("orientation", C.c_int32),
+                ("dx", C.c_double), ("dy", C.c_double), ("dw", C.c_double), ("dh", C.c_double)]
+
+
+class Plan(C.Structure):
+    _fields_ = [("out_w", C.c_double), ("out_h", C.c_double), ("scale_down", C.c_double),
+                ("super_sample", C.c_double), ("canvas_w", C.c_int64), ("canvas_h", C.c_int64),
+                ("big_task", C.c_int32), ("n_rects", C.c_int32), ("rects", C.POINTER(Rect))]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("image", C.c_int32), ("m", C.c_double * 6), ("s", C.c_double * 4),
+                ("d", C.c_double * 4), ("rgba", C.c_uint8 * 4), ("reserved", C.c_int32)]
+
+
+class Region(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
+
+
+class JobInfo(C.Structure):
+    _fields_ = [("canvas_w", C.c_int64), ("canvas_h", C.c_int64), ("n_ops", C.c_int32), ("n_cells", C.c_int32),
+                ("n_tiles", C.c_int64), ("out_pixels", C.c_int64), ("src_pixels_touched", C.c_int64),
+                ("algorithmic_bytes", C.c_int64), ("tiles_fill", C.c_int64), ("tiles_copy", C.c_int64),
+                ("tiles_sample", C.c_int64), ("tiles_general", C.c_int64)]
+
+
+# every symbol include/imagestitch.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("ist_abi_version", C.c_int, []),
+    ("ist_last_error", C.c_char_p, []),
+    ("ist_device_count", C.c_int, []),
+    ("ist_limits_default", None, [C.c_int, C.POINTER(Limits)]),
+    ("ist_limits_unlimited", None, [C.POINTER(Limits)]),
+    ("ist_plan_compute", C.c_int, [C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Limits), C.POINTER(Plan)]),
+    ("ist_plan_free", None, [C.POINTER(Plan)]),
+    ("ist_plan_ops", C.c_int, [C.POINTER(Plan), C.POINTER(ImageDesc), C.c_int, C.POINTER(Op), C.POINTER(C.c_int)]),
+    ("ist_ctx_create", C.c_void_p, [C.c_int]),
+    ("ist_ctx_destroy", None, [C.c_void_p]),
+    ("ist_job_create", C.c_void_p, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(Op), C.c_int,
+                                    C.POINTER(ImageDesc), C.c_int, C.c_int, C.POINTER(Region)]),
+    ("ist_job_info_get", C.c_int, [C.c_void_p, C.POINTER(JobInfo)]),
+    ("ist_job_launch", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("ist_job_destroy", None, [C.c_void_p]),
+    ("ist_stitch_rgba8", C.c_int, [C.c_void_p, C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int,
+                                   C.c_int, C.c_int, C.c_double, C.POINTER(Limits), C.c_int, C.POINTER(Plan),
+                                   C.POINTER(C.POINTER(C.c_uint8))]),
+    ("ist_render_rgba8", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(Op), C.c_int,
+                                   C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
+                                   C.POINTER(Region), C.c_void_p, C.c_size_t]),
+    ("ist_free", None, [C.c_void_p]),
+]
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "imagestitching_amd: %s is missing. The stitch path is HIP-only (no CPU fallback); build it with "
+        "`make -C imagestitching_amd/csrc` (hipcc, --offload-arch=gfx950)." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+for _name, _res, _args in SYMBOLS:
+    _f = getattr(lib, _name)          # AttributeError here = the library does not export a declared symbol
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+class StitchError(RuntimeError):
+    """Mirrors the reference's single catch: Error(msg) -> toast '拼图失败：'+msg (pages/index/index.js:1618-1624)."""
+
+    def __init__(self, code, message):
+        self.code = code
+        self.reason = message
+        super().__init__("拼图失败：%s [%s]" % (message, ERROR_NAMES.get(code, code)))
+
+
+def last_error():
+    s = lib.ist_last_error()
+    return s.decode("utf-8", "replace") if s else ""
+
+
+def check(rc):
+    if rc < 0:
+        raise StitchError(rc, last_error())
+    return rc

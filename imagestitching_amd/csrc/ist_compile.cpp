@@ -1,0 +1,262 @@
+// ist_compile.cpp — turns a recorded Canvas op list into the device tables of one fused launch.
+//
+// Reference anchor: what the WeChat Canvas does between createOffscreenCanvas (utils/canvas.js:131-150) and the
+// export (utils/canvas.js:205-242) for the calls onStitch issues: fillRect (pages/index/index.js:1424) and
+// drawImage under a CTM (utils/canvas.js:153-202).  Instead of rasterising call by call (one full-canvas white
+// pass + one pass per image = the output written twice), the op list is decomposed into CELLS — canvas rectangles
+// over which the paint stack is constant — so that one launch writes every output pixel exactly once.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "ist_internal.h"
+
+namespace ist {
+
+static inline uint32_t pack_rgba(const uint8_t c[4]) {
+  return static_cast<uint32_t>(c[0]) | (static_cast<uint32_t>(c[1]) << 8) | (static_cast<uint32_t>(c[2]) << 16) |
+         (static_cast<uint32_t>(c[3]) << 24);
+}
+
+// Shared arithmetic contract (DESIGN.md "raster contract"; the oracle implements the same formulas independently).
+int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, int img_h, DevOp* out) {
+  const double a = op.m[0], b = op.m[1], c = op.m[2], d = op.m[3], e = op.m[4], f = op.m[5];
+  const bool straight = (b == 0.0 && c == 0.0 && a != 0.0 && d != 0.0);
+  const bool turned = (a == 0.0 && d == 0.0 && b != 0.0 && c != 0.0);
+  std::memset(out, 0, sizeof(*out));
+  out->image = -1;
+  auto clip_box = [&](double xl, double xh, double yl, double yh) {
+    double X0 = std::ceil(xl - 0.5), X1 = std::ceil(xh - 0.5), Y0 = std::ceil(yl - 0.5), Y1 = std::ceil(yh - 0.5);
+    X0 = std::max(X0, 0.0); Y0 = std::max(Y0, 0.0);
+    X1 = std::min(X1, static_cast<double>(canvas_w)); Y1 = std::min(Y1, static_cast<double>(canvas_h));
+    out->X0 = static_cast<int32_t>(X0); out->X1 = static_cast<int32_t>(X1);
+    out->Y0 = static_cast<int32_t>(Y0); out->Y1 = static_cast<int32_t>(Y1);
+    return (out->X1 > out->X0 && out->Y1 > out->Y0);
+  };
+  if (op.kind == IST_OP_FILL || op.kind == IST_OP_HOLE) {
+    if (!straight) return fail(IST_E_UNSUPPORTED, "fillRect under a rotated transform is outside the stitch path");
+    if (op.kind == IST_OP_FILL && op.rgba[3] != 255) return fail(IST_E_UNSUPPORTED, "translucent fillStyle is outside the stitch path");
+    if (!(op.d[2] > 0.0) || !(op.d[3] > 0.0)) return 1;
+    const double xa = a * op.d[0] + e, xb = a * (op.d[0] + op.d[2]) + e;
+    const double ya = d * op.d[1] + f, yb = d * (op.d[1] + op.d[3]) + f;
+    out->flags = (op.kind == IST_OP_HOLE ? OPF_HOLE : OPF_FILL) | OPF_OPAQUE;
+    out->rgba = pack_rgba(op.rgba);
+    return clip_box(std::min(xa, xb), std::max(xa, xb), std::min(ya, yb), std::max(ya, yb)) ? 0 : 1;
+  }
+  if (op.kind != IST_OP_DRAW) return fail(IST_E_INVALID, "unknown op kind");
+  if (!straight && !turned) return fail(IST_E_UNSUPPORTED, "drawImage under a non axis-aligned transform is outside the stitch path");
+  const double sx = op.s[0], sy = op.s[1], sw = op.s[2], sh = op.s[3];
+  const double rx = op.d[0], ry = op.d[1], rw = op.d[2], rh = op.d[3];
+  if (!(rw > 0.0) || !(rh > 0.0) || !(sw > 0.0) || !(sh > 0.0)) return 1;     // Canvas draws nothing
+  // u (user x) is driven by canvas X (straight) or canvas Y (turned); v likewise
+  const double ku = turned ? b : a, eu = turned ? f : e;
+  const double kv = turned ? c : d, ev = turned ? e : f;
+  const double gx = sw / rw, gy = sh / rh;
+  out->kx = gx / ku;
+  out->ox = sx - (eu / ku + rx) * gx;
+  out->ky = gy / kv;
+  out->oy = sy - (ev / kv + ry) * gy;
+  const double wa = ku * rx + eu, wb = ku * (rx + rw) + eu;
+  const double za = kv * ry + ev, zb = kv * (ry + rh) + ev;
+  const double wl = std::min(wa, wb), wh = std::max(wa, wb), zl = std::min(za, zb), zh = std::max(za, zb);
+  const bool any = turned ? clip_box(zl, zh, wl, wh) : clip_box(wl, wh, zl, zh);
+  double t;
+  t = std::floor(sx);            out->cx0 = t < 0.0 ? 0 : static_cast<int32_t>(t);
+  t = std::ceil(sx + sw) - 1.0;  out->cx1 = t > img_w - 1 ? img_w - 1 : static_cast<int32_t>(t);
+  t = std::floor(sy);            out->cy0 = t < 0.0 ? 0 : static_cast<int32_t>(t);
+  t = std::ceil(sy + sh) - 1.0;  out->cy1 = t > img_h - 1 ? img_h - 1 : static_cast<int32_t>(t);
+  if (out->cx1 < out->cx0 || out->cy1 < out->cy0) return 1;
+  out->image = op.image;
+  out->flags = turned ? OPF_SWAP : 0;
+  if (!turned && out->kx == 1.0 && out->ky == 1.0 && out->ox == std::floor(out->ox) && out->oy == std::floor(out->oy))
+    out->flags |= OPF_IDENTITY;
+  return any ? 0 : 1;
+}
+
+// number of distinct source indices one axis of a draw touches over canvas coordinates [lo, hi)
+static int64_t distinct_taps(double k, double o, int lo, int hi, int clo, int chi, int filter) {
+  if (hi <= lo) return 0;
+  std::vector<int32_t> idx;
+  idx.reserve(static_cast<size_t>(hi - lo) * 2);
+  for (int w = lo; w < hi; ++w) {
+    const double s = k * (static_cast<double>(w) + 0.5) + o;
+    if (filter == IST_FILTER_BILINEAR) {
+      double fl = std::floor(s - 0.5);
+      fl = std::min(std::max(fl, -4.0e9), 4.0e9);
+      const int64_t i0 = static_cast<int64_t>(fl);
+      idx.push_back(static_cast<int32_t>(std::min<int64_t>(std::max<int64_t>(i0, clo), chi)));
+      idx.push_back(static_cast<int32_t>(std::min<int64_t>(std::max<int64_t>(i0 + 1, clo), chi)));
+    } else {
+      double fl = std::floor(s);
+      fl = std::min(std::max(fl, -4.0e9), 4.0e9);
+      idx.push_back(static_cast<int32_t>(std::min<int64_t>(std::max<int64_t>(static_cast<int64_t>(fl), clo), chi)));
+    }
+  }
+  std::sort(idx.begin(), idx.end());
+  return static_cast<int64_t>(std::unique(idx.begin(), idx.end()) - idx.begin());
+}
+
+int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,
+                const ist_image_desc* images, int n_images, int filter, const ist_region* clip, Compiled* out) {
+  if (canvas_w < 1 || canvas_h < 1 || canvas_w > (1 << 29) || canvas_h > 2147483647LL)
+    return fail(IST_E_OUTPUT_SIZE, "输出尺寸计算失败: canvas size out of range");
+  if (n_ops < 0 || (n_ops > 0 && !ops)) return fail(IST_E_INVALID, "compile_ops: bad op list");
+  if (filter != IST_FILTER_NEAREST && filter != IST_FILTER_BILINEAR) return fail(IST_E_INVALID, "unknown filter");
+  out->canvas_w = canvas_w; out->canvas_h = canvas_h; out->filter = filter;
+  out->ops.clear(); out->cells.clear(); out->stacks.clear();
+  out->img_w.assign(static_cast<size_t>(n_images), 0);
+  out->img_h.assign(static_cast<size_t>(n_images), 0);
+  for (int i = 0; i < n_images; ++i) {
+    out->img_w[i] = images[i].bmp_width > 0 ? images[i].bmp_width : images[i].width;
+    out->img_h[i] = images[i].bmp_height > 0 ? images[i].bmp_height : images[i].height;
+  }
+
+  // region to render
+  int64_t RX0 = 0, RY0 = 0, RX1 = canvas_w, RY1 = canvas_h;
+  if (clip) {
+    RX0 = std::max<int64_t>(0, clip->x); RY0 = std::max<int64_t>(0, clip->y);
+    RX1 = std::min<int64_t>(canvas_w, static_cast<int64_t>(clip->x) + clip->w);
+    RY1 = std::min<int64_t>(canvas_h, static_cast<int64_t>(clip->y) + clip->h);
+    if (RX1 <= RX0 || RY1 <= RY0) return fail(IST_E_INVALID, "clip region is empty");
+  }
+  out->rx0 = RX0; out->ry0 = RY0; out->rx1 = RX1; out->ry1 = RY1;
+
+  // 1. resolve every op into canvas space (ops that draw nothing are dropped)
+  for (int i = 0; i < n_ops; ++i) {
+    int iw = 0, ih = 0;
+    if (ops[i].kind == IST_OP_DRAW) {
+      if (ops[i].image < 0 || ops[i].image >= n_images) return fail(IST_E_INVALID, "op refers to a missing image");
+      iw = out->img_w[ops[i].image]; ih = out->img_h[ops[i].image];
+      if (iw < 1 || ih < 1) return fail(IST_E_DECODE, "图片" + std::to_string(ops[i].image) + "解码异常");
+    }
+    DevOp r;
+    const int rc = resolve_op(ops[i], canvas_w, canvas_h, iw, ih, &r);
+    if (rc < 0) return rc;
+    if (rc > 0) continue;
+    if (ops[i].kind == IST_OP_DRAW && images[ops[i].image].opaque) r.flags |= OPF_OPAQUE;
+    // clip to the render region
+    r.X0 = static_cast<int32_t>(std::max<int64_t>(r.X0, RX0)); r.X1 = static_cast<int32_t>(std::min<int64_t>(r.X1, RX1));
+    r.Y0 = static_cast<int32_t>(std::max<int64_t>(r.Y0, RY0)); r.Y1 = static_cast<int32_t>(std::min<int64_t>(r.Y1, RY1));
+    if (r.X1 <= r.X0 || r.Y1 <= r.Y0) continue;
+    out->ops.push_back(r);
+  }
+  const int n = static_cast<int>(out->ops.size());
+
+  // 2. grid of break lines
+  std::vector<int32_t> xs{static_cast<int32_t>(RX0), static_cast<int32_t>(RX1)}, ys{static_cast<int32_t>(RY0), static_cast<int32_t>(RY1)};
+  for (const DevOp& r : out->ops) { xs.push_back(r.X0); xs.push_back(r.X1); ys.push_back(r.Y0); ys.push_back(r.Y1); }
+  std::sort(xs.begin(), xs.end()); xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
+  std::sort(ys.begin(), ys.end()); ys.erase(std::unique(ys.begin(), ys.end()), ys.end());
+
+  // canvas clear colour: premultiplied (general path) and as it reads back (fill path)
+  uint8_t pm[4], back[4];
+  for (int c = 0; c < 3; ++c) pm[c] = static_cast<uint8_t>((clear_rgba[c] * clear_rgba[3] + 127) / 255);
+  pm[3] = clear_rgba[3];
+  for (int c = 0; c < 3; ++c) {
+    if (pm[3] == 255) back[c] = pm[c];
+    else if (pm[3] == 0) back[c] = 0;
+    else back[c] = static_cast<uint8_t>(std::min(255u, (pm[c] * 255u + pm[3] / 2u) / pm[3]));
+  }
+  back[3] = pm[3];
+  const uint32_t clear_pm = pack_rgba(pm), clear_back = pack_rgba(back);
+
+  // 3. cells: per grid row, merge horizontally adjacent grid cells whose paint stack is identical
+  ist_job_info& info = out->info;
+  std::memset(&info, 0, sizeof(info));
+  int64_t tiles = 0;
+  std::vector<int32_t> stack, prev_stack;
+  for (size_t yi = 0; yi + 1 < ys.size(); ++yi) {
+    const int32_t Y0 = ys[yi], Y1 = ys[yi + 1];
+    bool have_prev = false;
+    for (size_t xi = 0; xi + 1 < xs.size(); ++xi) {
+      const int32_t X0 = xs[xi], X1 = xs[xi + 1];
+      stack.clear();
+      for (int k = 0; k < n; ++k) {
+        const DevOp& r = out->ops[k];
+        if (r.X0 <= X0 && X1 <= r.X1 && r.Y0 <= Y0 && Y1 <= r.Y1) {
+          if (r.flags & OPF_OPAQUE) stack.clear();
+          stack.push_back(k);
+        }
+      }
+      if (have_prev && stack == prev_stack) {       // extend the previous cell to the right
+        DevCell& pc = out->cells.back();
+        // an identity cell may only grow while the whole span stays inside the source (no clamping)
+        pc.X1 = X1;
+        continue;
+      }
+      if (!stack.empty() && (out->ops[stack[0]].flags & OPF_HOLE)) {
+        if (stack.size() > 1) return fail(IST_E_UNSUPPORTED, "drawing over a region reserved for another producer");
+        have_prev = false;          // nothing is written here
+        continue;
+      }
+      DevCell cell;
+      std::memset(&cell, 0, sizeof(cell));
+      cell.X0 = X0; cell.Y0 = Y0; cell.X1 = X1; cell.Y1 = Y1;
+      cell.stack_off = static_cast<int32_t>(out->stacks.size());
+      // the colour under the stack
+      uint32_t bg_pm = clear_pm, bg_back = clear_back;
+      size_t first = 0;
+      if (!stack.empty() && (out->ops[stack[0]].flags & OPF_FILL)) { bg_pm = bg_back = out->ops[stack[0]].rgba; first = 1; }
+      for (size_t k = first; k < stack.size(); ++k) out->stacks.push_back(stack[k]);
+      cell.stack_len = static_cast<int32_t>(stack.size() - first);
+      cell.op = cell.stack_len ? out->stacks[cell.stack_off] : -1;
+      cell.bg = bg_pm;
+      out->cells.push_back(cell);
+      prev_stack = stack; have_prev = true;
+    }
+  }
+
+  // 4. classify + tile each cell
+  for (DevCell& cell : out->cells) {
+    const bool bg_opaque = (cell.bg >> 24) == 255u;
+    if (cell.stack_len == 0) {
+      cell.path = PATH_FILL;
+      if (!bg_opaque) cell.bg = clear_back;       // reads back un-premultiplied
+    } else if (cell.stack_len == 1 && !(out->ops[cell.op].flags & OPF_SWAP) &&
+               (bg_opaque || (out->ops[cell.op].flags & OPF_OPAQUE))) {
+      const DevOp& r = out->ops[cell.op];
+      bool copy = (r.flags & OPF_IDENTITY) != 0;
+      if (copy) {   // every source coordinate of the cell must be inside the clamp box
+        const int64_t ix0 = cell.X0 + static_cast<int64_t>(r.ox), ix1 = cell.X1 - 1 + static_cast<int64_t>(r.ox);
+        const int64_t iy0 = cell.Y0 + static_cast<int64_t>(r.oy), iy1 = cell.Y1 - 1 + static_cast<int64_t>(r.oy);
+        copy = ix0 >= r.cx0 && ix1 <= r.cx1 && iy0 >= r.cy0 && iy1 <= r.cy1;
+      }
+      cell.path = copy ? PATH_COPY : PATH_SAMPLE;
+      if (!bg_opaque) cell.bg = 0xFFFFFFFFu;      // never used: the draw is opaque
+    } else {
+      cell.path = PATH_GENERAL;
+    }
+    if (cell.path == PATH_GENERAL) { cell.tile_w = 64; cell.tile_h = 64; }
+    else { cell.tile_w = 256; cell.tile_h = 32; }
+    const int64_t w = cell.X1 - cell.X0, h = cell.Y1 - cell.Y0;
+    cell.tiles_x = static_cast<int32_t>((w + cell.tile_w - 1) / cell.tile_w);
+    const int64_t tiles_y = (h + cell.tile_h - 1) / cell.tile_h;
+    cell.tile_begin = tiles;
+    const int64_t nt = cell.tiles_x * tiles_y;
+    tiles += nt;
+    info.out_pixels += w * h;
+    switch (cell.path) {
+      case PATH_FILL: info.tiles_fill += nt; break;
+      case PATH_COPY: info.tiles_copy += nt; break;
+      case PATH_SAMPLE: info.tiles_sample += nt; break;
+      default: info.tiles_general += nt; break;
+    }
+    for (int k = 0; k < cell.stack_len; ++k) {
+      const DevOp& r = out->ops[out->stacks[cell.stack_off + k]];
+      if (r.flags & OPF_FILL) continue;
+      const bool sw = (r.flags & OPF_SWAP) != 0;
+      // source x is driven by canvas X (or Y when turned); source y by the other axis
+      const int64_t nx = distinct_taps(r.kx, r.ox, sw ? cell.Y0 : cell.X0, sw ? cell.Y1 : cell.X1, r.cx0, r.cx1, filter);
+      const int64_t ny = distinct_taps(r.ky, r.oy, sw ? cell.X0 : cell.Y0, sw ? cell.X1 : cell.Y1, r.cy0, r.cy1, filter);
+      info.src_pixels_touched += nx * ny;
+    }
+  }
+  if (tiles > 2147483647LL) return fail(IST_E_OUTPUT_SIZE, "canvas needs more than 2^31 tiles");
+  info.canvas_w = canvas_w; info.canvas_h = canvas_h;
+  info.n_ops = n; info.n_cells = static_cast<int32_t>(out->cells.size());
+  info.n_tiles = tiles;
+  info.algorithmic_bytes = 4 * info.src_pixels_touched + 4 * info.out_pixels;
+  return IST_OK;
+}
+
+}  // namespace ist

@@ -1,0 +1,80 @@
+// ist_internal.h — shared between the planner, the op-list compiler and the HIP launch code.
+#ifndef IST_INTERNAL_H_
+#define IST_INTERNAL_H_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/imagestitch.h"
+
+namespace ist {
+
+extern thread_local std::string g_last_error;
+extern thread_local int g_last_code;
+int fail(int code, const std::string& msg);
+
+// Canvas current transformation matrix:  X = a*u + c*v + e ;  Y = b*u + d*v + f
+struct Ctm {
+  double a = 1.0, b = 0.0, c = 0.0, d = 1.0, e = 0.0, f = 0.0;
+  void translate(double x, double y);
+  void scale(double x, double y);
+  void rotate(double rad);
+};
+
+// ---- device-visible tables -----------------------------------------------------------------------------------
+// A draw resolved into canvas space.  Sampling map (the arithmetic contract shared with the oracle):
+//     sxf = kx * Wc + ox ,  syf = ky * Zc + oy ,  (Wc, Zc) = swap ? (Y+0.5, X+0.5) : (X+0.5, Y+0.5)
+enum : int32_t { OPF_FILL = 1, OPF_SWAP = 2, OPF_OPAQUE = 4, OPF_IDENTITY = 8, OPF_HOLE = 16 };
+
+struct alignas(16) DevOp {
+  double kx, ox, ky, oy;
+  int32_t image;            // index into the launch's source table (-1 for fills)
+  int32_t flags;
+  int32_t cx0, cy0, cx1, cy1;   // inclusive clamp bounds in the source bitmap
+  uint32_t rgba;            // fill colour, packed little-endian R,G,B,A
+  int32_t X0, Y0, X1, Y1;   // covered canvas pixels (clipped); host-side use
+  int32_t pad;
+};
+
+// How a cell (a canvas rectangle whose paint stack is constant) is rendered
+enum : int32_t {
+  PATH_FILL = 0,      // constant colour
+  PATH_COPY = 1,      // opaque constant under ONE 1:1 draw with integer offset: HBM copy (+ source-over if alpha<255)
+  PATH_SAMPLE = 2,    // opaque constant under ONE axis-aligned draw, source x driven by canvas x
+  PATH_GENERAL = 3    // anything else: paint stack evaluated per pixel in canvas order (swap draws, overlaps,
+                      // translucent canvas)
+};
+
+struct alignas(16) DevCell {
+  int32_t X0, Y0, X1, Y1;
+  int32_t path;
+  int32_t op;               // the single draw for COPY/SAMPLE; first stack entry otherwise
+  int32_t stack_off, stack_len;
+  uint32_t bg;              // packed colour under the stack (fill colour or the canvas clear colour)
+  int32_t tile_w, tile_h;
+  int32_t tiles_x;
+  int64_t tile_begin;       // prefix sum of tiles over cells
+};
+
+struct Compiled {
+  int64_t canvas_w = 0, canvas_h = 0;
+  int64_t rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;   // rendered region (the clip, or the whole canvas)
+  int filter = IST_FILTER_BILINEAR;
+  std::vector<DevOp> ops;
+  std::vector<DevCell> cells;
+  std::vector<int32_t> stacks;
+  std::vector<int32_t> img_w, img_h;   // bitmap sizes per image (for launch-time validation)
+  ist_job_info info{};
+};
+
+// resolve + cell decomposition (host, pure CPU).  Returns IST_OK or an error code (g_last_error set).
+int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,
+                const ist_image_desc* images, int n_images, int filter, const ist_region* clip, Compiled* out);
+
+// resolve one op (exposed for tests): returns 0 ok, 1 nothing drawn, <0 error
+int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, int img_h, DevOp* out);
+
+}  // namespace ist
+
+#endif  // IST_INTERNAL_H_

@@ -1,0 +1,30 @@
+// ist_launch.h — kernel argument block + launch entry shared by ist_kernels.hip and ist_runtime.cpp
+#ifndef IST_LAUNCH_H_
+#define IST_LAUNCH_H_
+
+#include "ist_internal.h"
+
+namespace ist {
+
+// Source pointers travel BY VALUE in the kernarg segment (2 KiB for 128 images): a stitch can be re-launched on
+// new buffers with no table upload and no host synchronisation.  The reference UI caps a stitch at 9 images
+// (pages/index/index.js:311); BASELINE config 5 uses 64.
+constexpr int kMaxImages = 128;
+
+struct LaunchArgs {
+  uint8_t* dst;
+  size_t dst_pitch;
+  const DevOp* ops;
+  const DevCell* cells;
+  const int32_t* stacks;
+  int32_t n_cells;
+  int32_t filter;
+  const uint8_t* src[kMaxImages];
+  size_t pitch[kMaxImages];
+};
+
+int launch_stitch(const LaunchArgs& args, int64_t n_tiles, void* stream);
+
+}  // namespace ist
+
+#endif  // IST_LAUNCH_H_

@@ -1,0 +1,255 @@
+// ist_runtime.cpp — device context, compiled jobs and the host-buffer convenience path of the C-ABI.
+//
+// Reference anchors (miniprogram-stitch/miniprogram/): the context stands for the canvas node obtained at
+// pages/index/index.js:1196-1204; a job for the offscreen canvas + recorded draws (utils/canvas.js:131-150,
+// index.js:1391-1428, 1532-1551); launch for the raster flush the export forces (utils/canvas.js:205-242).
+// There is deliberately no CPU fallback: without a HIP device every rendering entry point fails.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+#include "ist_internal.h"
+#include "ist_launch.h"
+
+using namespace ist;
+
+#define IST_HIP(expr)                                                                                       \
+  do {                                                                                                      \
+    const hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) return fail(IST_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+struct ist_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;          // used by the host-buffer path only
+  void* scratch_src = nullptr; size_t scratch_src_bytes = 0;
+  void* scratch_dst = nullptr; size_t scratch_dst_bytes = 0;
+  std::mutex mu;                         // one host-path stitch in flight per context (index.js:772 isStitching)
+};
+
+struct ist_job {
+  ist_ctx* ctx = nullptr;
+  Compiled host;
+  DevOp* d_ops = nullptr;
+  DevCell* d_cells = nullptr;
+  int32_t* d_stacks = nullptr;
+  int max_image = -1;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int grow(void** p, size_t* have, size_t need) {
+  if (*have >= need) return IST_OK;
+  if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
+  IST_HIP(hipMalloc(p, need));
+  *have = need;
+  return IST_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ist_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+ist_ctx* ist_ctx_create(int device) {
+  const int n = ist_device_count();
+  if (n <= 0) { fail(IST_E_NO_DEVICE, "no HIP device: the stitch path has no CPU fallback"); return nullptr; }
+  if (device < 0 || device >= n) { fail(IST_E_INVALID, "device index out of range"); return nullptr; }
+  DeviceGuard g(device);
+  if (!g.ok) { fail(IST_E_NO_DEVICE, "hipSetDevice failed"); return nullptr; }
+  std::unique_ptr<ist_ctx> c(new ist_ctx);
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    fail(IST_E_HIP, "hipStreamCreate failed");
+    return nullptr;
+  }
+  return c.release();
+}
+
+void ist_ctx_destroy(ist_ctx* ctx) {
+  if (!ctx) return;
+  DeviceGuard g(ctx->device);
+  if (ctx->scratch_src) (void)hipFree(ctx->scratch_src);
+  if (ctx->scratch_dst) (void)hipFree(ctx->scratch_dst);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+ist_job* ist_job_create(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
+                        const ist_op* ops, int n_ops, const ist_image_desc* images, int n_images,
+                        int filter, const ist_region* clip) {
+  if (!ctx) { fail(IST_E_NO_CONTEXT, "无法获取绘图上下文"); return nullptr; }
+  if (n_images > kMaxImages) { fail(IST_E_UNSUPPORTED, "more than 128 images in one launch"); return nullptr; }
+  static const uint8_t transparent[4] = {0, 0, 0, 0};
+  std::unique_ptr<ist_job> job(new ist_job);
+  job->ctx = ctx;
+  if (compile_ops(canvas_w, canvas_h, clear_rgba ? clear_rgba : transparent, ops, n_ops, images, n_images, filter,
+                  clip, &job->host) != IST_OK)
+    return nullptr;
+  for (const DevOp& o : job->host.ops) job->max_image = std::max(job->max_image, o.image);
+  DeviceGuard g(ctx->device);
+  auto upload = [&](void** dptr, const void* src, size_t bytes) -> bool {
+    if (bytes == 0) { *dptr = nullptr; return true; }
+    if (hipMalloc(dptr, bytes) != hipSuccess) return false;
+    return hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  const Compiled& h = job->host;
+  const bool ok = upload(reinterpret_cast<void**>(&job->d_ops), h.ops.data(), h.ops.size() * sizeof(DevOp)) &&
+                  upload(reinterpret_cast<void**>(&job->d_cells), h.cells.data(), h.cells.size() * sizeof(DevCell)) &&
+                  upload(reinterpret_cast<void**>(&job->d_stacks), h.stacks.data(), h.stacks.size() * sizeof(int32_t));
+  if (!ok) {
+    fail(IST_E_HIP, "uploading the op tables failed");
+    ist_job_destroy(job.release());
+    return nullptr;
+  }
+  return job.release();
+}
+
+int ist_job_info_get(const ist_job* job, ist_job_info* out) {
+  if (!job || !out) return fail(IST_E_INVALID, "ist_job_info_get: NULL argument");
+  *out = job->host.info;
+  return IST_OK;
+}
+
+int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch, int n_images, void* dst,
+                   size_t dst_pitch, void* stream) {
+  if (!job || !dst) return fail(IST_E_INVALID, "ist_job_launch: NULL argument");
+  if (n_images <= job->max_image) return fail(IST_E_DECODE, "图片" + std::to_string(job->max_image) + "解码异常: source table too short");
+  if (n_images > kMaxImages) return fail(IST_E_UNSUPPORTED, "more than 128 images in one launch");
+  const Compiled& h = job->host;
+  // only the rendered region is ever addressed, so a compact band buffer (pitch = region width) is legal when the
+  // caller biases dst by -(ry0*pitch + rx0*4)
+  if (dst_pitch < static_cast<size_t>(h.rx1 - h.rx0) * 4 || (dst_pitch & 3)) return fail(IST_E_INVALID, "dst_pitch too small or not a multiple of 4");
+  LaunchArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.dst = static_cast<uint8_t*>(dst);
+  a.dst_pitch = dst_pitch;
+  a.ops = job->d_ops; a.cells = job->d_cells; a.stacks = job->d_stacks;
+  a.n_cells = static_cast<int32_t>(h.cells.size());
+  a.filter = h.filter;
+  for (const DevOp& o : h.ops) {
+    if (o.image < 0) continue;
+    const int i = o.image;
+    if (!src || !src[i]) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常");
+    const size_t p = src_pitch ? src_pitch[i] : static_cast<size_t>(h.img_w[i]) * 4;
+    if (p < static_cast<size_t>(h.img_w[i]) * 4 || (p & 3)) return fail(IST_E_INVALID, "src_pitch too small or not a multiple of 4");
+    if ((reinterpret_cast<uintptr_t>(src[i]) & 3) != 0) return fail(IST_E_INVALID, "source pixels must be 4-byte aligned");
+    a.src[i] = static_cast<const uint8_t*>(src[i]);
+    a.pitch[i] = p;
+  }
+  if ((reinterpret_cast<uintptr_t>(dst) & 3) != 0) return fail(IST_E_INVALID, "dst must be 4-byte aligned");
+  DeviceGuard g(job->ctx->device);
+  if (!g.ok) return fail(IST_E_NO_DEVICE, "hipSetDevice failed");
+  return launch_stitch(a, h.info.n_tiles, stream);
+}
+
+void ist_job_destroy(ist_job* job) {
+  if (!job) return;
+  if (job->ctx) {
+    DeviceGuard g(job->ctx->device);
+    if (job->d_ops) (void)hipFree(job->d_ops);
+    if (job->d_cells) (void)hipFree(job->d_cells);
+    if (job->d_stacks) (void)hipFree(job->d_stacks);
+  }
+  delete job;
+}
+
+int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
+                     const ist_op* ops, int n_ops, const ist_image_desc* images, const uint8_t* const* src,
+                     const size_t* src_pitch, int n_images, int filter, const ist_region* region, uint8_t* dst,
+                     size_t dst_pitch) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (!dst) return fail(IST_E_INVALID, "ist_render_rgba8: dst is NULL");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ist_job* job = ist_job_create(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, n_images, filter, region);
+  if (!job) return g_last_code ? g_last_code : IST_E_INVALID;
+  struct JobFree { ist_job* j; ~JobFree() { ist_job_destroy(j); } } jf{job};
+  DeviceGuard g(ctx->device);
+
+  // stage the sources that the job actually samples
+  std::vector<size_t> off(static_cast<size_t>(n_images), 0);
+  std::vector<char> used(static_cast<size_t>(n_images), 0);
+  for (const DevOp& o : job->host.ops) if (o.image >= 0) used[o.image] = 1;
+  size_t total = 0;
+  for (int i = 0; i < n_images; ++i) {
+    if (!used[i]) continue;
+    if (!src || !src[i]) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常");
+    off[i] = total;
+    total += (static_cast<size_t>(job->host.img_w[i]) * 4 * job->host.img_h[i] + 255) & ~static_cast<size_t>(255);
+  }
+  int rc = grow(&ctx->scratch_src, &ctx->scratch_src_bytes, total ? total : 256);
+  if (rc) return rc;
+  const size_t canvas_pitch = static_cast<size_t>(canvas_w) * 4;
+  rc = grow(&ctx->scratch_dst, &ctx->scratch_dst_bytes, canvas_pitch * static_cast<size_t>(canvas_h));
+  if (rc) return rc;
+  std::vector<const void*> dsrc(static_cast<size_t>(n_images), nullptr);
+  std::vector<size_t> dpitch(static_cast<size_t>(n_images), 0);
+  for (int i = 0; i < n_images; ++i) {
+    if (!used[i]) continue;
+    const size_t row = static_cast<size_t>(job->host.img_w[i]) * 4;
+    const size_t hp = src_pitch ? src_pitch[i] : row;
+    if (hp < row) return fail(IST_E_INVALID, "src_pitch too small");
+    uint8_t* d = static_cast<uint8_t*>(ctx->scratch_src) + off[i];
+    IST_HIP(hipMemcpy2DAsync(d, row, src[i], hp, row, static_cast<size_t>(job->host.img_h[i]), hipMemcpyHostToDevice, ctx->stream));
+    dsrc[i] = d; dpitch[i] = row;
+  }
+  rc = ist_job_launch(job, dsrc.data(), dpitch.data(), n_images, ctx->scratch_dst, canvas_pitch, ctx->stream);
+  if (rc) return rc;
+  // readback of the requested region (same-size export, index.js:1577-1579; or getImageData, 1564)
+  int64_t rx = 0, ry = 0, rw = canvas_w, rh = canvas_h;
+  if (region) {
+    rx = std::max<int64_t>(0, region->x); ry = std::max<int64_t>(0, region->y);
+    rw = std::min<int64_t>(canvas_w, static_cast<int64_t>(region->x) + region->w) - rx;
+    rh = std::min<int64_t>(canvas_h, static_cast<int64_t>(region->y) + region->h) - ry;
+  }
+  if (dst_pitch < static_cast<size_t>(rw) * 4) return fail(IST_E_INVALID, "dst_pitch too small");
+  const uint8_t* from = static_cast<const uint8_t*>(ctx->scratch_dst) + static_cast<size_t>(ry) * canvas_pitch + static_cast<size_t>(rx) * 4;
+  IST_HIP(hipMemcpy2DAsync(dst, dst_pitch, from, canvas_pitch, static_cast<size_t>(rw) * 4, static_cast<size_t>(rh), hipMemcpyDeviceToHost, ctx->stream));
+  IST_HIP(hipStreamSynchronize(ctx->stream));
+  return IST_OK;
+}
+
+int ist_stitch_rgba8(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch,
+                     int n_images, int direction, int mode, double gap, const ist_limits* limits, int filter,
+                     ist_plan* out_plan, uint8_t** out_pixels) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (!out_plan || !out_pixels) return fail(IST_E_INVALID, "ist_stitch_rgba8: NULL output");
+  *out_pixels = nullptr;
+  ist_limits lim;
+  if (limits) lim = *limits; else ist_limits_unlimited(&lim);
+  int rc = ist_plan_compute(images, n_images, direction, mode, gap, &lim, out_plan);
+  if (rc != IST_OK) return rc;
+  std::vector<ist_op> ops(static_cast<size_t>(out_plan->n_rects) + 1);
+  int n_ops = 0;
+  rc = ist_plan_ops(out_plan, images, n_images, ops.data(), &n_ops);
+  if (rc != IST_OK) { ist_plan_free(out_plan); return rc; }
+  const size_t pitch = static_cast<size_t>(out_plan->canvas_w) * 4;
+  uint8_t* px = static_cast<uint8_t*>(std::malloc(pitch * static_cast<size_t>(out_plan->canvas_h)));
+  if (!px) { ist_plan_free(out_plan); return fail(IST_E_NOMEM, "out of memory for the output canvas"); }
+  static const uint8_t transparent[4] = {0, 0, 0, 0};
+  rc = ist_render_rgba8(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, images, src,
+                        src_pitch, n_images, filter, nullptr, px, pitch);
+  if (rc != IST_OK) { std::free(px); ist_plan_free(out_plan); return rc; }
+  *out_pixels = px;
+  return IST_OK;
+}
+
+}  // extern "C"

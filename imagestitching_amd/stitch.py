@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's stitch surface, over the C-ABI (no pixel arithmetic in Python).
+
+Reference: Page.onStitch (miniprogram-stitch/miniprogram/pages/index/index.js:1186-1633) reads
+this.data.{images, direction, gap, verticalStitchMode, horizontalStitchMode}; here that is
+`stitch(images, direction, opts)` with opts = {mode, gap, platform, maxSide, maxPixels, superSample, filter}.
+
+Two ways in:
+  stitch(images, direction, opts)      host RGBA8 arrays in, host RGBA8 array out   (ist_stitch_rgba8)
+  Stitcher(device).compile(...)        device-resident: torch CUDA tensors in/out, one fused launch per call
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_DIRECTIONS = {"vertical": L.VERTICAL, "horizontal": L.HORIZONTAL}
+_MODES = {"min": L.MODE_MIN, "max": L.MODE_MAX, "original": L.MODE_ORIGINAL}
+_FILTERS = {"nearest": L.FILTER_NEAREST, "bilinear": L.FILTER_BILINEAR}
+_PLATFORMS = {"ios": L.PLATFORM_IOS, "android": L.PLATFORM_ANDROID, "devtools": L.PLATFORM_OTHER,
+              "windows": L.PLATFORM_OTHER, "mac": L.PLATFORM_OTHER, "other": L.PLATFORM_OTHER}
+
+DEFAULT_OPTS = {
+    "mode": "min",          # data.verticalStitchMode / horizontalStitchMode default (index.js:19-20)
+    "gap": 0,               # data.gap default (index.js:17)
+    "filter": "bilinear",   # imageSmoothingEnabled = true (index.js:1416-1418)
+    "platform": None,       # None: MI355X default = caps lifted; 'ios' / 'android' / 'devtools' reproduce the phone caps
+    "maxSide": None,        # deviceMaxCanvasSize override
+    "maxPixels": None,      # deviceMaxCanvasPixels override
+    "superSample": None,    # None: 1 when platform is None, reference rule (index.js:1363) otherwise
+}
+
+
+def _limits(opts):
+    lim = L.Limits()
+    if opts.get("platform") is None:
+        L.lib.ist_limits_unlimited(C.byref(lim))
+    else:
+        L.lib.ist_limits_default(_PLATFORMS[opts["platform"]], C.byref(lim))
+    if opts.get("maxSide") is not None:
+        lim.max_side = float(opts["maxSide"])
+    if opts.get("maxPixels") is not None:
+        lim.max_pixels = float(opts["maxPixels"])
+    if opts.get("superSample") is not None:
+        lim.max_super_sample = float(opts["superSample"])
+    return lim
+
+
+def _merge(opts):
+    o = dict(DEFAULT_OPTS)
+    if opts:
+        unknown = set(opts) - set(o)
+        if unknown:
+            raise TypeError("unknown stitch option(s): %s" % sorted(unknown))
+        o.update(opts)
+    return o
+
+
+def _descs(images):
+    """images: list of {'width','height','orientation'?,'fileSize'?,'opaque'?,'data'?} or HxWx4 uint8 arrays."""
+    arr = (L.ImageDesc * max(1, len(images)))()
+    for i, im in enumerate(images):
+        if isinstance(im, dict):
+            data = im.get("data")
+            w = im.get("width", data.shape[1] if hasattr(data, "shape") else 0)
+            h = im.get("height", data.shape[0] if hasattr(data, "shape") else 0)
+            bw = im.get("bmpWidth", data.shape[1] if hasattr(data, "shape") and data.ndim == 3 else 0)
+            bh = im.get("bmpHeight", data.shape[0] if hasattr(data, "shape") and data.ndim == 3 else 0)
+            arr[i] = L.ImageDesc(int(w or 0), int(h or 0), int(im.get("orientation", 1) or 0), int(bw or 0), int(bh or 0),
+                                 1 if im.get("opaque") else 0, int(im.get("fileSize", 0) or 0))
+        else:
+            arr[i] = L.ImageDesc(int(im.shape[1]), int(im.shape[0]), 1, 0, 0, 0, 0)
+    return arr
+
+
+class StitchPlan:
+    """Result of the planner (index.js stage 2 + rect loop).  Owns the C plan; freed on garbage collection."""
+
+    def __init__(self, cplan, descs, n_images):
+        self._c = cplan
+        self._descs = descs
+        self.n_images = n_images
+        self.out_w, self.out_h = cplan.out_w, cplan.out_h
+        self.scale_down, self.super_sample = cplan.scale_down, cplan.super_sample
+        self.canvas_w, self.canvas_h = int(cplan.canvas_w), int(cplan.canvas_h)
+        self.big_task = bool(cplan.big_task)
+        self.rects = [{"image": r.image, "orientation": r.orientation, "dx": r.dx, "dy": r.dy, "dw": r.dw, "dh": r.dh}
+                      for r in cplan.rects[:cplan.n_rects]]
+
+    def ops(self):
+        """The Canvas call sequence (white fill + one drawImage per rect with its CTM) as C ops."""
+        n = self._c.n_rects + 1
+        arr = (L.Op * n)()
+        cnt = C.c_int(0)
+        L.check(L.lib.ist_plan_ops(C.byref(self._c), self._descs, self.n_images, arr, C.byref(cnt)))
+        return arr, cnt.value
+
+    def ops_as_dicts(self):
+        arr, n = self.ops()
+        return [{"kind": "fill" if o.kind == 0 else "draw", "image": o.image, "m": list(o.m), "s": list(o.s),
+                 "d": list(o.d), "rgba": tuple(o.rgba)} for o in arr[:n]]
+
+    def __del__(self):
+        try:
+            L.lib.ist_plan_free(C.byref(self._c))
+        except Exception:
+            pass
+
+
+def plan(images, direction, opts=None):
+    """Pure-CPU planner.  Returns a StitchPlan, or None when there is nothing to stitch (index.js:1189)."""
+    o = _merge(opts)
+    descs = _descs(images)
+    cplan = L.Plan()
+    lim = _limits(o)
+    rc = L.check(L.lib.ist_plan_compute(descs, len(images), _DIRECTIONS[direction], _MODES[o["mode"]], float(o["gap"] or 0),
+                                        C.byref(lim), C.byref(cplan)))
+    if rc == L.IST_NOTHING_TO_DO:
+        return None
+    return StitchPlan(cplan, descs, len(images))
+
+
+_ctx_cache = {}
+
+
+def _ctx(device=0):
+    c = _ctx_cache.get(device)
+    if c is None:
+        c = L.lib.ist_ctx_create(int(device))
+        if not c:
+            raise L.StitchError(-5, L.last_error())
+        _ctx_cache[device] = c
+    return c
+
+
+def stitch(images, direction, opts=None, device=0):
+    """stitch(images, direction, opts) -> {'width', 'height', 'data'}: host arrays through the HIP path.
+
+    images[i] = {'width', 'height', 'data': HxWx4 uint8 (RGBA, straight alpha), 'orientation'?: 1..8, 'fileSize'?}
+    or simply an HxWx4 uint8 array.  Returns None when images is empty (the reference returns early).
+    """
+    o = _merge(opts)
+    n = len(images)
+    if n == 0:
+        return None
+    descs = _descs(images)
+    keep, ptrs, pitches = [], (C.c_void_p * n)(), (C.c_size_t * n)()
+    for i, im in enumerate(images):
+        a = im["data"] if isinstance(im, dict) else im
+        if a is None:
+            raise L.StitchError(-6, "图片%d解码异常" % i)
+        a = np.asarray(a)
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 4:
+            raise TypeError("image %d: expected an HxWx4 uint8 RGBA array" % i)
+        if a.strides[2] != 1 or a.strides[1] != 4:
+            a = np.ascontiguousarray(a)
+        keep.append(a)
+        ptrs[i] = a.ctypes.data
+        pitches[i] = a.strides[0]
+    cplan = L.Plan()
+    lim = _limits(o)
+    out = C.POINTER(C.c_uint8)()
+    rc = L.check(L.lib.ist_stitch_rgba8(_ctx(device), descs, ptrs, pitches, n, _DIRECTIONS[direction], _MODES[o["mode"]],
+                                        float(o["gap"] or 0), C.byref(lim), _FILTERS[o["filter"]], C.byref(cplan), C.byref(out)))
+    if rc == L.IST_NOTHING_TO_DO:
+        return None
+    try:
+        w, h = int(cplan.canvas_w), int(cplan.canvas_h)
+        data = np.ctypeslib.as_array(out, shape=(h, w, 4)).copy()
+    finally:
+        L.lib.ist_free(out)
+        L.lib.ist_plan_free(C.byref(cplan))
+    return {"width": w, "height": h, "data": data}
+
+
+class StitchJob:
+    """A compiled op list on one device: re-launchable on new source / destination buffers with no upload."""
+
+    def __init__(self, ctx, handle, n_images):
+        self._ctx, self._h, self.n_images = ctx, handle, n_images
+        info = L.JobInfo()
+        L.check(L.lib.ist_job_info_get(handle, C.byref(info)))
+        self.info = {k: getattr(info, k) for k, _ in L.JobInfo._fields_}
+        self.canvas_w, self.canvas_h = int(info.canvas_w), int(info.canvas_h)
+        self._src = (C.c_void_p * max(1, n_images))()
+        self._pitch = (C.c_size_t * max(1, n_images))()
+
+    def launch_ptrs(self, src_ptrs, src_pitches, dst_ptr, dst_pitch, stream=0):
+        for i, (p, q) in enumerate(zip(src_ptrs, src_pitches)):
+            self._src[i] = p
+            self._pitch[i] = q
+        L.check(L.lib.ist_job_launch(self._h, self._src, self._pitch, self.n_images, C.c_void_p(dst_ptr), dst_pitch,
+                                     C.c_void_p(stream)))
+
+    def launch(self, srcs, out, stream=None):
+        """srcs: list of HxWx4 uint8 CUDA tensors (None for images the job does not sample); out: canvas tensor."""
+        import torch
+        st = stream if stream is not None else torch.cuda.current_stream(out.device)
+        ptrs = [0 if t is None else t.data_ptr() for t in srcs]
+        pitches = [0 if t is None else t.stride(0) for t in srcs]
+        self.launch_ptrs(ptrs, pitches, out.data_ptr(), out.stride(0), st.cuda_stream)
+
+    def close(self):
+        if self._h:
+            L.lib.ist_job_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Stitcher:
+    """Device-resident stitcher: one per GPU (one process per GPU in the multi-GPU layout)."""
+
+    def __init__(self, device=0):
+        self.device = int(device)
+        self._ctx = _ctx(self.device)
+
+    def compile_ops(self, canvas_w, canvas_h, ops, n_ops, descs, n_images, filter="bilinear", clear=(0, 0, 0, 0), clip=None):
+        clr = (C.c_uint8 * 4)(*clear)
+        region = None
+        if clip is not None:
+            region = C.byref(L.Region(*[int(v) for v in clip]))
+        h = L.lib.ist_job_create(self._ctx, int(canvas_w), int(canvas_h), clr, ops, int(n_ops), descs, int(n_images),
+                                 _FILTERS[filter] if isinstance(filter, str) else int(filter), region)
+        if not h:
+            raise L.StitchError(-1, L.last_error())
+        return StitchJob(self._ctx, h, n_images)
+
+    def compile(self, images, direction, opts=None, only_images=None):
+        """Plan + compile.  only_images: iterable of image indices this device renders (multi-GPU sharding);
+        the other rects are dropped from the op list (their canvas area is left to whoever owns them)."""
+        o = _merge(opts)
+        p = plan(images, direction, o)
+        if p is None:
+            return None, None
+        ops, n_ops = p.ops()
+        if only_images is not None:
+            keep = set(int(i) for i in only_images)
+            sel = [ops[0]] + [ops[k] for k in range(1, n_ops) if ops[k].image in keep]
+            ops = (L.Op * len(sel))(*sel)
+            n_ops = len(sel)
+        job = self.compile_ops(p.canvas_w, p.canvas_h, ops, n_ops, p._descs, len(images), o["filter"])
+        return p, job

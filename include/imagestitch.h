@@ -1,0 +1,166 @@
+/*
+ * imagestitch.h — C-ABI of the MI355X-native strip stitcher (libimagestitch.so).
+ *
+ * This is the drop-in boundary for ONE path of Iamctb/ImageStitching: the Canvas-2D strip concatenation in
+ * Page.onStitch (plan -> per-image resample -> row/column blit into one buffer -> readback).  The reference has
+ * no FFI of its own (it is a WeChat mini-program: JavaScript calling the platform Canvas); the seam is the set
+ * of Canvas calls onStitch issues.  Every entry point below names the reference code it replaces; paths are
+ * relative to miniprogram-stitch/miniprogram/ in the reference repository.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures (a stream is passed as void* = hipStream_t);
+ *   - return 0 on success, a negative IST_E_* code on failure; ist_last_error() gives the thread-local message
+ *     (the reference throws Error(msg) into one catch that toasts '拼图失败：'+msg, pages/index/index.js:1618-1624);
+ *   - the caller owns every pixel buffer; the library owns only what it returns through ist_*_create /
+ *     ist_plan_compute and frees through the matching destroy/free call;
+ *   - pixels are RGBA8, row-major, straight (non-premultiplied) alpha, top row first, as ImageData is;
+ *   - no CPU fallback exists: rendering entry points fail with IST_E_NO_DEVICE when no HIP device is present.
+ */
+#ifndef IMAGESTITCH_H_
+#define IMAGESTITCH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IST_API __attribute__((visibility("default")))
+
+#define IST_ABI_VERSION 1
+
+/* error codes */
+enum {
+  IST_OK = 0,
+  IST_NOTHING_TO_DO = 1,        /* onStitch returns early when images is empty (pages/index/index.js:1189) */
+  IST_E_INVALID = -1,           /* bad argument */
+  IST_E_SIZE_UNAVAILABLE = -2,  /* '图片尺寸不可用'   (pages/index/index.js:1254) */
+  IST_E_OUTPUT_SIZE = -3,       /* '输出尺寸计算失败' (pages/index/index.js:1320) */
+  IST_E_NO_CONTEXT = -4,        /* '无法获取绘图上下文' (pages/index/index.js:1412) */
+  IST_E_NO_DEVICE = -5,         /* 'OffscreenCanvas 不可用' analogue (utils/canvas.js:149): no HIP device / HIP failure */
+  IST_E_DECODE = -6,            /* '图片N解码异常' (pages/index/index.js:1513): a source bitmap is missing or 0-sized */
+  IST_E_UNSUPPORTED = -7,       /* a Canvas feature outside the path (non axis-aligned transform, translucent fill) */
+  IST_E_NOMEM = -8,
+  IST_E_HIP = -9
+};
+
+enum { IST_VERTICAL = 0, IST_HORIZONTAL = 1 };                    /* data.direction  (index.js:16)    */
+enum { IST_MODE_MIN = 0, IST_MODE_MAX = 1, IST_MODE_ORIGINAL = 2 };/* data.*StitchMode (index.js:19-20) */
+enum { IST_PLATFORM_OTHER = 0, IST_PLATFORM_IOS = 1, IST_PLATFORM_ANDROID = 2 }; /* sys.platform       */
+enum { IST_OP_FILL = 0, IST_OP_DRAW = 1, IST_OP_HOLE = 2 };
+enum { IST_FILTER_NEAREST = 0, IST_FILTER_BILINEAR = 1 };         /* imageSmoothingEnabled false / true (index.js:1416-1418) */
+
+/* per-image record: the five fields the planner reads (index.js:724-739, 1194, 1211, 1252-1253, 1522-1523, 1532) */
+typedef struct ist_image_desc {
+  int32_t width, height;      /* naturalWidth, naturalHeight */
+  int32_t orientation;        /* EXIF 1..8; 0 = unset (treated as 1, utils/canvas.js:155) */
+  int32_t bmp_width, bmp_height; /* decoded bitmap size (bmp.width/height); 0 = same as natural */
+  int32_t opaque;             /* caller's hint: every alpha byte is 255 (JPEG-decoded photos). Never changes results. */
+  int64_t file_size;          /* bytes; feeds bigTask (index.js:1211-1212); 0 if unknown */
+} ist_image_desc;
+
+/* device caps: this.deviceMaxCanvasSize / deviceMaxCanvasPixels + sys.platform (index.js:126-156, 1323-1336) */
+typedef struct ist_limits {
+  int32_t platform;
+  int32_t reserved;
+  double max_side;            /* 0 = unset -> reference fallback (android 4096, else 12288) */
+  double max_pixels;          /* 0 = unset -> reference fallback */
+  double max_super_sample;    /* <=0: reference rule (bigTask 1, ios 2.2, else 2.6; index.js:1363); >0 replaces it */
+} ist_limits;
+
+/* one drawWithOrientation call (utils/canvas.js:153): destination rectangle in user space */
+typedef struct ist_rect {
+  int32_t image, orientation;
+  double dx, dy, dw, dh;
+} ist_rect;
+
+/* result of the planner: index.js stage 2 (1251-1386) + the rect/cursor loop (1432-1433, 1522-1554) */
+typedef struct ist_plan {
+  double out_w, out_h;        /* targetW/H after caps (1360-1361) */
+  double scale_down;          /* 1337-1357 */
+  double super_sample;        /* 1360-1386 */
+  int64_t canvas_w, canvas_h; /* canvasOutW/H: offscreen canvas + export size (1373-1383, 1391, 1577-1579) */
+  int32_t big_task;           /* 1212 */
+  int32_t n_rects;
+  ist_rect* rects;            /* library-owned; ist_plan_free */
+} ist_plan;
+
+/* One recorded Canvas call, in canvas order.  kind 0: fillRect(d) with fillStyle rgba (index.js:1423-1424);
+ * kind 1: 9-argument drawImage(image, s, d) (utils/canvas.js:156); kind 2 (no Canvas analogue): rectangle d is
+ * left untouched by the launch because another producer delivers those pixels (a band received in place over
+ * xGMI in the multi-GPU layout).  m = CTM at the time of the call:
+ * X = m0*u + m2*v + m4,  Y = m1*u + m3*v + m5  (same order as ctx.setTransform(a,b,c,d,e,f), index.js:1404). */
+typedef struct ist_op {
+  int32_t kind, image;
+  double m[6];
+  double s[4];                /* sx, sy, sw, sh */
+  double d[4];                /* dx, dy, dw, dh */
+  uint8_t rgba[4];
+  int32_t reserved;
+} ist_op;
+
+typedef struct ist_region { int32_t x, y, w, h; } ist_region;    /* getImageData / export region (index.js:1564, 1577) */
+
+typedef struct ist_job_info {
+  int64_t canvas_w, canvas_h;
+  int32_t n_ops, n_cells;
+  int64_t n_tiles;
+  int64_t out_pixels;         /* pixels written per launch */
+  int64_t src_pixels_touched; /* distinct source pixels inside the sampling footprints */
+  int64_t algorithmic_bytes;  /* 4*src_pixels_touched + 4*out_pixels */
+  int64_t tiles_fill, tiles_copy, tiles_sample, tiles_general;
+} ist_job_info;
+
+typedef struct ist_ctx ist_ctx;   /* one HIP device + scratch */
+typedef struct ist_job ist_job;   /* one compiled op list (device-side cell/op tables) */
+
+/* ---- diagnostics ------------------------------------------------------------------------------------------ */
+IST_API int ist_abi_version(void);
+IST_API const char* ist_last_error(void);
+IST_API int ist_device_count(void);                                   /* 0 when no HIP device is usable */
+
+/* ---- planner: pure CPU, bit-exact to index.js:1211-1216, 1251-1386, 1432-1433, 1522-1554 -------------------- */
+IST_API void ist_limits_default(int platform, ist_limits* out);        /* index.js:126-156 fallback branch */
+IST_API void ist_limits_unlimited(ist_limits* out);                    /* MI355X default: caps lifted, superSample 1 */
+IST_API int ist_plan_compute(const ist_image_desc* images, int n_images, int direction, int mode, double gap,
+                             const ist_limits* limits, ist_plan* out);
+IST_API void ist_plan_free(ist_plan* plan);
+/* the Canvas call sequence stage 3-4 issues for a plan: white fillRect over the canvas (index.js:1423-1424),
+ * ctx.scale(ss,ss) folded into every CTM (1426-1428), one drawWithOrientation per rect (utils/canvas.js:153-202).
+ * ops must hold n_rects + 1 entries. */
+IST_API int ist_plan_ops(const ist_plan* plan, const ist_image_desc* images, int n_images, ist_op* ops, int* n_ops);
+
+/* ---- device path: inputs and output already resident in HBM ------------------------------------------------- */
+IST_API ist_ctx* ist_ctx_create(int device);
+IST_API void ist_ctx_destroy(ist_ctx* ctx);
+/* compile an op list for a canvas (replaces createOffscreenCanvas + the recorded draw calls; utils/canvas.js:131,
+ * index.js:1391-1428, 1532-1551).  clear_rgba = canvas initial colour ({0,0,0,0} for a fresh canvas).
+ * clip = NULL renders the whole canvas; otherwise only that region is written (getImageData(0,0,1,1), 1564). */
+IST_API ist_job* ist_job_create(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
+                                const ist_op* ops, int n_ops, const ist_image_desc* images, int n_images,
+                                int filter, const ist_region* clip);
+IST_API int ist_job_info_get(const ist_job* job, ist_job_info* out);
+/* one fused launch: every canvas pixel (in clip) is written exactly once.  src[i] / dst are DEVICE pointers.
+ * stream = hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
+IST_API int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch, int n_images,
+                           void* dst, size_t dst_pitch, void* stream);
+IST_API void ist_job_destroy(ist_job* job);
+
+/* ---- host path: what stitch(images, direction, opts) binds (host RGBA8 in, host RGBA8 out) ------------------- */
+/* index.js:1251-1581 minus decode (1441-1520) and PNG encode (1579): plan, then render.
+ * *out_pixels is malloc'ed by the library (canvas_w*canvas_h*4 bytes, pitch canvas_w*4); free with ist_free. */
+IST_API int ist_stitch_rgba8(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* const* src,
+                             const size_t* src_pitch, int n_images, int direction, int mode, double gap,
+                             const ist_limits* limits, int filter, ist_plan* out_plan, uint8_t** out_pixels);
+/* render a recorded Canvas op list into a caller buffer (the Canvas-2D shim's export / getImageData) */
+IST_API int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
+                             const ist_op* ops, int n_ops, const ist_image_desc* images,
+                             const uint8_t* const* src, const size_t* src_pitch, int n_images, int filter,
+                             const ist_region* region, uint8_t* dst, size_t dst_pitch);
+IST_API void ist_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMAGESTITCH_H_ */

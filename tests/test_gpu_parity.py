@@ -1,0 +1,193 @@
+"""HIP path vs CPU oracle, through the C-ABI.  Bit-exact for nearest; within +-1 LSB per channel for bilinear
+(BASELINE.json north_star).  Needs a real MI355X: run with -m gpu."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import imagestitching_amd as ist
+from imagestitching_amd import _lib as L
+from oracle import oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+BILINEAR_TOL = 1   # LSB per channel, stated by BASELINE.json north_star
+
+
+def _check(pixels, direction, opts=None, orientations=None):
+    opts = dict(opts or {})
+    ref, pd, rl = U.oracle_stitch(pixels, direction, opts, orientations)
+    got = ist.stitch(U.hip_images(pixels, orientations), direction, opts)
+    assert (got["width"], got["height"]) == (int(pd["canvas_w"]), int(pd["canvas_h"]))
+    out = got["data"]
+    assert out.shape == ref.shape
+    if opts.get("filter", "bilinear") == "nearest":
+        assert np.array_equal(out, ref), "nearest must be bit-exact (%d px differ)" % int((out != ref).any(-1).sum())
+    else:
+        d = U.max_abs_diff(out, ref)
+        assert d <= BILINEAR_TOL, "bilinear max |diff| = %d" % d
+    return out, ref
+
+
+def test_config1_3x640x480_vertical_nearest_exact():
+    """BASELINE configs[0]: 3 x 640x480 vertical, nearest, superSample 1 -> 640x1440, bit-exact."""
+    px = [O.synth_image(k, 480, 640) for k in range(3)]
+    out, _ = _check(px, "vertical", {"filter": "nearest"})
+    assert out.shape == (1440, 640, 4)
+    for k in range(3):   # identity plan: the strip is the concatenation
+        assert np.array_equal(out[480 * k:480 * (k + 1)], px[k])
+
+
+@pytest.mark.parametrize("filt", ["nearest", "bilinear"])
+@pytest.mark.parametrize("direction", ["vertical", "horizontal"])
+@pytest.mark.parametrize("mode", ["min", "max", "original"])
+def test_mixed_sizes(filt, direction, mode):
+    sizes = [(403, 302), (302, 403), (400, 300), (192, 108), (37, 211)]
+    px = [U.smooth_image(10 + i, h, w) if i % 2 else U.rand_image(10 + i, h, w) for i, (w, h) in enumerate(sizes)]
+    _check(px, direction, {"filter": filt, "mode": mode, "gap": 7})
+
+
+@pytest.mark.parametrize("filt", ["nearest", "bilinear"])
+@pytest.mark.parametrize("orientation", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_exif_orientations(filt, orientation):
+    """utils/canvas.js:160-200, including the reference's orientation-7 placement (drawn one rect-height up)."""
+    px = [U.rand_image(20, 45, 61), U.smooth_image(21, 83, 50), U.rand_image(22, 64, 64)]
+    for direction in ("vertical", "horizontal"):
+        _check(px, direction, {"filter": filt, "gap": 3}, orientations=[orientation] * 3)
+
+
+@pytest.mark.parametrize("filt", ["nearest", "bilinear"])
+def test_translucent_sources_source_over_white(filt):
+    px = [U.rand_image(30 + i, h, w, opaque=False) for i, (w, h) in enumerate([(120, 90), (90, 120), (64, 33)])]
+    _check(px, "vertical", {"filter": filt, "mode": "max", "gap": 5})
+    _check(px, "horizontal", {"filter": filt, "mode": "original", "gap": 0})
+
+
+@pytest.mark.parametrize("filt", ["nearest", "bilinear"])
+@pytest.mark.parametrize("platform", ["devtools", "ios", "android"])
+def test_reference_default_plans_supersample_and_caps(filt, platform):
+    """n<7 small images -> the reference super-samples (2.6 / 2.2); big ones -> scaleDown<1 with fractional cursors."""
+    px = [U.smooth_image(40 + i, 48, 64) for i in range(3)]
+    _check(px, "vertical", {"filter": filt, "platform": platform})
+    px = [U.rand_image(50 + i, h, w) for i, (w, h) in enumerate([(403, 302), (108, 192), (400, 300), (192, 108), (403, 302), (108, 192), (400, 300)])]
+    _check(px, "vertical", {"filter": filt, "platform": platform, "gap": 10, "maxSide": 512, "maxPixels": 512 * 300})
+    _check(px, "horizontal", {"filter": filt, "platform": platform, "gap": 10, "maxSide": 640, "maxPixels": 640 * 200, "mode": "original"})
+
+
+@pytest.mark.parametrize("filt", ["nearest", "bilinear"])
+def test_ragged_and_tiny(filt):
+    _check([U.rand_image(60, 1, 1)], "vertical", {"filter": filt})
+    _check([U.rand_image(61, 1, 1), U.rand_image(62, 3, 500), U.rand_image(63, 900, 7)], "vertical", {"filter": filt, "gap": 3})
+    _check([U.rand_image(64, 5, 3), U.rand_image(65, 9, 13), U.rand_image(66, 2, 2)], "horizontal", {"filter": filt, "mode": "max", "gap": 1})
+    _check([U.rand_image(67, 33, 257), U.rand_image(68, 65, 259)], "vertical", {"filter": filt, "mode": "max"})
+    _check([U.rand_image(69, 31, 1021)], "horizontal", {"filter": filt})
+
+
+def test_empty_input_returns_none():
+    assert ist.stitch([], "vertical") is None
+
+
+def test_missing_bitmap_is_decode_error():
+    with pytest.raises(ist.StitchError) as e:
+        ist.stitch([{"width": 4, "height": 4, "data": None}], "vertical")
+    assert e.value.code == -6 and "解码异常" in str(e.value)
+
+
+def test_strided_host_buffers():
+    """src pitch != width*4 (a view into a wider buffer)."""
+    big = U.rand_image(70, 50, 100)
+    view = big[:, 10:70]           # 60 px wide, pitch 400
+    other = U.rand_image(71, 40, 60)
+    ref, _, _ = U.oracle_stitch([np.ascontiguousarray(view), other], "vertical", {"filter": "nearest"})
+    got = ist.stitch([view, other], "vertical", {"filter": "nearest"})
+    assert np.array_equal(got["data"], ref)
+
+
+def _device_stitch(px, direction, opts, orientations=None):
+    import torch
+    st = ist.Stitcher(0)
+    p, job = st.compile(U.hip_images(px, orientations), direction, opts)
+    srcs = [torch.from_numpy(a).cuda() for a in px]
+    out = torch.empty((p.canvas_h, p.canvas_w, 4), dtype=torch.uint8, device="cuda")
+    out.fill_(0x5A)                      # poison: every pixel must be overwritten by the single launch
+    job.launch(srcs, out)
+    torch.cuda.synchronize()
+    return p, job, srcs, out
+
+
+def test_device_path_full_size_vertical_identity():
+    """BASELINE configs[1] at full size: 9 x 4032x3024 vertical bilinear. Size-independent property: with equal
+    widths the strip is exactly the concatenation of the inputs (bilinear at 1:1 is the identity)."""
+    import torch
+    px = [O.synth_image(k, 3024, 4032) for k in range(9)]
+    p, job, srcs, out = _device_stitch(px, "vertical", {"filter": "bilinear"})
+    assert (p.canvas_w, p.canvas_h) == (4032, 27216)
+    assert job.info["tiles_copy"] > 0 and job.info["tiles_sample"] == 0 and job.info["tiles_general"] == 0
+    assert job.info["algorithmic_bytes"] == 8 * 4032 * 27216
+    for k in range(9):
+        assert torch.equal(out[3024 * k:3024 * (k + 1)], srcs[k])
+
+
+def test_device_path_full_size_horizontal_identity():
+    """BASELINE configs[2]: 9 x 4032x3024 horizontal -> 36288x3024, column bands."""
+    import torch
+    px = [O.synth_image(k, 3024, 4032) for k in range(9)]
+    p, job, srcs, out = _device_stitch(px, "horizontal", {"filter": "bilinear"})
+    assert (p.canvas_w, p.canvas_h) == (36288, 3024)
+    for k in range(9):
+        assert torch.equal(out[:, 4032 * k:4032 * (k + 1)], srcs[k])
+
+
+@pytest.mark.parametrize("direction", ["vertical", "horizontal"])
+def test_device_path_full_size_mixed_bilinear_vs_oracle(direction):
+    """Supplementary mixed-size variant of configs 2/3 at full size, against the oracle."""
+    sizes = [(4032, 3024), (3024, 4032), (4000, 3000), (3840, 2160), (4032, 3024), (3024, 4032), (4000, 3000), (3840, 2160), (4032, 3024)]
+    px = [O.synth_image(k, h, w) for k, (w, h) in enumerate(sizes)]
+    ref, pd, _ = U.oracle_stitch(px, direction, {"filter": "bilinear"}, threads=16)
+    p, job, srcs, out = _device_stitch(px, direction, {"filter": "bilinear"})
+    got = out.cpu().numpy()
+    assert got.shape == ref.shape
+    step = 1 << 22     # compare in slabs to bound host memory
+    flat_g, flat_r = got.reshape(-1), ref.reshape(-1)
+    worst = 0
+    for s in range(0, flat_g.size, step * 4):
+        worst = max(worst, int(np.abs(flat_g[s:s + step * 4].astype(np.int16) - flat_r[s:s + step * 4].astype(np.int16)).max()))
+    assert worst <= BILINEAR_TOL
+
+
+def test_clip_region_like_getImageData():
+    """index.js:1564 getImageData(0,0,1,1): render only a region of the canvas."""
+    import torch
+    px = [U.rand_image(80, 60, 80), U.rand_image(81, 30, 40)]
+    ref, pd, _ = U.oracle_stitch(px, "vertical", {"filter": "bilinear", "mode": "max"})
+    st = ist.Stitcher(0)
+    p = ist.plan(U.hip_images(px), "vertical", {"mode": "max"})
+    ops, n_ops = p.ops()
+    for clip in [(0, 0, 1, 1), (17, 33, 41, 70), (79, 0, 1, 120)]:
+        job = st.compile_ops(p.canvas_w, p.canvas_h, ops, n_ops, p._descs, 2, "bilinear", clip=clip)
+        out = torch.full((p.canvas_h, p.canvas_w, 4), 0x5A, dtype=torch.uint8, device="cuda")
+        job.launch([torch.from_numpy(a).cuda() for a in px], out)
+        got = out.cpu().numpy()
+        x, y, w, h = clip
+        assert U.max_abs_diff(got[y:y + h, x:x + w], ref[y:y + h, x:x + w]) <= 1
+        mask = np.ones(got.shape[:2], bool)
+        mask[y:y + h, x:x + w] = False
+        assert (got[mask] == 0x5A).all(), "pixels outside the clip must not be written"
+
+
+def test_pitched_device_buffers():
+    import torch
+    px = [U.rand_image(90, 50, 64), U.rand_image(91, 20, 64)]
+    st = ist.Stitcher(0)
+    p, job = st.compile(U.hip_images(px), "vertical", {"filter": "nearest"})
+    wide = [torch.zeros((a.shape[0], a.shape[1] + 12, 4), dtype=torch.uint8, device="cuda") for a in px]
+    for t, a in zip(wide, px):
+        t[:, 4:4 + a.shape[1]] = torch.from_numpy(a).cuda()
+    srcs = [t[:, 4:4 + a.shape[1]] for t, a in zip(wide, px)]
+    canvas = torch.zeros((p.canvas_h, p.canvas_w + 8, 4), dtype=torch.uint8, device="cuda")
+    out = canvas[:, 8:]
+    job.launch(srcs, out)
+    ref, _, _ = U.oracle_stitch(px, "vertical", {"filter": "nearest"})
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert int(canvas[:, :8].max()) == 0
