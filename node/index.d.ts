@@ -1,0 +1,27 @@
+// TypeScript surface of the Node host (tsc is not part of the build image; this file is the typed contract).
+/// <reference types="node" />
+export type Direction = 'vertical' | 'horizontal';
+export type StitchMode = 'min' | 'max' | 'original';
+export interface StitchImage {
+  width: number;            // naturalWidth  (pages/index/index.js:724-739)
+  height: number;           // naturalHeight
+  data?: Uint8Array;        // RGBA8, straight alpha, row-major, width*height*4 bytes
+  orientation?: 1 | 2 | 3 | 4 | 5 | 6 | 7 | 8;
+  fileSize?: number;        // bytes, feeds bigTask (index.js:1211-1212)
+  opaque?: boolean;         // hint: all alpha bytes are 255
+  bmpWidth?: number; bmpHeight?: number;
+}
+export interface StitchOptions {
+  mode?: StitchMode; gap?: number; filter?: 'bilinear' | 'nearest';
+  platform?: 'ios' | 'android' | 'devtools' | 'windows' | 'mac' | 'other';
+  maxSide?: number; maxPixels?: number; superSample?: number;
+}
+export interface PlanRect { image: number; orientation: number; dx: number; dy: number; dw: number; dh: number; }
+export interface StitchPlan {
+  outW: number; outH: number; scaleDown: number; superSample: number; canvasW: number; canvasH: number;
+  bigTask: boolean; rects: PlanRect[];
+}
+export interface StitchResult { width: number; height: number; data: Buffer; plan: StitchPlan; }
+export function stitch(images: StitchImage[], direction: Direction, opts?: StitchOptions): Promise<StitchResult | null>;
+export function stitchSync(images: StitchImage[], direction: Direction, opts?: StitchOptions): StitchResult | null;
+export function plan(images: StitchImage[], direction: Direction, opts?: StitchOptions): StitchPlan | null;

@@ -1,0 +1,63 @@
+'use strict';
+/**
+ * Node host of the MI355X strip stitcher: the reference's stitch surface as one function.
+ *
+ * Reference: Page.onStitch (miniprogram-stitch/miniprogram/pages/index/index.js:1186-1633) reads
+ * this.data.{images, direction, gap, verticalStitchMode, horizontalStitchMode}.  Here:
+ *
+ *   stitch(images, direction, opts?) -> Promise<{width, height, data: Buffer, plan}>
+ *
+ * images[i] = {width, height, data: Uint8Array (RGBA8, straight alpha, row-major), orientation?: 1..8, fileSize?, opaque?}
+ * direction = 'vertical' | 'horizontal'                         (data.direction, index.js:16)
+ * opts      = {mode: 'min'|'max'|'original' (default 'min', index.js:19-20), gap: 0..20 (default 0, index.js:17),
+ *              filter: 'bilinear'|'nearest' (imageSmoothingEnabled, index.js:1416), platform: 'ios'|'android'|'devtools'
+ *              (reproduces the phone caps, index.js:1323-1336; default: caps lifted, superSample 1),
+ *              maxSide, maxPixels (deviceMaxCanvasSize/Pixels), superSample (MAX_SUPER_SAMPLE, index.js:1363)}
+ * Errors reject with Error('拼图失败：' + reason) like the reference's catch (index.js:1618-1624); err.code is the
+ * C-ABI code.  No pixel arithmetic happens in JavaScript; there is no CPU fallback.
+ */
+const path = require('path');
+const native = require(path.join(__dirname, 'imagestitch.node'));
+
+const DIRECTION = { vertical: 0, horizontal: 1 };
+const MODE = { min: 0, max: 1, original: 2 };
+const FILTER = { nearest: 0, bilinear: 1 };
+const PLATFORM = { other: 0, devtools: 0, windows: 0, mac: 0, ios: 1, android: 2 };
+const KNOWN = ['mode', 'gap', 'filter', 'platform', 'maxSide', 'maxPixels', 'superSample'];
+
+function limitsOf(opts) {
+  const o = opts || {};
+  const lim = {};
+  if (o.platform !== undefined && o.platform !== null) {
+    if (!(o.platform in PLATFORM)) throw new TypeError('unknown platform ' + o.platform);
+    lim.platform = PLATFORM[o.platform];
+  }
+  if (typeof o.maxSide === 'number') lim.maxSide = o.maxSide;
+  if (typeof o.maxPixels === 'number') lim.maxPixels = o.maxPixels;
+  if (typeof o.superSample === 'number') lim.superSample = o.superSample;
+  return Object.keys(lim).length ? lim : null;
+}
+
+function args(images, direction, opts) {
+  const o = opts || {};
+  for (const k of Object.keys(o)) if (!KNOWN.includes(k)) throw new TypeError('unknown stitch option ' + k);
+  if (!(direction in DIRECTION)) throw new TypeError("direction must be 'vertical' or 'horizontal'");
+  const mode = o.mode || 'min';                      // `|| 'min'` (index.js:1257)
+  if (!(mode in MODE)) throw new TypeError('unknown mode ' + mode);
+  const filter = o.filter || 'bilinear';
+  if (!(filter in FILTER)) throw new TypeError('unknown filter ' + filter);
+  return [images || [], DIRECTION[direction], MODE[mode], Number(o.gap) || 0, limitsOf(o), FILTER[filter]];
+}
+
+function stitch(images, direction, opts) {
+  let a;
+  try { a = args(images, direction, opts); } catch (e) { return Promise.reject(e); }
+  return native.stitch(...a);
+}
+function stitchSync(images, direction, opts) { return native.stitchSync(...args(images, direction, opts)); }
+function plan(images, direction, opts) {
+  const a = args(images, direction, opts);
+  return native.plan(a[0], a[1], a[2], a[3], a[4]);
+}
+
+module.exports = { stitch, stitchSync, plan, native, DIRECTION, MODE, FILTER, PLATFORM };
