@@ -14,10 +14,11 @@ batch_isend_irecv -> ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd.
 The render backend is injected so that the sharding / assembly logic can be covered on CPU with gloo
 (tests pass an oracle-backed renderer; the product default is the HIP path and nothing else).
 """
-import ctypes as C
+import importlib
 
 from . import _lib as L
-from . import stitch as S
+
+S = importlib.import_module(".stitch", __package__)   # the package attribute `stitch` is the function, not the module
 
 OP_FILL, OP_DRAW, OP_HOLE = 0, 1, 2
 
@@ -47,7 +48,8 @@ def _boxes(plan, filter_name):
         Y0, Y1 = math.ceil(min(ya, yb) - 0.5), math.ceil(max(ya, yb) - 0.5)
         X0, Y0 = max(X0, 0), max(Y0, 0)
         X1, Y1 = min(X1, plan.canvas_w), min(Y1, plan.canvas_h)
-        boxes[o.image] = (X0, Y0, X1, Y1, k)
+        if X1 > X0 and Y1 > Y0:          # a draw clipped away entirely (the reference's orientation-7 first image) has no band
+            boxes[o.image] = (X0, Y0, X1, Y1, k)
     return boxes
 
 
