@@ -136,11 +136,13 @@ def run_sharded(args):
     import torch.distributed as dist
     import imagestitching_amd as ist
     from imagestitching_amd import dist as D
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     local = int(os.environ.get("LOCAL_RANK", rank))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in UNIFORM]
     sh = D.ShardedStitch(imgs, "vertical", {"filter": "bilinear"}, rank, world, 0)
     be = D.HipBackend(sh, local)
@@ -184,7 +186,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--quick", action="store_true", help="headline config only")
     args = ap.parse_args()
-    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("IST_BENCH_FORCE_SHARDED"):
         run_sharded(args)
     else:
         run_single(args)

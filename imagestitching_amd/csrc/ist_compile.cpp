@@ -7,6 +7,8 @@
 // over which the paint stack is constant — so that one launch writes every output pixel exactly once.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "ist_internal.h"
@@ -96,12 +98,21 @@ static int64_t distinct_taps(double k, double o, int lo, int hi, int clo, int ch
   return static_cast<int64_t>(std::unique(idx.begin(), idx.end()) - idx.begin());
 }
 
+// FILL / COPY tile shape.  IST_COPY_TILE=WxH is a tuning knob for benchmarks (W = 256, 512, 1024, ...).
+static int g_tile_w = 256, g_tile_h = 32;
+static void read_tile_knob() {
+  const char* e = std::getenv("IST_COPY_TILE");
+  int w = 0, h = 0;
+  if (e && std::sscanf(e, "%dx%d", &w, &h) == 2 && w >= 256 && (w & (w - 1)) == 0 && h >= 1 && h <= 4096) { g_tile_w = w; g_tile_h = h; }
+}
+
 int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,
                 const ist_image_desc* images, int n_images, int filter, const ist_region* clip, Compiled* out) {
   if (canvas_w < 1 || canvas_h < 1 || canvas_w > (1 << 29) || canvas_h > 2147483647LL)
     return fail(IST_E_OUTPUT_SIZE, "输出尺寸计算失败: canvas size out of range");
   if (n_ops < 0 || (n_ops > 0 && !ops)) return fail(IST_E_INVALID, "compile_ops: bad op list");
   if (filter != IST_FILTER_NEAREST && filter != IST_FILTER_BILINEAR) return fail(IST_E_INVALID, "unknown filter");
+  read_tile_knob();
   out->canvas_w = canvas_w; out->canvas_h = canvas_h; out->filter = filter;
   out->ops.clear(); out->cells.clear(); out->stacks.clear();
   out->img_w.assign(static_cast<size_t>(n_images), 0);
@@ -226,8 +237,24 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     } else {
       cell.path = PATH_GENERAL;
     }
-    if (cell.path == PATH_GENERAL) { cell.tile_w = 64; cell.tile_h = 64; }
-    else { cell.tile_w = 256; cell.tile_h = 32; }
+    if (cell.path == PATH_SAMPLE && filter == IST_FILTER_BILINEAR && !std::getenv("IST_NO_LDS")) {
+      // stage the tile's source footprint in LDS when it fits 40 KiB with at least 8 output rows per tile
+      const DevOp& r = out->ops[cell.op];
+      const double akx = std::fabs(r.kx), aky = std::fabs(r.ky);
+      if (r.cx1 > r.cx0 && r.cy1 > r.cy0 && akx <= 4.0 && aky <= 8.0) {
+        const int64_t wl = (static_cast<int64_t>(std::floor(255.0 * akx)) + 3 + 3) & ~3LL;      // pixels per LDS row
+        int th = 0;
+        for (int t = 32; t >= 8; t -= 4) {
+          const int64_t fh = static_cast<int64_t>(std::floor((t - 1) * aky)) + 3;
+          if (wl * fh <= 10240) { th = t; break; }
+        }
+        if (th) { cell.path = PATH_SAMPLE_LDS; cell.tile_w = 256; cell.tile_h = th; }
+      }
+    }
+    if (cell.path == PATH_SAMPLE_LDS) {}
+    else if (cell.path == PATH_GENERAL) { cell.tile_w = 64; cell.tile_h = 64; }
+    else if (cell.path == PATH_SAMPLE) { cell.tile_w = 256; cell.tile_h = 32; }
+    else { cell.tile_w = g_tile_w; cell.tile_h = g_tile_h; }   // FILL / COPY: tile_w = 256 << n
     const int64_t w = cell.X1 - cell.X0, h = cell.Y1 - cell.Y0;
     cell.tiles_x = static_cast<int32_t>((w + cell.tile_w - 1) / cell.tile_w);
     const int64_t tiles_y = (h + cell.tile_h - 1) / cell.tile_h;
@@ -238,7 +265,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     switch (cell.path) {
       case PATH_FILL: info.tiles_fill += nt; break;
       case PATH_COPY: info.tiles_copy += nt; break;
-      case PATH_SAMPLE: info.tiles_sample += nt; break;
+      case PATH_SAMPLE: case PATH_SAMPLE_LDS: info.tiles_sample += nt; break;
       default: info.tiles_general += nt; break;
     }
     for (int k = 0; k < cell.stack_len; ++k) {

@@ -42,6 +42,7 @@ enum : int32_t {
   PATH_FILL = 0,      // constant colour
   PATH_COPY = 1,      // opaque constant under ONE 1:1 draw with integer offset: HBM copy (+ source-over if alpha<255)
   PATH_SAMPLE = 2,    // opaque constant under ONE axis-aligned draw, source x driven by canvas x
+  PATH_SAMPLE_LDS = 4, // PATH_SAMPLE (bilinear, moderate scale) with the tile's source footprint staged in LDS
   PATH_GENERAL = 3    // anything else: paint stack evaluated per pixel in canvas order (swap draws, overlaps,
                       // translucent canvas)
 };

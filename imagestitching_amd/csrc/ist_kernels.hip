@@ -18,6 +18,9 @@
 // Build: hipcc --offload-arch=gfx950 -ffp-contract=off (the fp64 coordinate math must not be fused).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "ist_internal.h"
 #include "ist_launch.h"
 
@@ -32,6 +35,8 @@ typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
 
 IST_DEV u32x4 ld16(const uint8_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(p)); }
 IST_DEV void st16(uint8_t* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a4*>(p)); }
+IST_DEV u32x4 ld16_plain(const uint8_t* p) { return *reinterpret_cast<const u32x4_a4*>(p); }
+IST_DEV void st16_plain(uint8_t* p, u32x4 v) { *reinterpret_cast<u32x4_a4*>(p) = v; }
 IST_DEV uint32_t ld4(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
 IST_DEV u32x2 ld8(const uint8_t* p) { return *reinterpret_cast<const u32x2_a4*>(p); }
 IST_DEV void st4(uint8_t* p, uint32_t v) { __builtin_nontemporal_store(v, reinterpret_cast<uint32_t*>(p)); }
@@ -59,9 +64,9 @@ IST_DEV uint32_t to_u8(float v) {
 }
 
 // bilinear blend of four straight-alpha taps, composited over a premultiplied destination pixel
-IST_DEV uint32_t bilerp_over(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, float tx, float ty, uint32_t d) {
-  const uint32_t amin = (p00 & p01 & p10 & p11) >> 24;
-  if (amin == 255u) {   // all taps opaque: plain bilinear, result replaces the destination
+// `opaque` (wave-uniform, the caller's hint for JPEG-decoded bitmaps) skips the per-pixel alpha test
+IST_DEV uint32_t bilerp_over(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, float tx, float ty, uint32_t d, bool opaque = false) {
+  if (opaque || ((p00 & p01 & p10 & p11) >> 24) == 255u) {   // all taps opaque: plain bilinear, result replaces the destination
     uint32_t o = 0xFF000000u;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -110,67 +115,84 @@ IST_DEV int nearest_tap(double k, double o, int w, int lo, int hi) {
   return min(max(static_cast<int>(fl), lo), hi);
 }
 
+// ragged right edge of a cell: the last lane of a row segment holds 1..3 pixels
+IST_DEV u32x4 ld_px(const uint8_t* p, int nv) {
+  if (nv >= 4) return ld16(p);
+  u32x4 v = {0u, 0u, 0u, 0u};
+  v.x = ld4(p);
+  if (nv > 1) v.y = ld4(p + 4);
+  if (nv > 2) v.z = ld4(p + 8);
+  return v;
+}
+IST_DEV void st_px(uint8_t* p, u32x4 v, int nv) {
+  if (nv >= 4) { st16(p, v); return; }
+  st4(p, v.x);
+  if (nv > 1) st4(p + 4, v.y);
+  if (nv > 2) st4(p + 8, v.z);
+}
+
+// A tile is walked as ITEMS: one item = one wave-row = 64 lanes x 4 px = 1 KiB of one canvas row.  Items are numbered
+// along the row first (tile width = 256 << lg px), so a wave's U consecutive items are contiguous bytes when lg > 0.
+// Everything but the lane offset is wave-uniform (scalar registers).
+#define IST_ITEM(k)                                             \
+  const int row_ = (k) >> lg, chunk_ = (k) & ((1 << lg) - 1);   \
+  const int X = X0 + (chunk_ << 8) + lane4, Y = Y0 + row_;      \
+  const int nv = X1 - X
+
 // ------------------------------------------------------------------------------------------------ FILL
-IST_DEV void tile_fill(const LaunchArgs& A, uint32_t colour, int X0, int Y0, int X1, int Y1) {
-  const int lane = threadIdx.x & 63;
+IST_DEV void tile_fill(const LaunchArgs& A, uint32_t colour, int lg, int X0, int Y0, int X1, int Y1) {
+  const int lane4 = (threadIdx.x & 63) * 4;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int X = X0 + lane * 4;
-  const int nv = X1 - X;
-  if (nv <= 0) return;
+  const int items = (Y1 - Y0) << lg;
   const u32x4 v = {colour, colour, colour, colour};
-  for (int Y = Y0 + wave; Y < Y1; Y += 4) {
-    uint8_t* d = A.dst + static_cast<size_t>(Y) * A.dst_pitch + static_cast<size_t>(X) * 4;
-    if (nv >= 4) st16(d, v);
-    else for (int p = 0; p < nv; ++p) st4(d + 4 * p, colour);
+  for (int k = wave; k < items; k += 4) {
+    IST_ITEM(k);
+    if (nv > 0) st_px(A.dst + static_cast<size_t>(Y) * A.dst_pitch + static_cast<size_t>(X) * 4, v, nv);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ COPY
-template <int U>
-IST_DEV void tile_copy(const LaunchArgs& A, const DevOp& op, uint32_t bg, int X0, int Y0, int X1, int Y1) {
-  const int lane = threadIdx.x & 63;
+// U = wave-rows in flight per wave; IL = consecutive items go to different waves (true) or to one wave (false);
+// NTL / NTS = non-temporal hint on loads / stores.
+template <int U, bool IL, bool NTL, bool NTS>
+IST_DEV void tile_copy(const LaunchArgs& A, const DevOp op, uint32_t bg, int lg, int X0, int Y0, int X1, int Y1) {
+  const int lane4 = (threadIdx.x & 63) * 4;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int X = X0 + lane * 4;
-  const int nv = X1 - X;
-  if (nv <= 0) return;
+  const int items = (Y1 - Y0) << lg;
   const size_t sp = A.pitch[op.image];
-  const uint8_t* s = A.src[op.image] + (static_cast<int64_t>(X) + static_cast<int64_t>(op.ox)) * 4 +
-                     static_cast<int64_t>(op.oy) * static_cast<int64_t>(sp);
-  uint8_t* d = A.dst + static_cast<size_t>(X) * 4;
+  const uint8_t* s = A.src[op.image] + static_cast<int64_t>(op.ox) * 4 + static_cast<int64_t>(op.oy) * static_cast<int64_t>(sp);
   const bool opaque = (op.flags & OPF_OPAQUE) != 0;
-  if (nv >= 4) {
-    for (int Y = Y0 + wave; Y < Y1; Y += 4 * U) {
-      u32x4 v[U];
+  for (int j = 0; j * 4 * U < items; ++j) {
+    u32x4 v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int y = Y + 4 * u;
-        if (y < Y1) v[u] = ld16(s + static_cast<size_t>(y) * sp);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int y = Y + 4 * u;
-        if (y < Y1) {
-          u32x4 o = v[u];
-          if (!opaque && ((o.x & o.y & o.z & o.w) >> 24) != 255u) {
-            o.x = over_int(o.x, bg); o.y = over_int(o.y, bg); o.z = over_int(o.z, bg); o.w = over_int(o.w, bg);
-          }
-          st16(d + static_cast<size_t>(y) * A.dst_pitch, o);
-        }
+    for (int u = 0; u < U; ++u) {
+      const int k = IL ? ((j * U + u) * 4 + wave) : ((j * 4 + wave) * U + u);
+      IST_ITEM(k);
+      if (k < items && nv > 0) {
+        const uint8_t* p = s + static_cast<size_t>(Y) * sp + static_cast<size_t>(X) * 4;
+        v[u] = nv >= 4 ? (NTL ? ld16(p) : ld16_plain(p)) : ld_px(p, nv);
       }
     }
-  } else {   // ragged right edge of the cell: at most one lane per row segment
-    for (int Y = Y0 + wave; Y < Y1; Y += 4)
-      for (int p = 0; p < nv; ++p) {
-        uint32_t v = ld4(s + static_cast<size_t>(Y) * sp + 4 * p);
-        if (!opaque) v = over_int(v, bg);
-        st4(d + static_cast<size_t>(Y) * A.dst_pitch + 4 * p, v);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = IL ? ((j * U + u) * 4 + wave) : ((j * 4 + wave) * U + u);
+      IST_ITEM(k);
+      if (k < items && nv > 0) {
+        u32x4 o = v[u];
+        if (!opaque && ((o.x & o.y & o.z & o.w) >> 24) != 255u) {
+          o.x = over_int(o.x, bg); o.y = over_int(o.y, bg); o.z = over_int(o.z, bg); o.w = over_int(o.w, bg);
+        }
+        uint8_t* q = A.dst + static_cast<size_t>(Y) * A.dst_pitch + static_cast<size_t>(X) * 4;
+        if (nv >= 4) { if (NTS) st16(q, o); else st16_plain(q, o); }
+        else st_px(q, o, nv);
       }
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ SAMPLE
 template <int FILTER>
-IST_DEV void tile_sample(const LaunchArgs& A, const DevOp& op, uint32_t bg, int X0, int Y0, int X1, int Y1) {
+IST_DEV void tile_sample(const LaunchArgs& A, const DevOp op, uint32_t bg, int X0, int Y0, int X1, int Y1) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int X = X0 + lane * 4;
@@ -219,8 +241,90 @@ IST_DEV void tile_sample(const LaunchArgs& A, const DevOp& op, uint32_t bg, int 
       } else {
         p00 = p01 = ld4(r0 + off); p10 = p11 = ld4(r1 + off);
       }
-      o[p] = bilerp_over(p00, p01, p10, p11, tx[p].t, ty.t, bg);
+      o[p] = bilerp_over(p00, p01, p10, p11, tx[p].t, ty.t, bg, (op.flags & OPF_OPAQUE) != 0);
     }
+    uint8_t* dp = d + static_cast<size_t>(Y) * A.dst_pitch;
+    if (nv >= 4) { const u32x4 v = {o[0], o[1], o[2], o[3]}; st16(dp, v); }
+    else { st4(dp, o[0]); if (nv > 1) st4(dp + 4, o[1]); if (nv > 2) st4(dp + 8, o[2]); }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ SAMPLE via LDS
+// Bilinear resample with the tile's source footprint staged in LDS: every needed source byte crosses the vector
+// memory path ONCE, as coalesced 16-B loads (the direct path above issues 8-byte gathers whose lanes straddle ~3x
+// as many cache lines), and the 16 taps per lane then come from LDS (ds_read2_b32).  The host sizes tile_h so that
+// the footprint fits kLdsWords; the kernel re-checks and falls back to the direct path if it ever does not.
+constexpr int kLdsWords = 10240;   // 40 KiB per workgroup -> 4 workgroups per CU
+
+IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int X0, int Y0, int X1, int Y1, uint32_t* lds) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  // footprint of the tile (wave-uniform): the taps are monotonic in X and in Y, so the corners bound it
+  const Tap xa = bilinear_tap(op.kx, op.ox, X0, op.cx0, op.cx1), xb = bilinear_tap(op.kx, op.ox, X1 - 1, op.cx0, op.cx1);
+  const Tap ya = bilinear_tap(op.ky, op.oy, Y0, op.cy0, op.cy1), yb = bilinear_tap(op.ky, op.oy, Y1 - 1, op.cy0, op.cy1);
+  const int fx0 = __builtin_amdgcn_readfirstlane(min(xa.base, xb.base)), fx1 = __builtin_amdgcn_readfirstlane(max(xa.base, xb.base) + 1);
+  const int fy0 = __builtin_amdgcn_readfirstlane(min(ya.base, yb.base)), fy1 = __builtin_amdgcn_readfirstlane(max(ya.base, yb.base) + 1);
+  const int fh = fy1 - fy0 + 1;
+  const int wl = (fx1 - fx0 + 4) & ~3;            // LDS row stride in pixels (multiple of 4: 16-B aligned rows)
+  if (wl * fh > kLdsWords || op.cx1 <= op.cx0 || op.cy1 <= op.cy0) {   // uniform; not expected (host sizes the tile)
+    tile_sample<IST_FILTER_BILINEAR>(A, op, bg, X0, Y0, X1, Y1);
+    return;
+  }
+  const size_t sp = A.pitch[op.image];
+  const uint8_t* src = A.src[op.image];
+  __syncthreads();                                // a previous tile of this workgroup may still be reading the LDS
+  // ---- stage: wave w takes footprint rows w, w+4, ...; a pass moves 64 lanes x 16 B = 256 px of one row.
+  // LDS-DMA (global_load_lds_dwordx4): per-lane global address, LDS destination = uniform base + lane*16, no VGPR
+  // staging, so every pass of the wave is in flight at once; one vmcnt(0) + barrier at the end.
+  const int chunks = wl >> 2;
+  for (int r = wave; r < fh; r += 4) {
+    const uint8_t* grow = src + static_cast<size_t>(fy0 + r) * sp;
+    uint32_t* lrow = lds + r * wl;
+    // reading up to 12 B past the last sampled column is harmless (next row of the same bitmap) except on the last
+    // sampled row, where it could leave the allocation: that row's edge pass goes through registers instead
+    const bool last_row = (fy0 + r) >= op.cy1;
+    for (int c0 = 0; c0 < chunks; c0 += 64) {
+      const int c = c0 + lane;
+      const int col = fx0 + 4 * c;
+      const bool edge = last_row && (fx0 + 4 * min(c0 + 63, chunks - 1) + 3 > op.cx1);    // wave-uniform
+      if (!edge) {
+        if (c < chunks)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t*)(grow + static_cast<size_t>(col) * 4),
+                                           (__attribute__((address_space(3))) uint32_t*)(lrow + 4 * c0), 16, 0, 0);
+      } else if (c < chunks) {
+        u32x4 v;
+        if (col + 3 <= op.cx1) v = ld16(grow + static_cast<size_t>(col) * 4);
+        else {
+          v.x = ld4(grow + static_cast<size_t>(min(col, op.cx1)) * 4);
+          v.y = ld4(grow + static_cast<size_t>(min(col + 1, op.cx1)) * 4);
+          v.z = ld4(grow + static_cast<size_t>(min(col + 2, op.cx1)) * 4);
+          v.w = ld4(grow + static_cast<size_t>(min(col + 3, op.cx1)) * 4);
+        }
+        *reinterpret_cast<u32x4*>(lrow + 4 * c) = v;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA is tracked by vmcnt only
+  __syncthreads();
+  // ---- resample from LDS
+  const int X = X0 + lane * 4;
+  const int nv = X1 - X;
+  if (nv <= 0) return;
+  int lx[4]; float wx[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const Tap t = bilinear_tap(op.kx, op.ox, min(X + p, X1 - 1), op.cx0, op.cx1);   // lanes past the edge reuse the last column
+    lx[p] = t.base - fx0; wx[p] = t.t;
+  }
+  uint8_t* d = A.dst + static_cast<size_t>(X) * 4;
+  const bool opaque = (op.flags & OPF_OPAQUE) != 0;
+  for (int Y = Y0 + wave; Y < Y1; Y += 4) {
+    const Tap ty = bilinear_tap(op.ky, op.oy, Y, op.cy0, op.cy1);
+    const uint32_t* r0 = lds + (ty.base - fy0) * wl;
+    const uint32_t* r1 = r0 + wl;
+    uint32_t o[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) o[p] = bilerp_over(r0[lx[p]], r0[lx[p] + 1], r1[lx[p]], r1[lx[p] + 1], wx[p], ty.t, bg, opaque);
     uint8_t* dp = d + static_cast<size_t>(Y) * A.dst_pitch;
     if (nv >= 4) { const u32x4 v = {o[0], o[1], o[2], o[3]}; st16(dp, v); }
     else { st4(dp, o[0]); if (nv > 1) st4(dp + 4, o[1]); if (nv > 2) st4(dp + 8, o[2]); }
@@ -230,10 +334,10 @@ IST_DEV void tile_sample(const LaunchArgs& A, const DevOp& op, uint32_t bg, int 
 // ------------------------------------------------------------------------------------------------ GENERAL
 // one pixel through the whole paint stack, in canvas order, on a premultiplied 8-bit destination (what an
 // immediate-mode Canvas with 8-bit premultiplied backing store does call by call)
-IST_DEV uint32_t pixel_general(const LaunchArgs& A, const DevCell& c, int X, int Y) {
+IST_DEV uint32_t pixel_general(const LaunchArgs& A, const DevCell c, int X, int Y) {
   uint32_t d = c.bg;
   for (int k = 0; k < c.stack_len; ++k) {
-    const DevOp& op = A.ops[A.stacks[c.stack_off + k]];
+    const DevOp op = A.ops[A.stacks[c.stack_off + k]];
     const bool sw = (op.flags & OPF_SWAP) != 0;
     const int wx = sw ? Y : X, wy = sw ? X : Y;
     const uint8_t* src = A.src[op.image];
@@ -261,7 +365,7 @@ IST_DEV uint32_t pixel_general(const LaunchArgs& A, const DevCell& c, int X, int
   return r | (g << 8) | (b << 16) | (a << 24);
 }
 
-IST_DEV void tile_general(const LaunchArgs& A, const DevCell& c, int X0, int Y0, int X1, int Y1) {
+IST_DEV void tile_general(const LaunchArgs& A, const DevCell c, int X0, int Y0, int X1, int Y1) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int X = X0 + lane;
@@ -271,34 +375,80 @@ IST_DEV void tile_general(const LaunchArgs& A, const DevCell& c, int X0, int Y0,
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
-__global__ __launch_bounds__(256) void ist_stitch_kernel(const LaunchArgs A) {
-  const int64_t tile = static_cast<int64_t>(blockIdx.x);
+enum : int { HAS_FILL = 1, HAS_COPY = 2, HAS_SAMPLE = 4, HAS_GENERAL = 8 };
+
+template <int PATHS, int V>
+IST_DEV void run_tile(const LaunchArgs& A, int64_t tile) {
   // cells are few (tens): binary search on the tile prefix with wave-uniform (scalar) loads
   int lo = 0, hi = A.n_cells - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
     if (A.cells[mid].tile_begin <= tile) lo = mid; else hi = mid - 1;
   }
-  const DevCell& c = A.cells[lo];
+  const DevCell c = A.cells[lo];       // by value: scalar loads once; a reference would be re-read after every store
   const int local = static_cast<int>(tile - c.tile_begin);
   const int trow = local / c.tiles_x, tcol = local - trow * c.tiles_x;
   const int X0 = c.X0 + tcol * c.tile_w, Y0 = c.Y0 + trow * c.tile_h;
   const int X1 = min(X0 + c.tile_w, c.X1), Y1 = min(Y0 + c.tile_h, c.Y1);
-  switch (c.path) {
-    case PATH_FILL: tile_fill(A, c.bg, X0, Y0, X1, Y1); break;
-    case PATH_COPY: tile_copy<8>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1); break;
-    case PATH_SAMPLE:
-      if (A.filter == IST_FILTER_NEAREST) tile_sample<IST_FILTER_NEAREST>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);
-      else tile_sample<IST_FILTER_BILINEAR>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);
-      break;
-    default: tile_general(A, c, X0, Y0, X1, Y1); break;
+  const int lg = 31 - __builtin_clz(c.tile_w >> 8);
+  const int path = c.path;
+  if ((PATHS & HAS_COPY) && path == PATH_COPY) {
+    const DevOp op = A.ops[c.op];
+    if (V == 0) tile_copy<8, false, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
+    else if (V == 1) tile_copy<8, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
+    else if (V == 2) tile_copy<4, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
+    else if (V == 3) tile_copy<16, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
+    else if (V == 4) tile_copy<8, true, false, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
+    else if (V == 5) tile_copy<8, true, true, false>(A, op, c.bg, lg, X0, Y0, X1, Y1);
+    else tile_copy<8, true, false, false>(A, op, c.bg, lg, X0, Y0, X1, Y1);
+  } else if ((PATHS & HAS_FILL) && path == PATH_FILL) {
+    tile_fill(A, c.bg, lg, X0, Y0, X1, Y1);
+  } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE_LDS) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
+    tile_sample_lds(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1, lds);
+  } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE) {
+    if (A.filter == IST_FILTER_NEAREST) tile_sample<IST_FILTER_NEAREST>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);
+    else tile_sample<IST_FILTER_BILINEAR>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);
+  } else if (PATHS & HAS_GENERAL) {
+    tile_general(A, c, X0, Y0, X1, Y1);
   }
 }
 
-int launch_stitch(const LaunchArgs& args, int64_t n_tiles, void* stream) {
+// PATHS: which cell kinds this instantiation can render (a job with only fill/copy cells gets the lean one: fewer
+// VGPRs); PERSIST: one block per tile (false) or a fixed grid striding over the tiles (true)
+template <int PATHS, int V, bool PERSIST>
+__global__ __launch_bounds__(256) void ist_stitch_kernel(const LaunchArgs A, const int64_t n_tiles) {
+  if (PERSIST) {
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) run_tile<PATHS, V>(A, t);
+  } else {
+    run_tile<PATHS, V>(A, static_cast<int64_t>(blockIdx.x));
+  }
+}
+
+template <int PATHS, int V, bool PERSIST>
+static void launch_one(const LaunchArgs& args, int64_t n_tiles, hipStream_t stream, int persist_blocks) {
+  const unsigned grid = PERSIST ? static_cast<unsigned>(std::min<int64_t>(n_tiles, persist_blocks)) : static_cast<unsigned>(n_tiles);
+  hipLaunchKernelGGL((ist_stitch_kernel<PATHS, V, PERSIST>), dim3(grid), dim3(256), 0, stream, args, n_tiles);
+}
+
+template <int PATHS>
+static void launch_variant(int v, bool persist, const LaunchArgs& a, int64_t n, hipStream_t s, int pb) {
+#define IST_CASE(N) case N: if (persist) launch_one<PATHS, N, true>(a, n, s, pb); else launch_one<PATHS, N, false>(a, n, s, pb); break;
+  switch (v) { IST_CASE(0) IST_CASE(1) IST_CASE(2) IST_CASE(3) IST_CASE(4) IST_CASE(5) default: IST_CASE(6) }
+#undef IST_CASE
+}
+
+int launch_stitch(const LaunchArgs& args, int64_t n_tiles, bool lean, void* stream) {
   if (n_tiles <= 0) return IST_OK;
-  hipLaunchKernelGGL(ist_stitch_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), args);
+  // tuning knobs (benchmarks only): IST_VARIANT = copy variant + 100 * persistent; IST_PERSIST_BLOCKS; IST_FULL_KERNEL
+  const int knob = std::getenv("IST_VARIANT") ? std::atoi(std::getenv("IST_VARIANT")) : 0;
+  const int pb = std::getenv("IST_PERSIST_BLOCKS") ? std::atoi(std::getenv("IST_PERSIST_BLOCKS")) : 2048;
+  const bool full = std::getenv("IST_FULL_KERNEL") != nullptr;
+  const int v = knob % 100;
+  const bool persist = knob >= 100;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (lean && !full) launch_variant<HAS_FILL | HAS_COPY>(v, persist, args, n_tiles, s, pb);
+  else launch_variant<HAS_FILL | HAS_COPY | HAS_SAMPLE | HAS_GENERAL>(v, persist, args, n_tiles, s, pb);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(IST_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return IST_OK;

@@ -23,7 +23,8 @@ struct LaunchArgs {
   size_t pitch[kMaxImages];
 };
 
-int launch_stitch(const LaunchArgs& args, int64_t n_tiles, void* stream);
+// lean = the job has only FILL / COPY cells (the instantiation without the resample paths is launched)
+int launch_stitch(const LaunchArgs& args, int64_t n_tiles, bool lean, void* stream);
 
 }  // namespace ist
 

@@ -158,7 +158,7 @@ int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch
   if ((reinterpret_cast<uintptr_t>(dst) & 3) != 0) return fail(IST_E_INVALID, "dst must be 4-byte aligned");
   DeviceGuard g(job->ctx->device);
   if (!g.ok) return fail(IST_E_NO_DEVICE, "hipSetDevice failed");
-  return launch_stitch(a, h.info.n_tiles, stream);
+  return launch_stitch(a, h.info.n_tiles, h.info.tiles_sample == 0 && h.info.tiles_general == 0, stream);
 }
 
 void ist_job_destroy(ist_job* job) {

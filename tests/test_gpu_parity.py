@@ -84,6 +84,34 @@ def test_ragged_and_tiny(filt):
     _check([U.rand_image(69, 31, 1021)], "horizontal", {"filter": filt})
 
 
+@pytest.mark.parametrize("filt", ["nearest", "bilinear"])
+def test_heavy_downscale_uses_the_direct_gather_path(filt):
+    """scale factors beyond the LDS-staging budget (kx > 4): the phone-capped plans shrink 12 MP photos 6.6x."""
+    px = [U.smooth_image(120, 300, 2000), U.rand_image(121, 260, 1900), U.rand_image(122, 90, 300)]
+    _check(px, "vertical", {"filter": filt, "mode": "min"})
+    _check(px, "horizontal", {"filter": filt, "mode": "min"})
+    _check(px, "vertical", {"filter": filt, "platform": "android", "maxSide": 256, "maxPixels": 256 * 256})
+
+
+def test_direct_gather_path_matches_when_lds_staging_is_disabled(monkeypatch):
+    monkeypatch.setenv("IST_NO_LDS", "1")
+    sizes = [(403, 302), (302, 403), (400, 300), (192, 108)]
+    px = [U.rand_image(130 + i, h, w, opaque=(i != 2)) for i, (w, h) in enumerate(sizes)]
+    for direction in ("vertical", "horizontal"):
+        _check(px, direction, {"filter": "bilinear", "mode": "max", "gap": 2})
+    _check(px, "vertical", {"filter": "bilinear"}, orientations=[2, 3, 4, 1])
+
+
+def test_lds_staged_path_edges():
+    """upscale (tiny footprints), flips (negative scale), 2-pixel sources, ragged widths, translucent taps."""
+    px = [U.rand_image(140, 7, 9), U.rand_image(141, 2, 2, opaque=False), U.smooth_image(142, 40, 1000), U.rand_image(143, 33, 517)]
+    _check(px, "vertical", {"filter": "bilinear", "mode": "max"})
+    _check(px, "vertical", {"filter": "bilinear", "mode": "max"}, orientations=[2, 3, 4, 2])
+    _check(px, "horizontal", {"filter": "bilinear", "mode": "max", "gap": 1})
+    _check([U.rand_image(144, 300, 700), U.rand_image(145, 450, 1050)], "vertical", {"filter": "bilinear", "mode": "min"})   # 1.5x down
+    _check([U.rand_image(146, 300, 700), U.rand_image(147, 1200, 2450)], "vertical", {"filter": "bilinear", "mode": "min"})  # 3.5x down
+
+
 def test_empty_input_returns_none():
     assert ist.stitch([], "vertical") is None
 
