@@ -161,6 +161,43 @@ def run_sharded(args):
     torch.cuda.synchronize()
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+
+    # phase breakdown (informational): slowest rank's local launches alone, no exchange
+    def local_only():
+        if rank == 0:
+            be.render_root(srcs, canvas)
+        else:
+            for i in sh.mine:
+                be.render_band(i, srcs)
+    for _ in range(3):
+        local_only()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        local_only()
+    torch.cuda.synchronize()
+    loc = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+    dist.all_reduce(loc, op=dist.ReduceOp.MAX)
+
+    # informational: N independent replicas (every GPU stitches a whole 9 x 12 MP job; no exchange) = the layout a
+    # stitching service would use when jobs are independent
+    st = ist.Stitcher(local)
+    p_full, job_full = st.compile(imgs, "vertical", {"filter": "bilinear"})
+    full_src = [s_ if s_ is not None else synth(k, w, h, dev) for k, ((w, h), s_) in enumerate(zip(UNIFORM, srcs))]
+    full_out = torch.empty((p_full.canvas_h, p_full.canvas_w, 4), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        job_full.launch(full_src, full_out)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        job_full.launch(full_src, full_out)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    rep = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+    dist.all_reduce(rep, op=dist.ReduceOp.MAX)
     if rank == 0:
         sec = float(dt.item()) / args.steps
         mp = sh.plan.canvas_w * sh.plan.canvas_h / 1e6
@@ -173,6 +210,10 @@ def run_sharded(args):
                                    "GPU 0 with one grouped RCCL send/recv batch (%d bands received in place)" % (world, in_place),
                        "timed_region": "per-rank band launches + gather + root launch; inputs resident in each owner's HBM"},
             "roofline": None, "cpu_baseline": None,
+            "extra": {"local_launches_only_ms_per_step": round(float(loc.item()) / args.steps * 1e3, 5),
+                      "exchange_ms_per_step_by_difference": round((float(dt.item()) - float(loc.item())) / args.steps * 1e3, 5),
+                      "replicas_no_exchange": {"MPs": round(world * mp / (float(rep.item()) / args.steps), 1), "scaling": "weak",
+                                               "note": "every GPU stitches its own whole 9x12 MP job"}},
         }
         print(json.dumps(line))
     dist.destroy_process_group()

@@ -99,7 +99,8 @@ static int64_t distinct_taps(double k, double o, int lo, int hi, int clo, int ch
 }
 
 // FILL / COPY tile shape.  IST_COPY_TILE=WxH is a tuning knob for benchmarks (W = 256, 512, 1024, ...).
-static int g_tile_w = 256, g_tile_h = 32;
+static int g_tile_w = 256, g_tile_h = 8;      // measured optimum on MI355X: ~64 KB of loads in flight per CU
+static const int64_t g_lds_budget_words = 6144;    // 24 KiB footprint budget per workgroup: measured optimum (IST_LDS_BUDGET bytes overrides)
 static void read_tile_knob() {
   const char* e = std::getenv("IST_COPY_TILE");
   int w = 0, h = 0;
@@ -114,7 +115,8 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
   if (filter != IST_FILTER_NEAREST && filter != IST_FILTER_BILINEAR) return fail(IST_E_INVALID, "unknown filter");
   read_tile_knob();
   out->canvas_w = canvas_w; out->canvas_h = canvas_h; out->filter = filter;
-  out->ops.clear(); out->cells.clear(); out->stacks.clear();
+  out->ops.clear(); out->cells.clear(); out->stacks.clear(); out->bands.clear();
+  out->lds_words = 0;
   out->img_w.assign(static_cast<size_t>(n_images), 0);
   out->img_h.assign(static_cast<size_t>(n_images), 0);
   for (int i = 0; i < n_images; ++i) {
@@ -238,17 +240,21 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
       cell.path = PATH_GENERAL;
     }
     if (cell.path == PATH_SAMPLE && filter == IST_FILTER_BILINEAR && !std::getenv("IST_NO_LDS")) {
-      // stage the tile's source footprint in LDS when it fits 40 KiB with at least 8 output rows per tile
+      // stage the tile's source footprint in LDS when it fits the budget with at least 4 output rows per tile
       const DevOp& r = out->ops[cell.op];
       const double akx = std::fabs(r.kx), aky = std::fabs(r.ky);
+      const int64_t budget = std::getenv("IST_LDS_BUDGET") ? std::atoll(std::getenv("IST_LDS_BUDGET")) / 4 : g_lds_budget_words;
       if (r.cx1 > r.cx0 && r.cy1 > r.cy0 && akx <= 4.0 && aky <= 8.0) {
         const int64_t wl = (static_cast<int64_t>(std::floor(255.0 * akx)) + 3 + 3) & ~3LL;      // pixels per LDS row
-        int th = 0;
-        for (int t = 32; t >= 8; t -= 4) {
+        int th = 0; int64_t need = 0;
+        for (int t = 32; t >= 4; t -= 4) {
           const int64_t fh = static_cast<int64_t>(std::floor((t - 1) * aky)) + 3;
-          if (wl * fh <= 10240) { th = t; break; }
+          if (wl * fh <= budget) { th = t; need = wl * fh; break; }
         }
-        if (th) { cell.path = PATH_SAMPLE_LDS; cell.tile_w = 256; cell.tile_h = th; }
+        if (th) {
+          cell.path = PATH_SAMPLE_LDS; cell.tile_w = 256; cell.tile_h = th;
+          out->lds_words = std::max<int32_t>(out->lds_words, static_cast<int32_t>(need));
+        }
       }
     }
     if (cell.path == PATH_SAMPLE_LDS) {}
@@ -258,8 +264,22 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     const int64_t w = cell.X1 - cell.X0, h = cell.Y1 - cell.Y0;
     cell.tiles_x = static_cast<int32_t>((w + cell.tile_w - 1) / cell.tile_w);
     const int64_t tiles_y = (h + cell.tile_h - 1) / cell.tile_h;
-    cell.tile_begin = tiles;
     const int64_t nt = cell.tiles_x * tiles_y;
+    // bands: consecutive cells with the same rows and tile height are walked canvas-row-major as one unit
+    if (!out->bands.empty()) {
+      DevBand& b = out->bands.back();
+      const DevCell& f = out->cells[b.first_cell];
+      if (f.Y0 == cell.Y0 && f.Y1 == cell.Y1 && f.tile_h == cell.tile_h && !std::getenv("IST_NO_BANDS")) {
+        cell.band_x = b.tiles_per_row;
+        b.tiles_per_row += cell.tiles_x;
+        b.n_cells += 1;
+      } else {
+        out->bands.push_back(DevBand{tiles, static_cast<int32_t>(&cell - out->cells.data()), 1, cell.tiles_x, {0, 0, 0}});
+      }
+    } else {
+      out->bands.push_back(DevBand{tiles, static_cast<int32_t>(&cell - out->cells.data()), 1, cell.tiles_x, {0, 0, 0}});
+    }
+    cell.tile_begin = tiles;
     tiles += nt;
     info.out_pixels += w * h;
     switch (cell.path) {

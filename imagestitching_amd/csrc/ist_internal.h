@@ -55,15 +55,28 @@ struct alignas(16) DevCell {
   uint32_t bg;              // packed colour under the stack (fill colour or the canvas clear colour)
   int32_t tile_w, tile_h;
   int32_t tiles_x;
-  int64_t tile_begin;       // prefix sum of tiles over cells
+  int32_t band_x;           // tiles of this band's earlier cells in one tile row (prefix of tiles_x inside the band)
+  int64_t tile_begin;       // host-side bookkeeping
+};
+
+// A BAND = consecutive cells that share [Y0,Y1) and tile_h.  Tiles are enumerated band by band and, inside a band,
+// canvas-row-major ACROSS its cells, so the workgroups resident at one time cover whole canvas rows (contiguous
+// destination bytes) even when the strip is horizontal and every cell is a narrow column.
+struct alignas(16) DevBand {
+  int64_t tile_begin;       // prefix sum of tiles over bands
+  int32_t first_cell, n_cells;
+  int32_t tiles_per_row;    // sum of tiles_x over the band's cells
+  int32_t pad[3];
 };
 
 struct Compiled {
   int64_t canvas_w = 0, canvas_h = 0;
   int64_t rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;   // rendered region (the clip, or the whole canvas)
   int filter = IST_FILTER_BILINEAR;
+  int32_t lds_words = 0;               // LDS footprint buffer the SAMPLE_LDS cells need (32-bit words)
   std::vector<DevOp> ops;
   std::vector<DevCell> cells;
+  std::vector<DevBand> bands;
   std::vector<int32_t> stacks;
   std::vector<int32_t> img_w, img_h;   // bitmap sizes per image (for launch-time validation)
   ist_job_info info{};

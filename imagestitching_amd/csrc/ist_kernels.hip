@@ -254,7 +254,7 @@ IST_DEV void tile_sample(const LaunchArgs& A, const DevOp op, uint32_t bg, int X
 // memory path ONCE, as coalesced 16-B loads (the direct path above issues 8-byte gathers whose lanes straddle ~3x
 // as many cache lines), and the 16 taps per lane then come from LDS (ds_read2_b32).  The host sizes tile_h so that
 // the footprint fits kLdsWords; the kernel re-checks and falls back to the direct path if it ever does not.
-constexpr int kLdsWords = 10240;   // 40 KiB per workgroup -> 4 workgroups per CU
+// The footprint buffer is dynamic LDS sized by the host (LaunchArgs.lds_words = the largest footprint any cell needs).
 
 IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int X0, int Y0, int X1, int Y1, uint32_t* lds) {
   const int lane = threadIdx.x & 63;
@@ -266,7 +266,7 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
   const int fy0 = __builtin_amdgcn_readfirstlane(min(ya.base, yb.base)), fy1 = __builtin_amdgcn_readfirstlane(max(ya.base, yb.base) + 1);
   const int fh = fy1 - fy0 + 1;
   const int wl = (fx1 - fx0 + 4) & ~3;            // LDS row stride in pixels (multiple of 4: 16-B aligned rows)
-  if (wl * fh > kLdsWords || op.cx1 <= op.cx0 || op.cy1 <= op.cy0) {   // uniform; not expected (host sizes the tile)
+  if (wl * fh > A.lds_words || op.cx1 <= op.cx0 || op.cy1 <= op.cy0) {   // uniform; not expected (host sizes the tile)
     tile_sample<IST_FILTER_BILINEAR>(A, op, bg, X0, Y0, X1, Y1);
     return;
   }
@@ -379,32 +379,39 @@ enum : int { HAS_FILL = 1, HAS_COPY = 2, HAS_SAMPLE = 4, HAS_GENERAL = 8 };
 
 template <int PATHS, int V>
 IST_DEV void run_tile(const LaunchArgs& A, int64_t tile) {
-  // cells are few (tens): binary search on the tile prefix with wave-uniform (scalar) loads
-  int lo = 0, hi = A.n_cells - 1;
+  // bands and cells are few (tens): binary search on the tile prefix with wave-uniform (scalar) loads
+  int lo = 0, hi = A.n_bands - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (A.cells[mid].tile_begin <= tile) lo = mid; else hi = mid - 1;
+    if (A.bands[mid].tile_begin <= tile) lo = mid; else hi = mid - 1;
+  }
+  const DevBand b = A.bands[lo];
+  const int local = static_cast<int>(tile - b.tile_begin);
+  const int trow = local / b.tiles_per_row, rem = local - trow * b.tiles_per_row;
+  lo = b.first_cell; hi = b.first_cell + b.n_cells - 1;
+  while (lo < hi) {                      // the cell of this band that holds tile column `rem`
+    const int mid = (lo + hi + 1) >> 1;
+    if (A.cells[mid].band_x <= rem) lo = mid; else hi = mid - 1;
   }
   const DevCell c = A.cells[lo];       // by value: scalar loads once; a reference would be re-read after every store
-  const int local = static_cast<int>(tile - c.tile_begin);
-  const int trow = local / c.tiles_x, tcol = local - trow * c.tiles_x;
+  const int tcol = rem - c.band_x;
   const int X0 = c.X0 + tcol * c.tile_w, Y0 = c.Y0 + trow * c.tile_h;
   const int X1 = min(X0 + c.tile_w, c.X1), Y1 = min(Y0 + c.tile_h, c.Y1);
   const int lg = 31 - __builtin_clz(c.tile_w >> 8);
   const int path = c.path;
   if ((PATHS & HAS_COPY) && path == PATH_COPY) {
     const DevOp op = A.ops[c.op];
-    if (V == 0) tile_copy<8, false, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
+    if (V == 0) tile_copy<2, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);      // production: 256x8 tile, 2 rows per wave
     else if (V == 1) tile_copy<8, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
     else if (V == 2) tile_copy<4, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
     else if (V == 3) tile_copy<16, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
     else if (V == 4) tile_copy<8, true, false, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
     else if (V == 5) tile_copy<8, true, true, false>(A, op, c.bg, lg, X0, Y0, X1, Y1);
-    else tile_copy<8, true, false, false>(A, op, c.bg, lg, X0, Y0, X1, Y1);
+    else tile_copy<8, false, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
   } else if ((PATHS & HAS_FILL) && path == PATH_FILL) {
     tile_fill(A, c.bg, lg, X0, Y0, X1, Y1);
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE_LDS) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsWords];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     tile_sample_lds(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1, lds);
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE) {
     if (A.filter == IST_FILTER_NEAREST) tile_sample<IST_FILTER_NEAREST>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);
@@ -428,7 +435,10 @@ __global__ __launch_bounds__(256) void ist_stitch_kernel(const LaunchArgs A, con
 template <int PATHS, int V, bool PERSIST>
 static void launch_one(const LaunchArgs& args, int64_t n_tiles, hipStream_t stream, int persist_blocks) {
   const unsigned grid = PERSIST ? static_cast<unsigned>(std::min<int64_t>(n_tiles, persist_blocks)) : static_cast<unsigned>(n_tiles);
-  hipLaunchKernelGGL((ist_stitch_kernel<PATHS, V, PERSIST>), dim3(grid), dim3(256), 0, stream, args, n_tiles);
+  // IST_DYN_LDS (bytes): tuning knob, reserves unused dynamic LDS per workgroup to cap the workgroups resident per CU
+  unsigned dyn = std::getenv("IST_DYN_LDS") ? static_cast<unsigned>(std::atoi(std::getenv("IST_DYN_LDS"))) : 0u;
+  dyn = std::max(dyn, static_cast<unsigned>(args.lds_words) * 4u);
+  hipLaunchKernelGGL((ist_stitch_kernel<PATHS, V, PERSIST>), dim3(grid), dim3(256), dyn, stream, args, n_tiles);
 }
 
 template <int PATHS>

@@ -16,9 +16,12 @@ struct LaunchArgs {
   size_t dst_pitch;
   const DevOp* ops;
   const DevCell* cells;
+  const DevBand* bands;
   const int32_t* stacks;
   int32_t n_cells;
   int32_t filter;
+  int32_t lds_words;        // dynamic LDS the SAMPLE_LDS cells need (32-bit words); 0 when the job has none
+  int32_t n_bands;
   const uint8_t* src[kMaxImages];
   size_t pitch[kMaxImages];
 };

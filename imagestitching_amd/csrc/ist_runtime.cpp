@@ -35,6 +35,7 @@ struct ist_job {
   Compiled host;
   DevOp* d_ops = nullptr;
   DevCell* d_cells = nullptr;
+  DevBand* d_bands = nullptr;
   int32_t* d_stacks = nullptr;
   int max_image = -1;
 };
@@ -114,6 +115,7 @@ ist_job* ist_job_create(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const 
   const Compiled& h = job->host;
   const bool ok = upload(reinterpret_cast<void**>(&job->d_ops), h.ops.data(), h.ops.size() * sizeof(DevOp)) &&
                   upload(reinterpret_cast<void**>(&job->d_cells), h.cells.data(), h.cells.size() * sizeof(DevCell)) &&
+                  upload(reinterpret_cast<void**>(&job->d_bands), h.bands.data(), h.bands.size() * sizeof(DevBand)) &&
                   upload(reinterpret_cast<void**>(&job->d_stacks), h.stacks.data(), h.stacks.size() * sizeof(int32_t));
   if (!ok) {
     fail(IST_E_HIP, "uploading the op tables failed");
@@ -142,9 +144,11 @@ int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch
   std::memset(&a, 0, sizeof(a));
   a.dst = static_cast<uint8_t*>(dst);
   a.dst_pitch = dst_pitch;
-  a.ops = job->d_ops; a.cells = job->d_cells; a.stacks = job->d_stacks;
+  a.ops = job->d_ops; a.cells = job->d_cells; a.bands = job->d_bands; a.stacks = job->d_stacks;
+  a.n_bands = static_cast<int32_t>(h.bands.size());
   a.n_cells = static_cast<int32_t>(h.cells.size());
   a.filter = h.filter;
+  a.lds_words = h.lds_words;
   for (const DevOp& o : h.ops) {
     if (o.image < 0) continue;
     const int i = o.image;
@@ -167,6 +171,7 @@ void ist_job_destroy(ist_job* job) {
     DeviceGuard g(job->ctx->device);
     if (job->d_ops) (void)hipFree(job->d_ops);
     if (job->d_cells) (void)hipFree(job->d_cells);
+    if (job->d_bands) (void)hipFree(job->d_bands);
     if (job->d_stacks) (void)hipFree(job->d_stacks);
   }
   delete job;

@@ -13,23 +13,8 @@ import imagestitching_amd as ist  # noqa: E402
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 directions = sys.argv[2].split(",") if len(sys.argv) > 2 else ["vertical", "horizontal"]
 # (label, tile, variant, persist_blocks, full_kernel)
-CONFIGS = [
-    ("consec U8 nt 256x32", "256x32", 0, 0, 0),
-    ("inter  U8 nt 256x32", "256x32", 1, 0, 0),
-    ("inter  U4 nt 256x32", "256x32", 2, 0, 0),
-    ("inter U16 nt 256x32", "256x32", 3, 0, 0),
-    ("inter  U8 ntS only  ", "256x32", 4, 0, 0),
-    ("inter  U8 ntL only  ", "256x32", 5, 0, 0),
-    ("inter  U8 no nt     ", "256x32", 6, 0, 0),
-    ("inter  U8 nt FULLker", "256x32", 1, 0, 1),
-    ("inter  U8 nt 2048x4 ", "2048x4", 1, 0, 0),
-    ("inter  U4 nt 2048x4 ", "2048x4", 2, 0, 0),
-    ("inter  U4 nt 256x16 ", "256x16", 2, 0, 0),
-    ("persist2048 U8 256x32", "256x32", 101, 2048, 0),
-    ("persist1024 U8 256x32", "256x32", 101, 1024, 0),
-    ("persist4096 U4 256x32", "256x32", 102, 4096, 0),
-    ("persist2048 U8 2048x4", "2048x4", 101, 2048, 0),
-]
+CONFIGS = [("U2 256x8 bands", "256x8", 0, 0, 0, 0), ("U2 256x8 nobands", "256x8", 0, 0, 0, 0),
+           ("U2 512x4 bands", "512x4", 0, 0, 0, 0), ("U2 256x16 bands", "256x16", 2, 0, 0, 0)]
 dev = torch.device("cuda", 0)
 st = ist.Stitcher(0)
 imgs = [{"width": 4032, "height": 3024, "opaque": True} for _ in range(9)]
@@ -38,7 +23,12 @@ sets = [[torch.randint(0, 256, (3024, 4032, 4), dtype=torch.uint8, device=dev) f
 
 
 def setenv(cfg):
-    _, tile, v, pb, full = cfg
+    _, tile, v, pb, full, dyn = cfg
+    if "nobands" in cfg[0]:
+        os.environ["IST_NO_BANDS"] = "1"
+    else:
+        os.environ.pop("IST_NO_BANDS", None)
+    os.environ["IST_DYN_LDS"] = str(dyn)
     os.environ["IST_COPY_TILE"] = tile
     os.environ["IST_VARIANT"] = str(v)
     os.environ["IST_PERSIST_BLOCKS"] = str(pb or 2048)
