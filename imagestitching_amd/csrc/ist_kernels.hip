@@ -5,16 +5,18 @@
 // index.js:1577-1579 same-size readback).  ONE launch writes every canvas pixel exactly once:
 //
 //   grid      one 256-thread workgroup (4 wave64) per output tile; tiles enumerate the cells of ist_compile.cpp
-//   tile      256 px x 32 rows for fill / copy / sample cells: a wave row is 64 lanes x 16 B = 1 KiB contiguous
+//   tile      256 px x 8 rows for fill / copy cells (2 rows per wave: ~64 KB in flight per CU, the measured optimum);
+//             a wave row is 64 lanes x 16 B = 1 KiB contiguous
 //             (one global_store_dwordx4 per lane); 64 x 64 for general cells
 //   paths     FILL    constant colour                                   (gaps, centring margins, rounding slack)
-//             COPY    1:1 rect: 16-B loads -> 16-B stores, 8 rows in flight per wave (the BASELINE configs)
+//             COPY    1:1 rect: 16-B nt loads -> 16-B nt stores (the BASELINE configs)
+//             SAMPLE_LDS bilinear with the source footprint staged in LDS by LDS-DMA (mixed-size strips)
 //             SAMPLE  nearest / bilinear resample, source x driven by canvas x: per-lane column taps computed
 //                     once per tile in fp64 (bit-identical to the oracle), rows streamed, fp32 lerp
 //             GENERAL paint stack evaluated per pixel in canvas order (EXIF quarter turns, overlapping draws,
 //                     translucent canvas)
 //
-// HBM-bound byte movement: no MFMA, no LDS staging in this revision (taps come through the vector L1).
+// HBM-bound byte movement: no MFMA.
 // Build: hipcc --offload-arch=gfx950 -ffp-contract=off (the fp64 coordinate math must not be fused).
 #include <hip/hip_runtime.h>
 

@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 CSV output (kernel trace + PMC passes) of `bench.py` into a small text file for profiles/.
-usage: summarize.py <trace_dir> <fetch_dir> <write_dir> <label>"""
-import collections
+"""Summarise rocprofv3 CSV output (kernel trace + separate PMC passes) of `bench.py` into a small text file for
+profiles/.  usage: summarize.py <trace_dir> <fetch_dir> <write_dir> <label> <out.json> <trace counts e.g. 110,60,60,60> <pmc counts e.g. 22,12,12,12>
+bench.py runs its configurations back to back (uniform vertical, uniform horizontal, mixed vertical, mixed horizontal);
+consecutive dispatches of the same kernel + grid are one configuration."""
 import csv
 import glob
+import json
 import sys
+
+NAMES = ["uniform_vertical (BASELINE configs[1])", "uniform_horizontal (BASELINE configs[2])", "mixed_vertical (supplementary)", "mixed_horizontal (supplementary)"]
 
 
 def rows(d, pat):
@@ -12,37 +16,44 @@ def rows(d, pat):
     return list(csv.DictReader(open(f[0]))) if f else []
 
 
+def groups(rs, value, counts):
+    """split the ist_stitch dispatches, in time order, into bench configurations of known dispatch counts
+    (bench.py: warmup + steps per configuration)"""
+    mine = [r for r in rs if "ist_stitch" in r["Kernel_Name"]]
+    out, i = [], 0
+    for c in counts:
+        part = mine[i:i + c]
+        i += c
+        if part:
+            out.append([(part[0]["Kernel_Name"], part[0].get("Grid_Size") or part[0].get("Grid_Size_X")), [value(r) for r in part]])
+    return out
+
+
 def main():
     trace, fetch, write, label = sys.argv[1:5]
     out = ["# rocprofv3 summary — %s" % label, ""]
-    ks = rows(trace, "*_kernel_stats.csv")
-    out.append("## --kernel-trace --stats (all dispatches of the run)")
-    for r in ks:
-        out.append("%-45s calls=%s avg_ns=%s min_ns=%s max_ns=%s pct=%s" % (r["Name"][:45], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]))
-    kt = [r for r in rows(trace, "*_kernel_trace.csv") if "ist_stitch" in r["Kernel_Name"]]
-    # bench.py runs its configs back to back; group consecutive dispatches by grid size + order
-    groups, cur = [], None
-    for r in kt:
-        key = r["Grid_Size"] if "Grid_Size" in r else r.get("Grid_Size_X", "?")
-        if cur is None or cur[0] != key:
-            cur = [key, []]
-            groups.append(cur)
-        cur[1].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    out += ["", "## per bench configuration (consecutive dispatches with the same grid), durations in us"]
-    for key, d in groups:
+    out.append("## --kernel-trace --stats (all dispatches of the run, 4 bench configurations)")
+    for r in rows(trace, "*_kernel_stats.csv"):
+        out.append("%-60s calls=%s avg_ns=%s min_ns=%s max_ns=%s pct=%s" % (r["Name"][:60], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]))
+    kt = sorted(rows(trace, "*_kernel_trace.csv"), key=lambda r: int(r["Start_Timestamp"]))
+    out += ["", "## per bench configuration (kernel trace), durations in us"]
+    machine = {}
+    for i, (key, d) in enumerate(groups(kt, lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), [int(x) for x in sys.argv[6].split(",")])):
         d2 = sorted(d)
-        out.append("grid=%s n=%d avg=%.2f median=%.2f min=%.2f max=%.2f" % (key, len(d), sum(d) / len(d) / 1e3, d2[len(d2) // 2] / 1e3, d2[0] / 1e3, d2[-1] / 1e3))
-    for name, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
-        agg = collections.defaultdict(list)
-        for r in rows(d, "*_counter_collection.csv"):
-            if "ist_stitch" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in agg.items():
+        name = NAMES[i] if i < len(NAMES) else "config %d" % i
+        out.append("%-42s kernel=%s grid=%s n=%d avg=%.2f median=%.2f min=%.2f max=%.2f" % (name, key[0].split("(")[0][-40:], key[1], len(d), sum(d) / len(d) / 1e3, d2[len(d2) // 2] / 1e3, d2[0] / 1e3, d2[-1] / 1e3))
+        machine[name] = {"avg_us": sum(d) / len(d) / 1e3, "median_us": d2[len(d2) // 2] / 1e3, "n": len(d)}
+    for cname, d, scale, note in (("FETCH_SIZE", fetch, 2.0, "x2: on gfx950 FETCH_SIZE reports 1/2 of a 16-B/lane stream, MI355X_MICROARCH.md HBM section"), ("WRITE_SIZE", write, 1.0, "exact for 16-B/lane streaming stores")):
+        cc = sorted(rows(d, "*_counter_collection.csv"), key=lambda r: int(r["Start_Timestamp"]))
+        out += ["", "## --pmc %s (own pass; KB per dispatch; %s)" % (cname, note)]
+        for i, (key, v) in enumerate(groups(cc, lambda r: float(r["Counter_Value"]), [int(x) for x in sys.argv[7].split(",")])):
+            name = NAMES[i] if i < len(NAMES) else "config %d" % i
             mean = sum(v) / len(v)
-            note = " (x2 on gfx950 for 16-B/lane streams per MI355X_MICROARCH.md -> %.1f MB)" % (2 * mean * 1024 / 1e6) if k == "FETCH_SIZE" else " (-> %.1f MB)" % (mean * 1024 / 1e6)
-            out.append("")
-            out.append("## --pmc %s (headline config only): n=%d mean=%.1f KB min=%.1f max=%.1f%s" % (k, len(v), mean, min(v), max(v), note))
+            out.append("%-42s n=%d mean=%.1f KB -> %.2f MB per launch" % (name, len(v), mean, scale * mean * 1024 / 1e6))
+            machine.setdefault(name, {})[cname + "_bytes"] = scale * mean * 1024
     print("\n".join(out))
+    if len(sys.argv) > 5:
+        json.dump(machine, open(sys.argv[5], "w"), indent=1)
 
 
 if __name__ == "__main__":
