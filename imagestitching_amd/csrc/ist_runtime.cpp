@@ -52,6 +52,20 @@ struct DeviceGuard {
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// Page-locks a caller buffer for the duration of one stitch so that the copy engines DMA straight from / to it
+// (pageable hipMemcpy goes through a bounce buffer at a fraction of the PCIe rate).  Best effort: buffers that cannot
+// be registered (read-only mappings, tiny sizes) are simply copied the slow way.
+struct PinScope {
+  std::vector<void*> pinned;
+  void pin(const void* p, size_t bytes) {
+    static const bool off = std::getenv("IST_HOST_PIN") && std::atoi(std::getenv("IST_HOST_PIN")) == 0;
+    if (off || !p || bytes < (1u << 20)) return;
+    if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) pinned.push_back(const_cast<void*>(p));
+    else (void)hipGetLastError();
+  }
+  ~PinScope() { for (void* p : pinned) (void)hipHostUnregister(p); }
+};
+
 int grow(void** p, size_t* have, size_t need) {
   if (*have >= need) return IST_OK;
   if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
@@ -207,11 +221,13 @@ int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uin
   if (rc) return rc;
   std::vector<const void*> dsrc(static_cast<size_t>(n_images), nullptr);
   std::vector<size_t> dpitch(static_cast<size_t>(n_images), 0);
+  PinScope pins;
   for (int i = 0; i < n_images; ++i) {
     if (!used[i]) continue;
     const size_t row = static_cast<size_t>(job->host.img_w[i]) * 4;
     const size_t hp = src_pitch ? src_pitch[i] : row;
     if (hp < row) return fail(IST_E_INVALID, "src_pitch too small");
+    pins.pin(src[i], hp * static_cast<size_t>(job->host.img_h[i] - 1) + row);
     uint8_t* d = static_cast<uint8_t*>(ctx->scratch_src) + off[i];
     IST_HIP(hipMemcpy2DAsync(d, row, src[i], hp, row, static_cast<size_t>(job->host.img_h[i]), hipMemcpyHostToDevice, ctx->stream));
     dsrc[i] = d; dpitch[i] = row;
@@ -226,6 +242,7 @@ int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uin
     rh = std::min<int64_t>(canvas_h, static_cast<int64_t>(region->y) + region->h) - ry;
   }
   if (dst_pitch < static_cast<size_t>(rw) * 4) return fail(IST_E_INVALID, "dst_pitch too small");
+  pins.pin(dst, dst_pitch * static_cast<size_t>(rh - 1) + static_cast<size_t>(rw) * 4);
   const uint8_t* from = static_cast<const uint8_t*>(ctx->scratch_dst) + static_cast<size_t>(ry) * canvas_pitch + static_cast<size_t>(rx) * 4;
   IST_HIP(hipMemcpy2DAsync(dst, dst_pitch, from, canvas_pitch, static_cast<size_t>(rw) * 4, static_cast<size_t>(rh), hipMemcpyDeviceToHost, ctx->stream));
   IST_HIP(hipStreamSynchronize(ctx->stream));

@@ -157,6 +157,41 @@ def stitch(images, direction, opts=None, device=0):
         keep.append(a)
         ptrs[i] = a.ctypes.data
         pitches[i] = a.strides[0]
+    # plan on the CPU, then render straight into the numpy result (ist_stitch_rgba8 is the same two steps with a
+    # malloc'ed output; going through it would cost one more 439 MB host copy here)
+    cplan = L.Plan()
+    lim = _limits(o)
+    rc = L.check(L.lib.ist_plan_compute(descs, n, _DIRECTIONS[direction], _MODES[o["mode"]], float(o["gap"] or 0),
+                                        C.byref(lim), C.byref(cplan)))
+    if rc == L.IST_NOTHING_TO_DO:
+        return None
+    try:
+        w, h = int(cplan.canvas_w), int(cplan.canvas_h)
+        ops = (L.Op * (cplan.n_rects + 1))()
+        n_ops = C.c_int(0)
+        L.check(L.lib.ist_plan_ops(C.byref(cplan), descs, n, ops, C.byref(n_ops)))
+        data = np.empty((h, w, 4), np.uint8)
+        clear = (C.c_uint8 * 4)(0, 0, 0, 0)
+        L.check(L.lib.ist_render_rgba8(_ctx(device), w, h, clear, ops, n_ops.value, descs, ptrs, pitches, n,
+                                       _FILTERS[o["filter"]], None, data.ctypes.data, data.strides[0]))
+    finally:
+        L.lib.ist_plan_free(C.byref(cplan))
+    return {"width": w, "height": h, "data": data}
+
+
+def stitch_via_c_abi(images, direction, opts=None, device=0):
+    """Same as stitch() through the one-call C entry point ist_stitch_rgba8 (what the N-API addon binds)."""
+    o = _merge(opts)
+    n = len(images)
+    if n == 0:
+        return None
+    descs = _descs(images)
+    keep, ptrs, pitches = [], (C.c_void_p * n)(), (C.c_size_t * n)()
+    for i, im in enumerate(images):
+        a = np.ascontiguousarray(im["data"] if isinstance(im, dict) else im)
+        keep.append(a)
+        ptrs[i] = a.ctypes.data
+        pitches[i] = a.strides[0]
     cplan = L.Plan()
     lim = _limits(o)
     out = C.POINTER(C.c_uint8)()

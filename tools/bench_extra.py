@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Extra measurements quoted in DESIGN.md (not the driver's bench line):
+  config5  BASELINE configs[4] geometry on ONE GPU: 64 x 8000x6000 vertical -> 8000x384000 (3072 MP, 24.6 GB moved)
+  host     PCIe-inclusive rate of the host-buffer path (ist_stitch_rgba8) on configs[1]
+usage: python tools/bench_extra.py [config5] [host]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import imagestitching_amd as ist  # noqa: E402
+
+what = sys.argv[1:] or ["config5", "host"]
+dev = torch.device("cuda", 0)
+
+if "config5" in what:
+    st = ist.Stitcher(0)
+    n, w, h = 64, 8000, 6000
+    p, job = st.compile([{"width": w, "height": h, "opaque": True}] * n, "vertical", {"filter": "bilinear"})
+    srcs = [torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device=dev) for _ in range(n)]
+    out = torch.empty((p.canvas_h, p.canvas_w, 4), dtype=torch.uint8, device=dev)
+    job.launch(srcs, out)
+    torch.cuda.synchronize()
+    for k in (0, 17, 63):
+        assert torch.equal(out[h * k:h * (k + 1)], srcs[k])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        job.launch(srcs, out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    B = job.info["algorithmic_bytes"]
+    print("config5 1-GPU: canvas %dx%d, %d tiles, %.3f ms per stitch, %.0f GB/s (%.1f%% of 8 TB/s), %.0f MP/s"
+          % (p.canvas_w, p.canvas_h, job.info["n_tiles"], ms, B / ms / 1e6, B / ms / 1e6 / 80, p.canvas_w * p.canvas_h / 1e6 / (ms * 1e-3)), flush=True)
+    del srcs, out, job
+    torch.cuda.empty_cache()
+
+if "host" in what:
+    px = [np.random.default_rng(1000 + k).integers(0, 256, (3024, 4032, 4), dtype=np.uint8) for k in range(9)]
+    imgs = [{"width": 4032, "height": 3024, "data": a, "opaque": True} for a in px]
+    r = ist.stitch(imgs, "vertical", {"filter": "bilinear"})          # warm-up: scratch allocation
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        r = ist.stitch(imgs, "vertical", {"filter": "bilinear"})
+        ts.append(time.perf_counter() - t0)
+    assert np.array_equal(r["data"][:3024], px[0])
+    t = sorted(ts)[len(ts) // 2]
+    print("host path (pageable numpy in -> HIP -> numpy out, incl. plan, H2D, D2H, output copy): %.1f ms per stitch = %.0f MP/s, %.1f GB/s of PCIe payload"
+          % (t * 1e3, 109.734912 / t, 2 * 438.94e6 / t / 1e9), flush=True)
