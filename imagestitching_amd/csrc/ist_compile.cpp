@@ -70,8 +70,13 @@ int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, 
   if (out->cx1 < out->cx0 || out->cy1 < out->cy0) return 1;
   out->image = op.image;
   out->flags = turned ? OPF_SWAP : 0;
-  if (!turned && out->kx == 1.0 && out->ky == 1.0 && out->ox == std::floor(out->ox) && out->oy == std::floor(out->oy))
+  if (!turned && std::fabs(out->kx) == 1.0 && std::fabs(out->ky) == 1.0 && out->ox == std::floor(out->ox) && out->oy == std::floor(out->oy)) {
     out->flags |= OPF_IDENTITY;
+    if (out->kx < 0.0) out->flags |= OPF_FLIPX;
+    if (out->ky < 0.0) out->flags |= OPF_FLIPY;
+  }
+  if (turned && std::fabs(out->kx) == 1.0 && std::fabs(out->ky) == 1.0 && out->ox == std::floor(out->ox) && out->oy == std::floor(out->oy))
+    out->flags |= OPF_UNIT_SWAP;
   return any ? 0 : 1;
 }
 
@@ -230,14 +235,34 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
       const DevOp& r = out->ops[cell.op];
       bool copy = (r.flags & OPF_IDENTITY) != 0;
       if (copy) {   // every source coordinate of the cell must be inside the clamp box
-        const int64_t ix0 = cell.X0 + static_cast<int64_t>(r.ox), ix1 = cell.X1 - 1 + static_cast<int64_t>(r.ox);
-        const int64_t iy0 = cell.Y0 + static_cast<int64_t>(r.oy), iy1 = cell.Y1 - 1 + static_cast<int64_t>(r.oy);
-        copy = ix0 >= r.cx0 && ix1 <= r.cx1 && iy0 >= r.cy0 && iy1 <= r.cy1;
+        const int64_t ox = static_cast<int64_t>(r.ox), oy = static_cast<int64_t>(r.oy);
+        const int64_t xa = (r.flags & OPF_FLIPX) ? ox - 1 - cell.X0 : cell.X0 + ox, xb = (r.flags & OPF_FLIPX) ? ox - cell.X1 : cell.X1 - 1 + ox;
+        const int64_t ya = (r.flags & OPF_FLIPY) ? oy - 1 - cell.Y0 : cell.Y0 + oy, yb = (r.flags & OPF_FLIPY) ? oy - cell.Y1 : cell.Y1 - 1 + oy;
+        copy = std::min(xa, xb) >= r.cx0 && std::max(xa, xb) <= r.cx1 && std::min(ya, yb) >= r.cy0 && std::max(ya, yb) <= r.cy1;
       }
       cell.path = copy ? PATH_COPY : PATH_SAMPLE;
       if (!bg_opaque) cell.bg = 0xFFFFFFFFu;      // never used: the draw is opaque
     } else {
       cell.path = PATH_GENERAL;
+      // one quarter-turned draw over an opaque colour, bilinear: stage the footprint transposed in LDS
+      if (cell.stack_len == 1 && (out->ops[cell.op].flags & OPF_SWAP) && filter == IST_FILTER_BILINEAR &&
+          (bg_opaque || (out->ops[cell.op].flags & OPF_OPAQUE)) && !std::getenv("IST_NO_LDS")) {
+        const DevOp& r = out->ops[cell.op];
+        const double akx = std::fabs(r.kx), aky = std::fabs(r.ky);
+        if (r.cx1 > r.cx0 && r.cy1 > r.cy0) {
+          for (int th = 64; th >= 16; th >>= 1) {
+            const int64_t fw = static_cast<int64_t>(std::floor((th - 1) * akx)) + 3;     // source columns (driven by canvas Y)
+            const int64_t fh = static_cast<int64_t>(std::floor(63.0 * aky)) + 3;         // source rows (driven by canvas X)
+            const int64_t need = fw * (fh | 1);
+            if (need <= 8192) {                                                          // 32 KiB
+              cell.path = PATH_SWAP_LDS; cell.tile_w = 64; cell.tile_h = th;
+              out->lds_words = std::max<int32_t>(out->lds_words, static_cast<int32_t>(need));
+              if (!bg_opaque) cell.bg = 0xFFFFFFFFu;
+              break;
+            }
+          }
+        }
+      }
     }
     if (cell.path == PATH_SAMPLE && filter == IST_FILTER_BILINEAR && !std::getenv("IST_NO_LDS")) {
       // stage the tile's source footprint in LDS when it fits the budget with at least 4 output rows per tile
@@ -257,7 +282,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
         }
       }
     }
-    if (cell.path == PATH_SAMPLE_LDS) {}
+    if (cell.path == PATH_SAMPLE_LDS || cell.path == PATH_SWAP_LDS) {}
     else if (cell.path == PATH_GENERAL) { cell.tile_w = 64; cell.tile_h = 64; }
     else if (cell.path == PATH_SAMPLE) { cell.tile_w = 256; cell.tile_h = 32; }
     else { cell.tile_w = g_tile_w; cell.tile_h = g_tile_h; }   // FILL / COPY: tile_w = 256 << n
@@ -285,7 +310,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     switch (cell.path) {
       case PATH_FILL: info.tiles_fill += nt; break;
       case PATH_COPY: info.tiles_copy += nt; break;
-      case PATH_SAMPLE: case PATH_SAMPLE_LDS: info.tiles_sample += nt; break;
+      case PATH_SAMPLE: case PATH_SAMPLE_LDS: case PATH_SWAP_LDS: info.tiles_sample += nt; break;
       default: info.tiles_general += nt; break;
     }
     for (int k = 0; k < cell.stack_len; ++k) {

@@ -25,7 +25,10 @@ struct Ctm {
 // ---- device-visible tables -----------------------------------------------------------------------------------
 // A draw resolved into canvas space.  Sampling map (the arithmetic contract shared with the oracle):
 //     sxf = kx * Wc + ox ,  syf = ky * Zc + oy ,  (Wc, Zc) = swap ? (Y+0.5, X+0.5) : (X+0.5, Y+0.5)
-enum : int32_t { OPF_FILL = 1, OPF_SWAP = 2, OPF_OPAQUE = 4, OPF_IDENTITY = 8, OPF_HOLE = 16 };
+enum : int32_t { OPF_FILL = 1, OPF_SWAP = 2, OPF_OPAQUE = 4, OPF_IDENTITY = 8, OPF_HOLE = 16, OPF_FLIPX = 32, OPF_FLIPY = 64, OPF_UNIT_SWAP = 128 };
+// OPF_UNIT_SWAP: a quarter turn at unit scale with integer offsets (a pure transposition-type index remap).
+// OPF_IDENTITY: unit scale on both axes with integer offsets and no quarter turn, so every canvas pixel maps to exactly
+// one source pixel: ix = X + ox (or ox - 1 - X with OPF_FLIPX), iy likewise.  EXIF 2/3/4 at 1:1 are such draws.
 
 struct alignas(16) DevOp {
   double kx, ox, ky, oy;
@@ -43,6 +46,7 @@ enum : int32_t {
   PATH_COPY = 1,      // opaque constant under ONE 1:1 draw with integer offset: HBM copy (+ source-over if alpha<255)
   PATH_SAMPLE = 2,    // opaque constant under ONE axis-aligned draw, source x driven by canvas x
   PATH_SAMPLE_LDS = 4, // PATH_SAMPLE (bilinear, moderate scale) with the tile's source footprint staged in LDS
+  PATH_SWAP_LDS = 5,   // ONE quarter-turned draw (EXIF 5-8), bilinear: footprint staged TRANSPOSED in LDS
   PATH_GENERAL = 3    // anything else: paint stack evaluated per pixel in canvas order (swap draws, overlaps,
                       // translucent canvas)
 };

@@ -161,8 +161,11 @@ IST_DEV void tile_copy(const LaunchArgs& A, const DevOp op, uint32_t bg, int lg,
   const int lane4 = (threadIdx.x & 63) * 4;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int items = (Y1 - Y0) << lg;
-  const size_t sp = A.pitch[op.image];
-  const uint8_t* s = A.src[op.image] + static_cast<int64_t>(op.ox) * 4 + static_cast<int64_t>(op.oy) * static_cast<int64_t>(sp);
+  const int64_t sp = static_cast<int64_t>(A.pitch[op.image]);
+  // unit-scale map: ix = X + ox, or ox - 1 - X when mirrored (EXIF 2/3/4 at 1:1); rows likewise
+  const bool fx = (op.flags & OPF_FLIPX) != 0, fy = (op.flags & OPF_FLIPY) != 0;
+  const int64_t bx = static_cast<int64_t>(op.ox) - (fx ? 1 : 0), by = static_cast<int64_t>(op.oy) - (fy ? 1 : 0);
+  const uint8_t* s = A.src[op.image];
   const bool opaque = (op.flags & OPF_OPAQUE) != 0;
   for (int j = 0; j * 4 * U < items; ++j) {
     u32x4 v[U];
@@ -171,8 +174,19 @@ IST_DEV void tile_copy(const LaunchArgs& A, const DevOp op, uint32_t bg, int lg,
       const int k = IL ? ((j * U + u) * 4 + wave) : ((j * 4 + wave) * U + u);
       IST_ITEM(k);
       if (k < items && nv > 0) {
-        const uint8_t* p = s + static_cast<size_t>(Y) * sp + static_cast<size_t>(X) * 4;
-        v[u] = nv >= 4 ? (NTL ? ld16(p) : ld16_plain(p)) : ld_px(p, nv);
+        const int64_t iy = fy ? by - Y : by + Y;
+        if (!fx) {
+          const uint8_t* p = s + iy * sp + (bx + X) * 4;
+          v[u] = nv >= 4 ? (NTL ? ld16(p) : ld16_plain(p)) : ld_px(p, nv);
+        } else if (nv >= 4) {           // mirrored: canvas X..X+3 <- source bx-X-3 .. bx-X, reversed in registers
+          const u32x4 t = ld16(s + iy * sp + (bx - X - 3) * 4);
+          v[u].x = t.w; v[u].y = t.z; v[u].z = t.y; v[u].w = t.x;
+        } else {
+          v[u].x = ld4(s + iy * sp + (bx - X) * 4);
+          v[u].y = nv > 1 ? ld4(s + iy * sp + (bx - X - 1) * 4) : 0u;
+          v[u].z = nv > 2 ? ld4(s + iy * sp + (bx - X - 2) * 4) : 0u;
+          v[u].w = 0u;
+        }
       }
     }
 #pragma unroll
@@ -251,6 +265,25 @@ IST_DEV void tile_sample(const LaunchArgs& A, const DevOp op, uint32_t bg, int X
   }
 }
 
+// The taps of the tile's rows are wave-uniform: lane i computes the tap of row R0+i ONCE, the row loop then picks its
+// row's tap with v_readlane (tiles are at most 64 rows tall).
+struct RowTaps { int base; float t; };
+IST_DEV RowTaps row_taps(double k, double o, int R0, int R1, int lo, int hi) {
+  const int lane = threadIdx.x & 63;
+  const Tap t = bilinear_tap(k, o, min(R0 + lane, R1 - 1), lo, hi);
+  RowTaps r; r.base = t.base; r.t = t.t;
+  // pin the values here, while every lane of the wave is active: without this the compiler may sink the computation
+  // below a later divergent branch, and v_readlane would then read lanes that never computed it
+  asm volatile("" : "+v"(r.base), "+v"(r.t));
+  return r;
+}
+IST_DEV Tap row_tap(const RowTaps& r, int j) {
+  Tap t;
+  t.base = __builtin_amdgcn_readlane(r.base, j);
+  t.t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.t), j));
+  return t;
+}
+
 // ------------------------------------------------------------------------------------------------ SAMPLE via LDS
 // Bilinear resample with the tile's source footprint staged in LDS: every needed source byte crosses the vector
 // memory path ONCE, as coalesced 16-B loads (the direct path above issues 8-byte gathers whose lanes straddle ~3x
@@ -309,6 +342,7 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA is tracked by vmcnt only
   __syncthreads();
   // ---- resample from LDS
+  const RowTaps rows = row_taps(op.ky, op.oy, Y0, Y1, op.cy0, op.cy1);   // all 64 lanes still active here (readlane source)
   const int X = X0 + lane * 4;
   const int nv = X1 - X;
   if (nv <= 0) return;
@@ -321,7 +355,7 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
   uint8_t* d = A.dst + static_cast<size_t>(X) * 4;
   const bool opaque = (op.flags & OPF_OPAQUE) != 0;
   for (int Y = Y0 + wave; Y < Y1; Y += 4) {
-    const Tap ty = bilinear_tap(op.ky, op.oy, Y, op.cy0, op.cy1);
+    const Tap ty = row_tap(rows, Y - Y0);
     const uint32_t* r0 = lds + (ty.base - fy0) * wl;
     const uint32_t* r1 = r0 + wl;
     uint32_t o[4];
@@ -331,6 +365,92 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
     if (nv >= 4) { const u32x4 v = {o[0], o[1], o[2], o[3]}; st16(dp, v); }
     else { st4(dp, o[0]); if (nv > 1) st4(dp + 4, o[1]); if (nv > 2) st4(dp + 8, o[2]); }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ SWAP via LDS
+// One quarter-turned draw (EXIF 5-8: source x is driven by canvas Y, source y by canvas X), bilinear.  A 64 x th
+// canvas tile needs a (th*|kx|+2)-column x (64*|ky|+2)-row source patch.  The patch is read row by row with coalesced
+// 16-B loads and written TRANSPOSED into LDS (T[source col][source row], odd pitch -> conflict-free), so that at
+// sampling time the 64 lanes of a canvas row read consecutive LDS words and the store is 256 contiguous bytes.
+// Returns false (before touching LDS or any barrier, wave-uniformly) when the patch does not fit: the caller then
+// renders the tile through the general path.
+IST_DEV bool tile_swap_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int X0, int Y0, int X1, int Y1, uint32_t* lds) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const Tap ca = bilinear_tap(op.kx, op.ox, Y0, op.cx0, op.cx1), cb = bilinear_tap(op.kx, op.ox, Y1 - 1, op.cx0, op.cx1);
+  const Tap ra = bilinear_tap(op.ky, op.oy, X0, op.cy0, op.cy1), rb = bilinear_tap(op.ky, op.oy, X1 - 1, op.cy0, op.cy1);
+  const int fx0 = __builtin_amdgcn_readfirstlane(min(ca.base, cb.base)), fx1 = __builtin_amdgcn_readfirstlane(max(ca.base, cb.base) + 1);
+  const int fy0 = __builtin_amdgcn_readfirstlane(min(ra.base, rb.base)), fy1 = __builtin_amdgcn_readfirstlane(max(ra.base, rb.base) + 1);
+  const int fw = fx1 - fx0 + 1, fh = fy1 - fy0 + 1;
+  const int pitch = fh | 1;
+  if (fw * pitch > A.lds_words || op.cx1 <= op.cx0 || op.cy1 <= op.cy0) return false;
+  const size_t sp = A.pitch[op.image];
+  const uint8_t* src = A.src[op.image];
+  __syncthreads();
+  // ---- stage transposed: work item = (source row r, 4-pixel chunk c)
+  const int chunks = (fw + 3) >> 2;
+  const int total = chunks * fh;
+  for (int i0 = 0; i0 < total; i0 += 256 * 4) {
+    u32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256 + tid;
+      if (i < total) {
+        const int r = i / chunks, c = i - r * chunks;
+        const int col = fx0 + 4 * c;
+        const uint8_t* grow = src + static_cast<size_t>(fy0 + r) * sp;
+        if (col + 3 <= op.cx1) v[u] = ld16(grow + static_cast<size_t>(col) * 4);
+        else {
+          v[u].x = ld4(grow + static_cast<size_t>(min(col, op.cx1)) * 4);
+          v[u].y = ld4(grow + static_cast<size_t>(min(col + 1, op.cx1)) * 4);
+          v[u].z = ld4(grow + static_cast<size_t>(min(col + 2, op.cx1)) * 4);
+          v[u].w = ld4(grow + static_cast<size_t>(min(col + 3, op.cx1)) * 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256 + tid;
+      if (i < total) {
+        const int r = i / chunks, c = i - r * chunks;
+        uint32_t* t = lds + (4 * c) * pitch + r;
+        t[0] = v[u].x;
+        if (4 * c + 1 < fw) t[pitch] = v[u].y;
+        if (4 * c + 2 < fw) t[2 * pitch] = v[u].z;
+        if (4 * c + 3 < fw) t[3 * pitch] = v[u].w;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- sample: lane = canvas X (drives the source ROW), loop over canvas Y (drives the source COLUMN, wave-uniform)
+  const RowTaps cols = row_taps(op.kx, op.ox, Y0, Y1, op.cx0, op.cx1);   // all 64 lanes still active here (readlane source)
+  const int X = X0 + lane;
+  if (X >= X1) return true;
+  const Tap tr = bilinear_tap(op.ky, op.oy, X, op.cy0, op.cy1);
+  const uint32_t* col0 = lds + (tr.base - fy0);
+  const bool opaque = (op.flags & OPF_OPAQUE) != 0;
+  uint8_t* dcol = A.dst + static_cast<size_t>(X) * 4;
+  if (op.flags & OPF_UNIT_SWAP) {      // pure quarter turn at 1:1: every canvas pixel IS one source pixel
+    // exact integer indices (the bilinear tap pair clamps its base at the last column/row and would need t = 1 there)
+    const int sy = nearest_tap(op.ky, op.oy, X, op.cy0, op.cy1) - fy0;
+    const int step = op.kx > 0.0 ? pitch : -pitch;
+    const uint32_t* a = lds + sy + (nearest_tap(op.kx, op.ox, Y0 + wave, op.cx0, op.cx1) - fx0) * pitch;
+    for (int Y = Y0 + wave; Y < Y1; Y += 4, a += 4 * step) {
+      uint32_t px = a[0];
+      if (!opaque) px = over_int(px, bg);
+      st4(dcol + static_cast<size_t>(Y) * A.dst_pitch, px);
+    }
+    return true;
+  }
+  for (int Y = Y0 + wave; Y < Y1; Y += 4) {
+    const Tap tc = row_tap(cols, Y - Y0);
+    const uint32_t* a = col0 + (tc.base - fx0) * pitch;     // T[sx][sy], T[sx][sy+1]
+    const uint32_t* b = a + pitch;                           // T[sx+1][...]
+    // bilerp_over(p00, p01, p10, p11, tx, ty): p01 = next source column, p10 = next source row
+    const uint32_t o = bilerp_over(a[0], b[0], a[1], b[1], tc.t, tr.t, bg, opaque);
+    st4(A.dst + static_cast<size_t>(Y) * A.dst_pitch + static_cast<size_t>(X) * 4, o);
+  }
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------ GENERAL
@@ -415,6 +535,9 @@ IST_DEV void run_tile(const LaunchArgs& A, int64_t tile) {
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE_LDS) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     tile_sample_lds(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1, lds);
+  } else if ((PATHS & HAS_SAMPLE) && path == PATH_SWAP_LDS) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (!tile_swap_lds(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1, lds)) tile_general(A, c, X0, Y0, X1, Y1);
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE) {
     if (A.filter == IST_FILTER_NEAREST) tile_sample<IST_FILTER_NEAREST>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);
     else tile_sample<IST_FILTER_BILINEAR>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);

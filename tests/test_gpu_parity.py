@@ -273,3 +273,24 @@ def test_one_call_c_entry_point_equals_two_step_path():
     a = ist.stitch(U.hip_images(px), "vertical", {"mode": "max", "gap": 3})
     b = stitch_via_c_abi(U.hip_images(px), "vertical", {"mode": "max", "gap": 3})
     assert (a["width"], a["height"]) == (b["width"], b["height"]) and np.array_equal(a["data"], b["data"])
+
+
+@pytest.mark.parametrize("filt", ["nearest", "bilinear"])
+def test_orientations_at_photo_scale(filt):
+    """EXIF 2-8 on larger bitmaps: 1:1 flips (mirrored COPY path), quarter turns at 1:1 and scaled (transposed LDS
+    path), translucent pixels, odd sizes that leave ragged tiles."""
+    a = U.rand_image(160, 301, 403, opaque=False)       # landscape bitmap
+    b = U.smooth_image(161, 403, 301)                   # portrait bitmap
+    for o in (2, 3, 4):
+        _check([a, a], "vertical", {"filter": filt}, orientations=[o, o])            # 1:1 mirrored copies
+    for o in (5, 6, 7, 8):
+        # natural size = oriented size (portrait), bitmap stored landscape: pure quarter turn at 1:1
+        imgs = [{"width": 301, "height": 403, "bmpWidth": 403, "bmpHeight": 301, "orientation": o, "data": a}] * 2
+        descs = [{"width": 301, "height": 403, "bmp_w": 403, "bmp_h": 301, "orientation": o}] * 2
+        rc, pd, rl = O.plan(descs, "vertical", "min", 5, U.oracle_limits({}))
+        ref = O.render(pd, rl, descs, [a, a], filt, 4)
+        got = ist.stitch(imgs, "vertical", {"filter": filt, "gap": 5})["data"]
+        assert got.shape == ref.shape
+        assert U.max_abs_diff(got, ref) <= (0 if filt == "nearest" else 1), o
+        # scaled quarter turns next to a plain image
+        _check([a, b, a], "horizontal", {"filter": filt, "mode": "max", "gap": 2}, orientations=[o, 1, o])
