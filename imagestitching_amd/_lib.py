@@ -86,6 +86,17 @@ SYMBOLS = [
                                    C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
                                    C.POINTER(Region), C.c_void_p, C.c_size_t]),
     ("ist_free", None, [C.c_void_p]),
+    ("ist_png_bound", C.c_int64, [C.c_int64, C.c_int64]),
+    ("ist_png_encode_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                        C.POINTER(C.c_int64), C.c_void_p]),
+    ("ist_png_encode_rgba8", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64,
+                                       C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int64)]),
+    ("ist_render_png", C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(Op), C.c_int,
+                                 C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
+                                 C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int64)]),
+    ("ist_stitch_png", C.c_int, [C.c_void_p, C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int,
+                                 C.c_int, C.c_int, C.c_double, C.POINTER(Limits), C.c_int, C.POINTER(Plan),
+                                 C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int64)]),
 ]
 
 if not os.path.exists(LIB_PATH):

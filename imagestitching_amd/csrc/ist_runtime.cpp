@@ -191,17 +191,15 @@ void ist_job_destroy(ist_job* job) {
   delete job;
 }
 
-int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
-                     const ist_op* ops, int n_ops, const ist_image_desc* images, const uint8_t* const* src,
-                     const size_t* src_pitch, int n_images, int filter, const ist_region* region, uint8_t* dst,
-                     size_t dst_pitch) {
-  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
-  if (!dst) return fail(IST_E_INVALID, "ist_render_rgba8: dst is NULL");
-  std::lock_guard<std::mutex> lock(ctx->mu);
+// host sources -> device scratch -> fused launch into ctx->scratch_dst (left on the device, stream NOT synchronised).
+// Caller holds ctx->mu.  pins keeps the caller's buffers page-locked until it goes out of scope.
+static int render_to_scratch(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
+                             const ist_op* ops, int n_ops, const ist_image_desc* images, const uint8_t* const* src,
+                             const size_t* src_pitch, int n_images, int filter, const ist_region* region,
+                             PinScope* pins) {
   ist_job* job = ist_job_create(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, n_images, filter, region);
   if (!job) return g_last_code ? g_last_code : IST_E_INVALID;
   struct JobFree { ist_job* j; ~JobFree() { ist_job_destroy(j); } } jf{job};
-  DeviceGuard g(ctx->device);
 
   // stage the sources that the job actually samples
   std::vector<size_t> off(static_cast<size_t>(n_images), 0);
@@ -221,20 +219,36 @@ int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uin
   if (rc) return rc;
   std::vector<const void*> dsrc(static_cast<size_t>(n_images), nullptr);
   std::vector<size_t> dpitch(static_cast<size_t>(n_images), 0);
-  PinScope pins;
   for (int i = 0; i < n_images; ++i) {
     if (!used[i]) continue;
     const size_t row = static_cast<size_t>(job->host.img_w[i]) * 4;
     const size_t hp = src_pitch ? src_pitch[i] : row;
     if (hp < row) return fail(IST_E_INVALID, "src_pitch too small");
-    pins.pin(src[i], hp * static_cast<size_t>(job->host.img_h[i] - 1) + row);
+    pins->pin(src[i], hp * static_cast<size_t>(job->host.img_h[i] - 1) + row);
     uint8_t* d = static_cast<uint8_t*>(ctx->scratch_src) + off[i];
     IST_HIP(hipMemcpy2DAsync(d, row, src[i], hp, row, static_cast<size_t>(job->host.img_h[i]), hipMemcpyHostToDevice, ctx->stream));
     dsrc[i] = d; dpitch[i] = row;
   }
   rc = ist_job_launch(job, dsrc.data(), dpitch.data(), n_images, ctx->scratch_dst, canvas_pitch, ctx->stream);
   if (rc) return rc;
+  // the job's device tables are freed when `jf` goes out of scope: the launch must have consumed them
+  IST_HIP(hipStreamSynchronize(ctx->stream));
+  return IST_OK;
+}
+
+int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
+                     const ist_op* ops, int n_ops, const ist_image_desc* images, const uint8_t* const* src,
+                     const size_t* src_pitch, int n_images, int filter, const ist_region* region, uint8_t* dst,
+                     size_t dst_pitch) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (!dst) return fail(IST_E_INVALID, "ist_render_rgba8: dst is NULL");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  PinScope pins;
+  int rc = render_to_scratch(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, src, src_pitch, n_images, filter, region, &pins);
+  if (rc) return rc;
   // readback of the requested region (same-size export, index.js:1577-1579; or getImageData, 1564)
+  const size_t canvas_pitch = static_cast<size_t>(canvas_w) * 4;
   int64_t rx = 0, ry = 0, rw = canvas_w, rh = canvas_h;
   if (region) {
     rx = std::max<int64_t>(0, region->x); ry = std::max<int64_t>(0, region->y);
@@ -246,6 +260,82 @@ int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uin
   const uint8_t* from = static_cast<const uint8_t*>(ctx->scratch_dst) + static_cast<size_t>(ry) * canvas_pitch + static_cast<size_t>(rx) * 4;
   IST_HIP(hipMemcpy2DAsync(dst, dst_pitch, from, canvas_pitch, static_cast<size_t>(rw) * 4, static_cast<size_t>(rh), hipMemcpyDeviceToHost, ctx->stream));
   IST_HIP(hipStreamSynchronize(ctx->stream));
+  return IST_OK;
+}
+
+// PNG of a rendered op list: the canvas never leaves the device, only the PNG bytes cross PCIe
+int ist_render_png(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops,
+                   int n_ops, const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch,
+                   int n_images, int filter, uint8_t** out_png, int64_t* out_len) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (!out_png || !out_len) return fail(IST_E_INVALID, "ist_render_png: NULL output");
+  *out_png = nullptr; *out_len = 0;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  PinScope pins;
+  int rc = render_to_scratch(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, src, src_pitch, n_images, filter, nullptr, &pins);
+  if (rc) return rc;
+  const int64_t cap = ist_png_bound(canvas_w, canvas_h);
+  void* dpng = nullptr;
+  IST_HIP(hipMalloc(&dpng, static_cast<size_t>(cap)));
+  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{dpng};
+  int64_t len = 0;
+  rc = ist_png_encode_device(ctx, ctx->scratch_dst, static_cast<size_t>(canvas_w) * 4, canvas_w, canvas_h, dpng, cap, &len, ctx->stream);
+  if (rc) return rc;
+  uint8_t* host = static_cast<uint8_t*>(std::malloc(static_cast<size_t>(len)));
+  if (!host) return fail(IST_E_NOMEM, "out of memory for the PNG");
+  pins.pin(host, static_cast<size_t>(len));
+  if (hipMemcpyAsync(host, dpng, static_cast<size_t>(len), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) { std::free(host); return fail(IST_E_HIP, "PNG readback failed"); }
+  *out_png = host; *out_len = len;
+  return IST_OK;
+}
+
+// plan + render + PNG: onStitch stages 2-5 including the export (index.js:1251-1581), decode excluded
+int ist_stitch_png(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch,
+                   int n_images, int direction, int mode, double gap, const ist_limits* limits, int filter,
+                   ist_plan* out_plan, uint8_t** out_png, int64_t* out_len) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (!out_plan || !out_png || !out_len) return fail(IST_E_INVALID, "ist_stitch_png: NULL output");
+  ist_limits lim;
+  if (limits) lim = *limits; else ist_limits_unlimited(&lim);
+  int rc = ist_plan_compute(images, n_images, direction, mode, gap, &lim, out_plan);
+  if (rc != IST_OK) return rc;
+  std::vector<ist_op> ops(static_cast<size_t>(out_plan->n_rects) + 1);
+  int n_ops = 0;
+  rc = ist_plan_ops(out_plan, images, n_images, ops.data(), &n_ops);
+  static const uint8_t transparent[4] = {0, 0, 0, 0};
+  if (rc == IST_OK)
+    rc = ist_render_png(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, images, src, src_pitch,
+                        n_images, filter, out_png, out_len);
+  if (rc != IST_OK) ist_plan_free(out_plan);
+  return rc;
+}
+
+// PNG of host pixels (H2D, encode, D2H)
+int ist_png_encode_rgba8(ist_ctx* ctx, const uint8_t* pixels, size_t pitch, int64_t w, int64_t h, uint8_t** out_png,
+                         int64_t* out_len) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (!pixels || !out_png || !out_len || w < 1 || h < 1 || pitch < static_cast<size_t>(w) * 4) return fail(IST_E_INVALID, "ist_png_encode_rgba8: bad argument");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  const size_t row = static_cast<size_t>(w) * 4;
+  int rc = grow(&ctx->scratch_dst, &ctx->scratch_dst_bytes, row * static_cast<size_t>(h));
+  if (rc) return rc;
+  PinScope pins;
+  pins.pin(pixels, pitch * static_cast<size_t>(h - 1) + row);
+  IST_HIP(hipMemcpy2DAsync(ctx->scratch_dst, row, pixels, pitch, row, static_cast<size_t>(h), hipMemcpyHostToDevice, ctx->stream));
+  const int64_t cap = ist_png_bound(w, h);
+  void* dpng = nullptr;
+  IST_HIP(hipMalloc(&dpng, static_cast<size_t>(cap)));
+  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{dpng};
+  int64_t len = 0;
+  rc = ist_png_encode_device(ctx, ctx->scratch_dst, row, w, h, dpng, cap, &len, ctx->stream);
+  if (rc) return rc;
+  uint8_t* host = static_cast<uint8_t*>(std::malloc(static_cast<size_t>(len)));
+  if (!host) return fail(IST_E_NOMEM, "out of memory for the PNG");
+  if (hipMemcpy(host, dpng, static_cast<size_t>(len), hipMemcpyDeviceToHost) != hipSuccess) { std::free(host); return fail(IST_E_HIP, "PNG readback failed"); }
+  *out_png = host; *out_len = len;
   return IST_OK;
 }
 

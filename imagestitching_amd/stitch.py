@@ -208,6 +208,72 @@ def stitch_via_c_abi(images, direction, opts=None, device=0):
     return {"width": w, "height": h, "data": data}
 
 
+def _take_png(out, n):
+    try:
+        return bytes(C.string_at(out, n.value))
+    finally:
+        L.lib.ist_free(out)
+
+
+def encode_png(pixels, device=0):
+    """Lossless PNG (colour type 6) of an HxWx4 uint8 array, encoded on the GPU (export step, utils/canvas.js:205-242)."""
+    a = np.asarray(pixels)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 4:
+        raise TypeError("expected an HxWx4 uint8 RGBA array")
+    if a.strides[2] != 1 or a.strides[1] != 4:
+        a = np.ascontiguousarray(a)
+    out, n = C.POINTER(C.c_uint8)(), C.c_int64(0)
+    L.check(L.lib.ist_png_encode_rgba8(_ctx(device), a.ctypes.data, a.strides[0], a.shape[1], a.shape[0], C.byref(out), C.byref(n)))
+    return _take_png(out, n)
+
+
+def stitch_png(images, direction, opts=None, device=0):
+    """stitch(images, direction, opts) with the reference's export: returns {'width','height','png': bytes}.  The
+    canvas stays on the device; only the PNG crosses PCIe."""
+    o = _merge(opts)
+    n = len(images)
+    if n == 0:
+        return None
+    descs = _descs(images)
+    keep, ptrs, pitches = [], (C.c_void_p * n)(), (C.c_size_t * n)()
+    for i, im in enumerate(images):
+        a = im["data"] if isinstance(im, dict) else im
+        if a is None:
+            raise L.StitchError(-6, "图片%d解码异常" % i)
+        a = np.ascontiguousarray(a)
+        keep.append(a)
+        ptrs[i] = a.ctypes.data
+        pitches[i] = a.strides[0]
+    cplan = L.Plan()
+    lim = _limits(o)
+    out, ln = C.POINTER(C.c_uint8)(), C.c_int64(0)
+    rc = L.check(L.lib.ist_stitch_png(_ctx(device), descs, ptrs, pitches, n, _DIRECTIONS[direction], _MODES[o["mode"]],
+                                      float(o["gap"] or 0), C.byref(lim), _FILTERS[o["filter"]], C.byref(cplan), C.byref(out), C.byref(ln)))
+    if rc == L.IST_NOTHING_TO_DO:
+        return None
+    w, h = int(cplan.canvas_w), int(cplan.canvas_h)
+    L.lib.ist_plan_free(C.byref(cplan))
+    return {"width": w, "height": h, "png": _take_png(out, ln)}
+
+
+def encode_png_device(canvas, out=None, stream=None, device=None):
+    """PNG of a canvas that is resident in HBM (HxWx4 uint8 CUDA tensor) into a CUDA uint8 tensor; returns (tensor, length)."""
+    import torch
+    h, w = int(canvas.shape[0]), int(canvas.shape[1])
+    cap = int(L.lib.ist_png_bound(w, h))
+    if out is None:
+        out = torch.empty(cap + 16, dtype=torch.uint8, device=canvas.device)
+    base = out.data_ptr()
+    aligned = (base + 15) & ~15
+    st = stream if stream is not None else torch.cuda.current_stream(canvas.device)
+    n = C.c_int64(0)
+    dev = canvas.device.index if device is None else device
+    L.check(L.lib.ist_png_encode_device(_ctx(dev or 0), C.c_void_p(canvas.data_ptr()), canvas.stride(0), w, h,
+                                        C.c_void_p(aligned), out.numel() - (aligned - base), C.byref(n), C.c_void_p(st.cuda_stream)))
+    off = aligned - base
+    return out[off:off + n.value], n.value
+
+
 class StitchJob:
     """A compiled op list on one device: re-launchable on new source / destination buffers with no upload."""
 

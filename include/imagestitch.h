@@ -160,6 +160,26 @@ IST_API int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, c
                              const ist_region* region, uint8_t* dst, size_t dst_pitch);
 IST_API void ist_free(void* p);
 
+/* ---- export: lossless PNG (fileType 'png', quality 1; utils/canvas.js:205-242, index.js:1577-1579) --------------- */
+/* upper bound of the file size for a w x h RGBA canvas */
+IST_API int64_t ist_png_bound(int64_t w, int64_t h);
+/* encode a canvas that is resident in HBM into a device buffer (16-byte aligned, ist_png_bound bytes); one HBM-bound
+ * pass; the checksums are combined on the host, so the call synchronises `stream` before it returns */
+IST_API int ist_png_encode_device(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* out,
+                                  int64_t out_cap, int64_t* out_len, void* stream);
+/* host pixels -> PNG bytes (malloc'ed, free with ist_free) */
+IST_API int ist_png_encode_rgba8(ist_ctx* ctx, const uint8_t* pixels, size_t pitch, int64_t w, int64_t h,
+                                 uint8_t** out_png, int64_t* out_len);
+/* recorded Canvas op list -> PNG bytes (wx.canvasToTempFilePath of the shim); the canvas never leaves the device */
+IST_API int ist_render_png(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
+                           const ist_op* ops, int n_ops, const ist_image_desc* images, const uint8_t* const* src,
+                           const size_t* src_pitch, int n_images, int filter, uint8_t** out_png, int64_t* out_len);
+/* onStitch stages 2-5 including the export: plan, render, PNG */
+IST_API int ist_stitch_png(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* const* src,
+                           const size_t* src_pitch, int n_images, int direction, int mode, double gap,
+                           const ist_limits* limits, int filter, ist_plan* out_plan, uint8_t** out_png,
+                           int64_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,8 @@
  *   plan(images, direction, mode, gap, limits)                         -> plan object        (pure CPU)
  *   stitch(images, direction, mode, gap, limits, filter)              -> Promise<{width,height,data}>  (napi_async_work)
  *   stitchSync(...same...)                                             -> {width,height,data}
- *   render(canvasW, canvasH, clearRGBA, ops, images, filter, region)   -> Buffer (region pixels)   (Canvas shim export)
+ *   render(canvasW, canvasH, clearRGBA, ops, images, filter, region, asPng?) -> Buffer (region pixels, or the PNG file)
+ *   encodePng(data, width, height) -> Buffer;  stitch(..., filter, true) resolves {width,height,png}
  *   deviceCount(), lastError(), abiVersion()
  *
  * images[i] = {width, height, orientation?, fileSize?, opaque?, bmpWidth?, bmpHeight?, data?: Uint8Array|Buffer}
@@ -204,6 +205,7 @@ static napi_value js_plan(napi_env env, napi_callback_info info) {
 typedef struct {
   images_t im;
   int direction, mode, filter; double gap; ist_limits lim;
+  int want_png; int64_t png_len;          /* stitchPng: `pixels` holds the PNG file bytes */
   ist_plan plan; uint8_t* pixels; int rc; char err[256];
   napi_deferred deferred; napi_async_work work;
 } stitch_job;
@@ -213,11 +215,11 @@ static void free_pixels(napi_env env, void* data, void* hint) { (void)env; (void
 static napi_value stitch_result(napi_env env, stitch_job* j) {
   napi_value o, buf;
   napi_create_object(env, &o);
-  const size_t bytes = (size_t)j->plan.canvas_w * (size_t)j->plan.canvas_h * 4;
+  const size_t bytes = j->want_png ? (size_t)j->png_len : (size_t)j->plan.canvas_w * (size_t)j->plan.canvas_h * 4;
   if (napi_create_external_buffer(env, bytes, j->pixels, free_pixels, NULL, &buf) != napi_ok) { ist_free(j->pixels); return NULL; }
   set_num(env, o, "width", (double)j->plan.canvas_w);
   set_num(env, o, "height", (double)j->plan.canvas_h);
-  napi_set_named_property(env, o, "data", buf);
+  napi_set_named_property(env, o, j->want_png ? "png" : "data", buf);
   napi_set_named_property(env, o, "plan", plan_to_js(env, &j->plan));
   ist_plan_free(&j->plan);
   return o;
@@ -230,8 +232,12 @@ static void stitch_execute(napi_env env, void* data) {
   if (!ctx) { j->rc = IST_E_NO_DEVICE; strncpy(j->err, g_ctx_err, sizeof j->err - 1); return; }
   for (int i = 0; i < j->im.n; i++)
     if (!j->im.data[i]) { j->rc = IST_E_DECODE; snprintf(j->err, sizeof j->err, "\xe5\x9b\xbe\xe7\x89\x87%d\xe8\xa7\xa3\xe7\xa0\x81\xe5\xbc\x82\xe5\xb8\xb8", i); return; }
-  j->rc = ist_stitch_rgba8(ctx, j->im.descs, j->im.data, j->im.pitch, j->im.n, j->direction, j->mode, j->gap, &j->lim,
-                           j->filter, &j->plan, &j->pixels);
+  if (j->want_png)
+    j->rc = ist_stitch_png(ctx, j->im.descs, j->im.data, j->im.pitch, j->im.n, j->direction, j->mode, j->gap, &j->lim,
+                           j->filter, &j->plan, &j->pixels, &j->png_len);
+  else
+    j->rc = ist_stitch_rgba8(ctx, j->im.descs, j->im.data, j->im.pitch, j->im.n, j->direction, j->mode, j->gap, &j->lim,
+                             j->filter, &j->plan, &j->pixels);
   if (j->rc < 0) strncpy(j->err, ist_last_error(), sizeof j->err - 1);
 }
 
@@ -263,7 +269,7 @@ static void stitch_complete(napi_env env, napi_status status, void* data) {
 }
 
 static stitch_job* stitch_parse(napi_env env, napi_callback_info info, int want_refs) {
-  size_t argc = 6; napi_value argv[6];
+  size_t argc = 7; napi_value argv[7];
   if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < 6) {
     napi_throw_type_error(env, NULL, "stitch(images, direction, mode, gap, limits, filter)");
     return NULL;
@@ -276,6 +282,7 @@ static stitch_job* stitch_parse(napi_env env, napi_callback_info info, int want_
   napi_get_value_double(env, argv[3], &j->gap);
   limits_parse(env, argv[4], &j->lim);
   napi_get_value_int32(env, argv[5], &v); j->filter = v;
+  if (argc > 6) { bool b = false; napi_get_value_bool(env, argv[6], &b); j->want_png = b ? 1 : 0; }
   return j;
 }
 
@@ -307,7 +314,7 @@ static napi_value js_stitch_sync(napi_env env, napi_callback_info info) {
 
 /* render(canvasW, canvasH, clearRGBA(Uint8Array 4), ops(Float64Array 18/op), images, filter, region|null) -> Buffer */
 static napi_value js_render(napi_env env, napi_callback_info info) {
-  size_t argc = 7; napi_value argv[7];
+  size_t argc = 8; napi_value argv[8];
   CHECK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   if (argc < 6) { napi_throw_type_error(env, NULL, "render(canvasW, canvasH, clear, ops, images, filter, region)"); return NULL; }
   double cw = 0, ch = 0; int32_t filter = 1;
@@ -351,6 +358,21 @@ static napi_value js_render(napi_env env, napi_callback_info info) {
     }
   }
   if (reg.w < 1 || reg.h < 1) { images_free(env, &im); free(ops); napi_throw_range_error(env, NULL, "empty region"); return NULL; }
+  if (argc > 7) {                 /* asPng: wx.canvasToTempFilePath({fileType:'png'}) - the canvas stays on the device */
+    bool as_png = false; napi_get_value_bool(env, argv[7], &as_png);
+    if (as_png) {
+      uint8_t* png = NULL; int64_t len = 0;
+      ist_ctx* c2 = get_ctx();
+      int rc2 = c2 ? ist_render_png(c2, (int64_t)cw, (int64_t)ch, clear, ops, n_ops, im.descs, im.data, im.pitch, im.n, filter, &png, &len)
+                   : IST_E_NO_DEVICE;
+      images_free(env, &im); free(ops);
+      if (rc2 == IST_E_NO_DEVICE && !c2) { napi_throw(env, make_error(env, rc2, g_ctx_err)); return NULL; }
+      if (rc2 < 0) return throw_ist(env, rc2);
+      napi_value buf;
+      if (napi_create_external_buffer(env, (size_t)len, png, free_pixels, NULL, &buf) != napi_ok) { ist_free(png); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+      return buf;
+    }
+  }
   const size_t bytes = (size_t)reg.w * (size_t)reg.h * 4;
   void* out_data = NULL; napi_value out;
   if (napi_create_buffer(env, bytes, &out_data, &out) != napi_ok) { images_free(env, &im); free(ops); napi_throw_error(env, NULL, "out of memory"); return NULL; }
@@ -362,6 +384,28 @@ static napi_value js_render(napi_env env, napi_callback_info info) {
   if (rc == IST_E_NO_DEVICE && !ctx) { napi_throw(env, make_error(env, rc, g_ctx_err)); return NULL; }
   if (rc < 0) return throw_ist(env, rc);
   return out;
+}
+
+/* encodePng(data: Uint8Array RGBA, width, height) -> Buffer (PNG file bytes) */
+static napi_value js_encode_png(napi_env env, napi_callback_info info) {
+  size_t argc = 3; napi_value argv[3];
+  CHECK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 3) { napi_throw_type_error(env, NULL, "encodePng(data, width, height)"); return NULL; }
+  bool ta = false, isbuf = false; void* p = NULL; size_t len = 0;
+  napi_is_buffer(env, argv[0], &isbuf); napi_is_typedarray(env, argv[0], &ta);
+  if (isbuf) napi_get_buffer_info(env, argv[0], &p, &len);
+  else if (ta) { napi_typedarray_type tt; napi_value ab; size_t off; napi_get_typedarray_info(env, argv[0], &tt, &len, &p, &ab, &off); }
+  double w = 0, h = 0;
+  napi_get_value_double(env, argv[1], &w); napi_get_value_double(env, argv[2], &h);
+  if (!p || w < 1 || h < 1 || (double)len < w * h * 4) { napi_throw_range_error(env, NULL, "data is smaller than width*height*4"); return NULL; }
+  ist_ctx* ctx = get_ctx();
+  if (!ctx) { napi_throw(env, make_error(env, IST_E_NO_DEVICE, g_ctx_err)); return NULL; }
+  uint8_t* png = NULL; int64_t n = 0;
+  const int rc = ist_png_encode_rgba8(ctx, (const uint8_t*)p, (size_t)w * 4, (int64_t)w, (int64_t)h, &png, &n);
+  if (rc < 0) return throw_ist(env, rc);
+  napi_value buf;
+  if (napi_create_external_buffer(env, (size_t)n, png, free_pixels, NULL, &buf) != napi_ok) { ist_free(png); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+  return buf;
 }
 
 static napi_value js_device_count(napi_env env, napi_callback_info info) {
@@ -380,6 +424,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"stitch", NULL, js_stitch, NULL, NULL, NULL, napi_default, NULL},
       {"stitchSync", NULL, js_stitch_sync, NULL, NULL, NULL, napi_default, NULL},
       {"render", NULL, js_render, NULL, NULL, NULL, napi_default, NULL},
+      {"encodePng", NULL, js_encode_png, NULL, NULL, NULL, napi_default, NULL},
       {"deviceCount", NULL, js_device_count, NULL, NULL, NULL, napi_default, NULL},
       {"lastError", NULL, js_last_error, NULL, NULL, NULL, napi_default, NULL},
       {"abiVersion", NULL, js_abi_version, NULL, NULL, NULL, napi_default, NULL},

@@ -111,7 +111,7 @@ class ShimCanvas {
     try { const r = this._env.exportCanvas(this, o); if (o.success) o.success(r); } catch (e) { if (o.fail) o.fail(e); }
   }
   /** one fused launch over the recorded ops; returns the region's RGBA bytes */
-  _render(region, smoothing) {
+  _render(region, smoothing, asPng) {
     if (this._w < 1 || this._h < 1) throw new Error('canvas has no size');
     const bitmaps = [], index = new Map();
     const packed = new Float64Array(this._ops.length * 18);
@@ -130,7 +130,7 @@ class ShimCanvas {
                                 bitmaps: bitmaps.map((b) => [b.width, b.height]) });
       return Buffer.alloc(Math.min((reg ? reg.w * reg.h : this._w * this._h) * 4, 1 << 16));   // placeholder pixels
     }
-    return native.render(this._w, this._h, new Uint8Array([0, 0, 0, 0]), packed, bitmaps, smoothing ? 1 : 0, reg);
+    return native.render(this._w, this._h, new Uint8Array([0, 0, 0, 0]), packed, bitmaps, smoothing ? 1 : 0, reg, !!asPng);
   }
 }
 
@@ -138,8 +138,8 @@ class ShimCanvas {
  * A `wx` + canvas-node environment for running the reference page.  files: {path: {width, height, data, opaque?,
  * orientation?}} are the "decoded bitmaps" (decode is outside the path: SURVEY.md section 8f rank 3).
  */
-function makeEnvironment({ platform = 'devtools', files = {}, storage = {}, recordOnly = false } = {}) {
-  const env = { platform, files, storage, exports: {}, toasts: [], nextExport: 0, recordOnly, recorded: [] };
+function makeEnvironment({ platform = 'devtools', files = {}, storage = {}, recordOnly = false, outDir = null } = {}) {
+  const env = { platform, files, storage, exports: {}, toasts: [], nextExport: 0, recordOnly, recorded: [], outDir };
   env.exportCanvas = (canvas, o) => {
     const w = Math.max(1, Math.floor(o.width || canvas.width)), h = Math.max(1, Math.floor(o.height || canvas.height));
     if ((o.destWidth && o.destWidth !== w) || (o.destHeight && o.destHeight !== h)) throw new Error('export rescale is outside the stitch path');
@@ -147,6 +147,15 @@ function makeEnvironment({ platform = 'devtools', files = {}, storage = {}, reco
     const data = canvas._render({ x: o.x || 0, y: o.y || 0, w, h }, smoothing);
     const p = 'shim://export/' + (env.nextExport++) + '.' + (o.fileType || 'png');
     env.exports[p] = { width: w, height: h, data };
+    // fileType 'png' of the whole canvas: also produce the file itself (GPU encoder), written out when outDir is set
+    if (!env.recordOnly && (o.fileType || 'png') === 'png' && (o.x || 0) === 0 && (o.y || 0) === 0 && w === canvas.width && h === canvas.height) {
+      env.exports[p].png = canvas._render(null, smoothing, true);
+      if (env.outDir) {
+        const file = require('path').join(env.outDir, 'export' + (env.nextExport - 1) + '.png');
+        require('fs').writeFileSync(file, env.exports[p].png);
+        env.exports[p].file = file;
+      }
+    }
     env.files[p] = { width: w, height: h, data, opaque: true };
     return { tempFilePath: p };
   };

@@ -21,6 +21,7 @@ async function main() {
   let result;
   if (job.mode === 'stitch') {
     const api = require('./index.js');
+    if (job.png) { const r = await api.stitchPng(images, job.direction, job.opts); fs.writeFileSync(job.out, r.png); console.log(JSON.stringify({ width: r.width, height: r.height, bytes: r.png.length, png: true })); return; }
     result = job.sync ? api.stitchSync(images, job.direction, job.opts) : await api.stitch(images, job.direction, job.opts);
   } else if (job.mode === 'shim') {
     const api = require('./index.js');
@@ -28,7 +29,7 @@ async function main() {
     const p = api.plan(images, job.direction, job.opts);
     const files = {};
     images.forEach((im, i) => { files['img' + i] = im; });
-    const env = shim.makeEnvironment({ files });
+    const env = shim.makeEnvironment({ files, outDir: job.outDir || null });
     const off = env.mainCanvas.createOffscreenCanvas({ type: '2d', width: p.canvasW, height: p.canvasH });
     const ctx = off.getContext('2d');
     ctx.imageSmoothingEnabled = (job.opts && job.opts.filter) !== 'nearest';
@@ -43,6 +44,7 @@ async function main() {
     }
     const exp = await env.wx.canvasToTempFilePath({ canvas: off, x: 0, y: 0, width: p.canvasW, height: p.canvasH, destWidth: p.canvasW, destHeight: p.canvasH, fileType: 'png', quality: 1 });
     result = env.exports[exp.tempFilePath];
+    if (result.file) result.plan = { file: result.file };
   } else if (job.mode === 'reference') {
     const shim = require('./canvas_shim.js');
     const root = job.referenceRoot || '/root/reference';

@@ -25,3 +25,6 @@ export interface StitchResult { width: number; height: number; data: Buffer; pla
 export function stitch(images: StitchImage[], direction: Direction, opts?: StitchOptions): Promise<StitchResult | null>;
 export function stitchSync(images: StitchImage[], direction: Direction, opts?: StitchOptions): StitchResult | null;
 export function plan(images: StitchImage[], direction: Direction, opts?: StitchOptions): StitchPlan | null;
+export interface StitchPngResult { width: number; height: number; png: Buffer; plan: StitchPlan; }
+export function stitchPng(images: StitchImage[], direction: Direction, opts?: StitchOptions): Promise<StitchPngResult | null>;
+export function encodePng(data: Uint8Array, width: number, height: number): Buffer;

@@ -55,9 +55,18 @@ function stitch(images, direction, opts) {
   return native.stitch(...a);
 }
 function stitchSync(images, direction, opts) { return native.stitchSync(...args(images, direction, opts)); }
+/** stitch + the reference's export step: resolves {width, height, png: Buffer (a lossless PNG file), plan}. The canvas
+ *  never leaves the GPU; only the PNG bytes cross PCIe (utils/canvas.js:205-242, index.js:1577-1579). */
+function stitchPng(images, direction, opts) {
+  let a;
+  try { a = args(images, direction, opts); } catch (e) { return Promise.reject(e); }
+  return native.stitch(...a, true);
+}
+/** Lossless PNG of RGBA8 pixels, encoded on the GPU. */
+function encodePng(data, width, height) { return native.encodePng(data, width, height); }
 function plan(images, direction, opts) {
   const a = args(images, direction, opts);
   return native.plan(a[0], a[1], a[2], a[3], a[4]);
 }
 
-module.exports = { stitch, stitchSync, plan, native, DIRECTION, MODE, FILTER, PLATFORM };
+module.exports = { stitch, stitchSync, stitchPng, encodePng, plan, native, DIRECTION, MODE, FILTER, PLATFORM };

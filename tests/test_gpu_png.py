@@ -1,0 +1,94 @@
+"""PNG export on the GPU: the file must be a valid PNG that decodes, with two independent
+decoders (PIL; and a by-hand chunk walk + zlib.decompress), to exactly the canvas bytes."""
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import imagestitching_amd as ist
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _decode_by_hand(png):
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr, n_idat = 8, b"", None, 0
+    while pos < len(png):
+        ln, typ = struct.unpack(">I4s", png[pos:pos + 8])
+        data = png[pos + 8:pos + 8 + ln]
+        crc, = struct.unpack(">I", png[pos + 8 + ln:pos + 12 + ln])
+        assert zlib.crc32(typ + data) == crc, "bad CRC in %r chunk" % typ
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", data)
+        elif typ == b"IDAT":
+            idat += data
+            n_idat += 1
+        elif typ == b"IEND":
+            assert ln == 0 and pos + 12 == len(png)
+        pos += 12 + ln
+    w, h, depth, ctype, comp, filt, inter = ihdr
+    assert (depth, ctype, comp, filt, inter) == (8, 6, 0, 0, 0)
+    raw = zlib.decompress(idat)                      # also verifies the Adler-32
+    assert len(raw) == h * (4 * w + 1)
+    rows = np.frombuffer(raw, np.uint8).reshape(h, 4 * w + 1)
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:].reshape(h, w, 4), n_idat
+
+
+def _check(a):
+    from PIL import Image
+    png = ist.encode_png(a)
+    by_hand, _ = _decode_by_hand(png)
+    assert np.array_equal(by_hand, a)
+    pil = np.asarray(Image.open(io.BytesIO(png)).convert("RGBA"))
+    assert np.array_equal(pil, a)
+    return png
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 5), (4, 4), (5, 3), (64, 33), (257, 19), (1000, 700), (4032, 50)])
+def test_png_roundtrip_shapes(w, h):
+    _check(U.rand_image(400 + w, h, w, opaque=False))
+
+
+def test_png_rows_longer_than_one_stored_block():
+    """36288-px rows (BASELINE configs[2]) are 145 KB: three 63-KiB stored blocks per row."""
+    _check(U.rand_image(410, 7, 36288))
+    _check(U.rand_image(411, 3, 16129))       # 64516 bytes: one byte over a block
+
+
+def test_png_more_rows_than_one_grid_slab():
+    _check(U.rand_image(412, 70000, 8))
+
+
+def test_png_multiple_idat_chunks(monkeypatch):
+    monkeypatch.setenv("IST_PNG_IDAT_LIMIT", "65536")
+    a = U.rand_image(413, 300, 257)
+    png = ist.encode_png(a)
+    got, n_idat = _decode_by_hand(png)
+    assert n_idat > 3 and np.array_equal(got, a)
+
+
+def test_stitch_png_equals_stitch_pixels():
+    from PIL import Image
+    px = [U.rand_image(420 + i, h, w) for i, (w, h) in enumerate([(403, 302), (302, 403), (400, 300)])]
+    for direction in ("vertical", "horizontal"):
+        ref = ist.stitch(U.hip_images(px), direction, {"mode": "max", "gap": 4})
+        got = ist.stitch_png(U.hip_images(px), direction, {"mode": "max", "gap": 4})
+        assert (got["width"], got["height"]) == (ref["width"], ref["height"])
+        dec = np.asarray(Image.open(io.BytesIO(got["png"])).convert("RGBA"))
+        assert np.array_equal(dec, ref["data"])
+
+
+def test_png_device_resident_full_size():
+    """BASELINE configs[1] canvas (4032x27216, 439 MB) encoded without leaving HBM; decoded by zlib on the host."""
+    import torch
+    canvas = torch.randint(0, 256, (27216, 4032, 4), dtype=torch.uint8, device="cuda")
+    out, n = ist.encode_png_device(canvas)
+    torch.cuda.synchronize()
+    png = out.cpu().numpy().tobytes()
+    assert len(png) == n and n < ist._lib.lib.ist_png_bound(4032, 27216)
+    got, n_idat = _decode_by_hand(png)
+    assert n_idat == 1 and np.array_equal(got, canvas.cpu().numpy())

@@ -136,3 +136,22 @@ def test_canvas_shim_pixels_match_oracle(tmp_path):
         got = np.fromfile(tmp_path / "o.rgba", np.uint8).reshape(out["height"], out["width"], 4)
         assert got.shape == ref.shape
         assert U.max_abs_diff(got, ref) <= (0 if opts["filter"] == "nearest" else 1)
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_png_export(tmp_path):
+    """stitchPng (S1 + export) and the shim's canvasToTempFilePath({fileType:'png'}) write real PNG files."""
+    import io
+    from PIL import Image
+    px = [U.rand_image(500 + i, 48, 64) for i in range(3)]
+    imgs = _write_images(px, tmp_path)
+    ref, pd, _ = U.oracle_stitch(px, "vertical", {"filter": "nearest"})
+    out = tmp_path / "o.png"
+    rc, meta, err = _cli({"mode": "stitch", "png": True, "direction": "vertical", "opts": {"filter": "nearest"}, "images": imgs, "out": str(out)}, tmp_path)
+    assert rc == 0 and meta["png"], err
+    assert np.array_equal(np.asarray(Image.open(out).convert("RGBA")), ref)
+    rc, meta, err = _cli({"mode": "shim", "direction": "vertical", "opts": {"filter": "nearest"}, "images": imgs, "out": str(tmp_path / "o.rgba"),
+                          "outDir": str(tmp_path)}, tmp_path)
+    assert rc == 0, err
+    assert np.array_equal(np.asarray(Image.open(meta["plan"]["file"]).convert("RGBA")), ref)

@@ -14,7 +14,7 @@ import torch  # noqa: E402
 
 import imagestitching_amd as ist  # noqa: E402
 
-what = sys.argv[1:] or ["config5", "host"]
+what = sys.argv[1:] or ["config5", "host", "png"]
 dev = torch.device("cuda", 0)
 
 if "config5" in what:
@@ -54,3 +54,18 @@ if "host" in what:
     t = sorted(ts)[len(ts) // 2]
     print("host path (pageable numpy in -> HIP -> numpy out, incl. plan, H2D, D2H, output copy): %.1f ms per stitch = %.0f MP/s, %.1f GB/s of PCIe payload"
           % (t * 1e3, 109.734912 / t, 2 * 438.94e6 / t / 1e9), flush=True)
+
+if "png" in what:
+    canvas = torch.randint(0, 256, (27216, 4032, 4), dtype=torch.uint8, device=dev)
+    out, n = ist.encode_png_device(canvas)               # warm-up
+    buf = torch.empty(out.numel() + 64, dtype=torch.uint8, device=dev)
+    ts = []
+    for _ in range(10):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out, n = ist.encode_png_device(canvas, out=buf)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[len(ts) // 2]
+    print("png device-resident 4032x27216: %d bytes (%.4f x raw), %.3f ms per encode incl. host checksum combine = %.0f MP/s, %.0f GB/s read+write"
+          % (n, n / canvas.numel(), t * 1e3, 109.734912 / t, (canvas.numel() + n) / t / 1e9), flush=True)
