@@ -557,12 +557,12 @@ __global__ __launch_bounds__(256) void ist_stitch_kernel(const LaunchArgs A, con
   }
 }
 
+static unsigned g_dyn_lds = 0;   // IST_DYN_LDS tuning knob: unused dynamic LDS per workgroup caps the workgroups per CU
+
 template <int PATHS, int V, bool PERSIST>
 static void launch_one(const LaunchArgs& args, int64_t n_tiles, hipStream_t stream, int persist_blocks) {
   const unsigned grid = PERSIST ? static_cast<unsigned>(std::min<int64_t>(n_tiles, persist_blocks)) : static_cast<unsigned>(n_tiles);
-  // IST_DYN_LDS (bytes): tuning knob, reserves unused dynamic LDS per workgroup to cap the workgroups resident per CU
-  unsigned dyn = std::getenv("IST_DYN_LDS") ? static_cast<unsigned>(std::atoi(std::getenv("IST_DYN_LDS"))) : 0u;
-  dyn = std::max(dyn, static_cast<unsigned>(args.lds_words) * 4u);
+  const unsigned dyn = std::max(g_dyn_lds, static_cast<unsigned>(args.lds_words) * 4u);
   hipLaunchKernelGGL((ist_stitch_kernel<PATHS, V, PERSIST>), dim3(grid), dim3(256), dyn, stream, args, n_tiles);
 }
 
@@ -575,10 +575,13 @@ static void launch_variant(int v, bool persist, const LaunchArgs& a, int64_t n, 
 
 int launch_stitch(const LaunchArgs& args, int64_t n_tiles, bool lean, void* stream) {
   if (n_tiles <= 0) return IST_OK;
-  // tuning knobs (benchmarks only): IST_VARIANT = copy variant + 100 * persistent; IST_PERSIST_BLOCKS; IST_FULL_KERNEL
-  const int knob = std::getenv("IST_VARIANT") ? std::atoi(std::getenv("IST_VARIANT")) : 0;
-  const int pb = std::getenv("IST_PERSIST_BLOCKS") ? std::atoi(std::getenv("IST_PERSIST_BLOCKS")) : 2048;
-  const bool full = std::getenv("IST_FULL_KERNEL") != nullptr;
+  // tuning knobs, read only when the process was started with IST_TUNING=1 (tools/sweep_*.py): IST_VARIANT = copy variant
+  // + 100 * persistent; IST_PERSIST_BLOCKS; IST_FULL_KERNEL; IST_DYN_LDS.  Production launches touch no environment.
+  static const bool tuning = std::getenv("IST_TUNING") != nullptr;
+  const int knob = tuning && std::getenv("IST_VARIANT") ? std::atoi(std::getenv("IST_VARIANT")) : 0;
+  const int pb = tuning && std::getenv("IST_PERSIST_BLOCKS") ? std::atoi(std::getenv("IST_PERSIST_BLOCKS")) : 2048;
+  const bool full = tuning && std::getenv("IST_FULL_KERNEL") != nullptr;
+  g_dyn_lds = tuning && std::getenv("IST_DYN_LDS") ? static_cast<unsigned>(std::atoi(std::getenv("IST_DYN_LDS"))) : 0u;
   const int v = knob % 100;
   const bool persist = knob >= 100;
   hipStream_t s = static_cast<hipStream_t>(stream);

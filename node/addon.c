@@ -40,7 +40,7 @@ static pthread_once_t g_ctx_once = PTHREAD_ONCE_INIT;
 static char g_ctx_err[256];
 static void make_ctx(void) {
   g_ctx = ist_ctx_create(0);
-  if (!g_ctx) strncpy(g_ctx_err, ist_last_error(), sizeof g_ctx_err - 1);
+  if (!g_ctx) snprintf(g_ctx_err, sizeof g_ctx_err, "%s", ist_last_error());
 }
 /* one context for the process; NULL (with the reason in g_ctx_err) when there is no HIP device: no CPU fallback */
 static ist_ctx* get_ctx(void) {
@@ -229,7 +229,7 @@ static void stitch_execute(napi_env env, void* data) {
   (void)env;
   stitch_job* j = (stitch_job*)data;
   ist_ctx* ctx = get_ctx();
-  if (!ctx) { j->rc = IST_E_NO_DEVICE; strncpy(j->err, g_ctx_err, sizeof j->err - 1); return; }
+  if (!ctx) { j->rc = IST_E_NO_DEVICE; snprintf(j->err, sizeof j->err, "%s", g_ctx_err); return; }
   for (int i = 0; i < j->im.n; i++)
     if (!j->im.data[i]) { j->rc = IST_E_DECODE; snprintf(j->err, sizeof j->err, "\xe5\x9b\xbe\xe7\x89\x87%d\xe8\xa7\xa3\xe7\xa0\x81\xe5\xbc\x82\xe5\xb8\xb8", i); return; }
   if (j->want_png)
@@ -238,7 +238,7 @@ static void stitch_execute(napi_env env, void* data) {
   else
     j->rc = ist_stitch_rgba8(ctx, j->im.descs, j->im.data, j->im.pitch, j->im.n, j->direction, j->mode, j->gap, &j->lim,
                              j->filter, &j->plan, &j->pixels);
-  if (j->rc < 0) strncpy(j->err, ist_last_error(), sizeof j->err - 1);
+  if (j->rc < 0) snprintf(j->err, sizeof j->err, "%s", ist_last_error());
 }
 
 static napi_value make_error(napi_env env, int code, const char* why) {

@@ -12,7 +12,8 @@
  * opts      = {mode: 'min'|'max'|'original' (default 'min', index.js:19-20), gap: 0..20 (default 0, index.js:17),
  *              filter: 'bilinear'|'nearest' (imageSmoothingEnabled, index.js:1416), platform: 'ios'|'android'|'devtools'
  *              (reproduces the phone caps, index.js:1323-1336; default: caps lifted, superSample 1),
- *              maxSide, maxPixels (deviceMaxCanvasSize/Pixels), superSample (MAX_SUPER_SAMPLE, index.js:1363)}
+ *              maxSide, maxPixels (deviceMaxCanvasSize/Pixels), superSample (MAX_SUPER_SAMPLE, index.js:1363),
+ *              onProgress: (percent) => void  (the stitchProgress checkpoints of index.js:1193-1611)}
  * Errors reject with Error('拼图失败：' + reason) like the reference's catch (index.js:1618-1624); err.code is the
  * C-ABI code.  No pixel arithmetic happens in JavaScript; there is no CPU fallback.
  */
@@ -23,7 +24,7 @@ const DIRECTION = { vertical: 0, horizontal: 1 };
 const MODE = { min: 0, max: 1, original: 2 };
 const FILTER = { nearest: 0, bilinear: 1 };
 const PLATFORM = { other: 0, devtools: 0, windows: 0, mac: 0, ios: 1, android: 2 };
-const KNOWN = ['mode', 'gap', 'filter', 'platform', 'maxSide', 'maxPixels', 'superSample'];
+const KNOWN = ['mode', 'gap', 'filter', 'platform', 'maxSide', 'maxPixels', 'superSample', 'onProgress'];
 
 function limitsOf(opts) {
   const o = opts || {};
@@ -49,10 +50,21 @@ function args(images, direction, opts) {
   return [images || [], DIRECTION[direction], MODE[mode], Number(o.gap) || 0, limitsOf(o), FILTER[filter]];
 }
 
+// The reference reports progress through setData({stitchProgress}): 1 at the start (index.js:1193), 25 when every image
+// is prepared (:1247-1248), 30 after planning (:1358), 30 + 60*(i+1)/n (capped at 90) per drawn image (:1556-1557), 96
+// after the export (:1581), 100 at the end (:1611).  Here the draw loop is ONE launch, so the per-image steps collapse
+// into 90; opts.onProgress(percent) receives the same checkpoints.
+function withProgress(opts, run) {
+  const cb = opts && typeof opts.onProgress === 'function' ? opts.onProgress : null;
+  if (!cb) return run();
+  cb(1); cb(25); cb(30);
+  return run().then((r) => { cb(90); cb(96); cb(100); return r; }, (e) => { cb(0); throw e; });       // failure resets to 0 (:1622)
+}
+
 function stitch(images, direction, opts) {
   let a;
   try { a = args(images, direction, opts); } catch (e) { return Promise.reject(e); }
-  return native.stitch(...a);
+  return withProgress(opts, () => native.stitch(...a));
 }
 function stitchSync(images, direction, opts) { return native.stitchSync(...args(images, direction, opts)); }
 /** stitch + the reference's export step: resolves {width, height, png: Buffer (a lossless PNG file), plan}. The canvas
@@ -60,7 +72,7 @@ function stitchSync(images, direction, opts) { return native.stitchSync(...args(
 function stitchPng(images, direction, opts) {
   let a;
   try { a = args(images, direction, opts); } catch (e) { return Promise.reject(e); }
-  return native.stitch(...a, true);
+  return withProgress(opts, () => native.stitch(...a, true));
 }
 /** Lossless PNG of RGBA8 pixels, encoded on the GPU. */
 function encodePng(data, width, height) { return native.encodePng(data, width, height); }

@@ -71,3 +71,34 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"(from|import)\s+oracle|oracle/|libist_oracle|orc_", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_planner_argument_errors_map_to_codes():
+    import ctypes as C
+    from imagestitching_amd import _lib as L
+    lim = L.Limits()
+    L.lib.ist_limits_unlimited(C.byref(lim))
+    plan = L.Plan()
+    descs = (L.ImageDesc * 1)(L.ImageDesc(4, 4, 1, 0, 0, 0, 0))
+    assert L.lib.ist_plan_compute(descs, 0, 0, 0, 0.0, C.byref(lim), C.byref(plan)) == L.IST_NOTHING_TO_DO
+    assert L.lib.ist_plan_compute(descs, 1, 7, 0, 0.0, C.byref(lim), C.byref(plan)) == -1          # bad direction
+    assert "direction" in L.last_error()
+    assert L.lib.ist_plan_compute(None, 1, 0, 0, 0.0, C.byref(lim), C.byref(plan)) == -1           # NULL images
+    assert L.lib.ist_plan_compute(descs, 1, 0, 99, 0.0, C.byref(lim), C.byref(plan)) == 0          # unknown mode -> 'min' (index.js:1257)
+    L.lib.ist_plan_free(C.byref(plan))
+    huge = (L.ImageDesc * 2)(L.ImageDesc(2 ** 30, 8, 1, 0, 0, 0, 0), L.ImageDesc(2 ** 30, 8, 1, 0, 0, 0, 0))
+    assert L.lib.ist_plan_compute(huge, 2, 1, 0, 0.0, C.byref(lim), C.byref(plan)) == 0            # the caps shrink it (index.js:1337-1357)
+    assert plan.canvas_w <= 1048576 and plan.scale_down < 1.0
+    L.lib.ist_plan_free(C.byref(plan))
+    lim.max_side, lim.max_pixels = float(2 ** 40), float(2 ** 70)
+    assert L.lib.ist_plan_compute(huge, 2, 1, 0, 0.0, C.byref(lim), C.byref(plan)) == -3           # canvas side beyond 2^29
+    assert L.lib.ist_png_bound(0, 5) == 0 and L.lib.ist_png_bound(4032, 27216) > 4032 * 27216 * 4
+
+
+def test_job_and_render_need_a_context():
+    import ctypes as C
+    from imagestitching_amd import _lib as L
+    assert not L.lib.ist_job_create(None, 4, 4, None, None, 0, None, 0, 1, None)
+    assert "绘图上下文" in L.last_error()                                                              # index.js:1412
+    out, n = C.POINTER(C.c_uint8)(), C.c_int64(0)
+    assert L.lib.ist_png_encode_rgba8(None, None, 0, 1, 1, C.byref(out), C.byref(n)) == -4

@@ -155,3 +155,15 @@ def test_node_png_export(tmp_path):
                           "outDir": str(tmp_path)}, tmp_path)
     assert rc == 0, err
     assert np.array_equal(np.asarray(Image.open(meta["plan"]["file"]).convert("RGBA")), ref)
+
+
+@needs_node
+def test_node_progress_checkpoints_and_option_validation():
+    code = ("const api=require('%s/node/index.js'); const seen=[];"
+            "let bad=0; try{api.plan([],'diagonal')}catch(e){bad++} try{api.plan([],'vertical',{bogus:1})}catch(e){bad++}"
+            "api.stitch([], 'vertical', {onProgress:p=>seen.push(p)}).then(r=>console.log(JSON.stringify({r, seen, bad})), e=>console.log(JSON.stringify({err:e.message, code:e.code, seen, bad})));") % ROOT
+    out = subprocess.run([NODE, "-e", code], capture_output=True, text=True, timeout=60)
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["bad"] == 2
+    # empty image list: the reference returns early (index.js:1189) -> resolves null, progress ran to 100
+    assert res.get("r", "x") is None and res["seen"] == [1, 25, 30, 90, 96, 100]

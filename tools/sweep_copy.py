@@ -4,6 +4,8 @@
 import os
 import sys
 
+os.environ["IST_TUNING"] = "1"      # the launch-time knobs are only read in tuning mode
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
