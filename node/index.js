@@ -64,14 +64,16 @@ function withProgress(opts, run) {
 function stitch(images, direction, opts) {
   let a;
   try { a = args(images, direction, opts); } catch (e) { return Promise.reject(e); }
+  if (!a[0].length) return Promise.resolve(null);      // `if (!originalImages.length) return;` (index.js:1189): no progress, no error
   return withProgress(opts, () => native.stitch(...a));
 }
-function stitchSync(images, direction, opts) { return native.stitchSync(...args(images, direction, opts)); }
+function stitchSync(images, direction, opts) { const a = args(images, direction, opts); return a[0].length ? native.stitchSync(...a) : null; }
 /** stitch + the reference's export step: resolves {width, height, png: Buffer (a lossless PNG file), plan}. The canvas
  *  never leaves the GPU; only the PNG bytes cross PCIe (utils/canvas.js:205-242, index.js:1577-1579). */
 function stitchPng(images, direction, opts) {
   let a;
   try { a = args(images, direction, opts); } catch (e) { return Promise.reject(e); }
+  if (!a[0].length) return Promise.resolve(null);
   return withProgress(opts, () => native.stitch(...a, true));
 }
 /** Lossless PNG of RGBA8 pixels, encoded on the GPU. */

@@ -165,5 +165,5 @@ def test_node_progress_checkpoints_and_option_validation():
     out = subprocess.run([NODE, "-e", code], capture_output=True, text=True, timeout=60)
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["bad"] == 2
-    # empty image list: the reference returns early (index.js:1189) -> resolves null, progress ran to 100
-    assert res.get("r", "x") is None and res["seen"] == [1, 25, 30, 90, 96, 100]
+    # empty image list: the reference returns before touching any state (index.js:1189) -> resolves null, no progress
+    assert res.get("r", "x") is None and res["seen"] == []
