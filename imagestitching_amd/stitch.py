@@ -215,6 +215,35 @@ def _take_png(out, n):
         L.lib.ist_free(out)
 
 
+def decode_png(data):
+    """PNG file bytes -> HxWx4 uint8 RGBA (straight alpha).  Host decode (zlib + the PNG predictors); no GPU needed."""
+    buf = bytes(data)
+    w, h = C.c_int32(0), C.c_int32(0)
+    L.check(L.lib.ist_png_info(buf, len(buf), C.byref(w), C.byref(h)))
+    out = np.empty((h.value, w.value, 4), np.uint8)
+    L.check(L.lib.ist_png_decode_rgba8(buf, len(buf), out.ctypes.data, out.strides[0]))
+    return out
+
+
+def stitch_files(paths, direction, opts=None, out_path=None, device=0):
+    """File to file for PNG inputs: decode (host) -> stitch -> PNG export (GPU).  Returns the PNG bytes (and writes
+    out_path when given).  The mini-program's whole onStitch for 'png' images: index.js:1441-1581."""
+    images = []
+    for i, p in enumerate(paths):
+        with open(p, "rb") as f:
+            data = f.read()
+        try:
+            px = decode_png(data)
+        except L.StitchError as e:
+            raise L.StitchError(e.code, "图片%d解码异常: %s" % (i, e.reason))
+        images.append({"width": px.shape[1], "height": px.shape[0], "data": px, "fileSize": len(data)})
+    res = stitch_png(images, direction, opts, device)
+    if res is not None and out_path:
+        with open(out_path, "wb") as f:
+            f.write(res["png"])
+    return res
+
+
 def encode_png(pixels, device=0):
     """Lossless PNG (colour type 6) of an HxWx4 uint8 array, encoded on the GPU (export step, utils/canvas.js:205-242)."""
     a = np.asarray(pixels)

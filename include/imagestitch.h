@@ -160,6 +160,12 @@ IST_API int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, c
                              const ist_region* region, uint8_t* dst, size_t dst_pitch);
 IST_API void ist_free(void* p);
 
+/* ---- decode: PNG file -> RGBA8 (host; the Image.src step, utils/canvas.js:27-121, for 'png' inputs, index.js:4) ---- */
+/* colour types 0/2/3/4/6, bit depths 1-16 (16-bit keeps the high byte), tRNS, non-interlaced.  JPEG / WebP / HEIC and
+ * Adam7 return IST_E_UNSUPPORTED; damaged files IST_E_DECODE ('图片N解码异常' analogue). */
+IST_API int ist_png_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height);
+IST_API int ist_png_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch);
+
 /* ---- export: lossless PNG (fileType 'png', quality 1; utils/canvas.js:205-242, index.js:1577-1579) --------------- */
 /* upper bound of the file size for a w x h RGBA canvas */
 IST_API int64_t ist_png_bound(int64_t w, int64_t h);

@@ -85,7 +85,10 @@ class ShimImage {
   set src(v) {
     this._src = v;
     if (!v) { this._pixels = null; this.width = 0; this.height = 0; return; }     // `bmp.src = ''` releases (index.js:1569)
-    const f = this._files[v];
+    let f = this._files[v];
+    if (!f && /\.png$/i.test(v)) {          // a real PNG on disk: decode it (the platform's Image.src does the same)
+      try { f = this._files[v] = native.decodePng(require('fs').readFileSync(v)); } catch (e) { f = null; }
+    }
     setImmediate(() => {
       if (this._src !== v) return;
       if (f && f.data) { this.width = f.width; this.height = f.height; this._pixels = f.data; this._opaque = !!f.opaque; if (this.onload) this.onload(); }

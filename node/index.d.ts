@@ -29,3 +29,5 @@ export function plan(images: StitchImage[], direction: Direction, opts?: StitchO
 export interface StitchPngResult { width: number; height: number; png: Buffer; plan: StitchPlan; }
 export function stitchPng(images: StitchImage[], direction: Direction, opts?: StitchOptions): Promise<StitchPngResult | null>;
 export function encodePng(data: Uint8Array, width: number, height: number): Buffer;
+export function decodePng(file: Uint8Array): { width: number; height: number; data: Buffer };
+export function stitchFiles(paths: string[], direction: Direction, opts?: StitchOptions, outPath?: string): Promise<StitchPngResult | null>;

@@ -76,6 +76,22 @@ function stitchPng(images, direction, opts) {
   if (!a[0].length) return Promise.resolve(null);
   return withProgress(opts, () => native.stitch(...a, true));
 }
+/** PNG file bytes -> {width, height, data} (RGBA8, straight alpha). Host decode: the Image.src step for 'png' inputs
+ *  (utils/canvas.js:27-121; SUPPORTED_IMAGE_TYPES, index.js:4). JPEG / WebP / HEIC are not built: err.code '-7'. */
+function decodePng(file) { return native.decodePng(file); }
+/** File to file for PNG inputs: decode -> stitch -> PNG export. Resolves {width, height, png, plan}; writes opts-free
+ *  outPath when given. A file that does not decode rejects with '图片N解码异常' like index.js:1512-1514. */
+async function stitchFiles(paths, direction, opts, outPath) {
+  const fs = require('fs');
+  const images = paths.map((p, i) => {
+    const file = fs.readFileSync(p);
+    try { return Object.assign(native.decodePng(file), { fileSize: file.length }); }
+    catch (e) { const err = new Error('拼图失败：图片' + i + '解码异常: ' + String(e.message).replace(/^拼图失败：/, '')); err.code = e.code; throw err; }
+  });
+  const res = await stitchPng(images, direction, opts);
+  if (res && outPath) fs.writeFileSync(outPath, res.png);
+  return res;
+}
 /** Lossless PNG of RGBA8 pixels, encoded on the GPU. */
 function encodePng(data, width, height) { return native.encodePng(data, width, height); }
 function plan(images, direction, opts) {
@@ -83,4 +99,4 @@ function plan(images, direction, opts) {
   return native.plan(a[0], a[1], a[2], a[3], a[4]);
 }
 
-module.exports = { stitch, stitchSync, stitchPng, encodePng, plan, native, DIRECTION, MODE, FILTER, PLATFORM };
+module.exports = { stitch, stitchSync, stitchPng, stitchFiles, encodePng, decodePng, plan, native, DIRECTION, MODE, FILTER, PLATFORM };

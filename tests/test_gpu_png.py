@@ -92,3 +92,22 @@ def test_png_device_resident_full_size():
     assert len(png) == n and n < ist._lib.lib.ist_png_bound(4032, 27216)
     got, n_idat = _decode_by_hand(png)
     assert n_idat == 1 and np.array_equal(got, canvas.cpu().numpy())
+
+
+def test_stitch_files_png_in_png_out(tmp_path):
+    from PIL import Image
+    px = [U.rand_image(430 + i, h, w, opaque=(i != 1)) for i, (w, h) in enumerate([(120, 90), (90, 120), (64, 33)])]
+    paths = []
+    for i, a in enumerate(px):
+        Image.fromarray(a, "RGBA").save(tmp_path / ("in%d.png" % i))
+        paths.append(str(tmp_path / ("in%d.png" % i)))
+    res = ist.stitch_files(paths, "horizontal", {"mode": "min", "gap": 2}, out_path=str(tmp_path / "out.png"))
+    ref, pd, _ = U.oracle_stitch(px, "horizontal", {"mode": "min", "gap": 2})
+    got = np.asarray(Image.open(tmp_path / "out.png").convert("RGBA"))
+    assert (res["width"], res["height"]) == (ref.shape[1], ref.shape[0])
+    assert U.max_abs_diff(got, ref) <= 1
+    assert np.array_equal(ist.decode_png(res["png"]), got)          # own decoder reads own encoder's files
+    with pytest.raises(ist.StitchError) as e:
+        (tmp_path / "bad.png").write_bytes(b"not a png at all, definitely not, no no no no no no no no no no no")
+        ist.stitch_files([paths[0], str(tmp_path / "bad.png")], "vertical")
+    assert "图片1解码异常" in str(e.value)

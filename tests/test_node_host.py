@@ -167,3 +167,39 @@ def test_node_progress_checkpoints_and_option_validation():
     assert res["bad"] == 2
     # empty image list: the reference returns before touching any state (index.js:1189) -> resolves null, no progress
     assert res.get("r", "x") is None and res["seen"] == []
+
+
+@needs_node
+def test_node_decode_png_matches_pil(tmp_path):
+    from PIL import Image
+    a = U.rand_image(600, 23, 31, opaque=False)
+    Image.fromarray(a, "RGBA").save(tmp_path / "a.png")
+    code = ("const api=require('%s/node/index.js'); const fs=require('fs');"
+            "const r=api.decodePng(fs.readFileSync(process.argv[1])); fs.writeFileSync(process.argv[2], r.data); console.log(JSON.stringify([r.width,r.height]));"
+            "try{api.decodePng(Buffer.from([0xff,0xd8,0xff,0xe0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46]))}catch(e){console.log(JSON.stringify({code:e.code,msg:e.message}))}") % ROOT
+    out = subprocess.run([NODE, "-e", code, str(tmp_path / "a.png"), str(tmp_path / "a.rgba")], capture_output=True, text=True, timeout=60)
+    lines = out.stdout.strip().splitlines()
+    assert json.loads(lines[0]) == [31, 23], out.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "a.rgba", np.uint8).reshape(23, 31, 4), a)
+    err = json.loads(lines[1])
+    assert err["code"] == "-7" and "JPEG" in err["msg"]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_stitch_files_png_in_png_out(tmp_path):
+    """File to file: PNG inputs -> decode -> stitch -> GPU PNG export (the whole onStitch for 'png' images)."""
+    from PIL import Image
+    px = [U.rand_image(610 + i, h, w) for i, (w, h) in enumerate([(64, 48), (50, 80), (33, 20)])]
+    paths = []
+    for i, a in enumerate(px):
+        p = tmp_path / ("in%d.png" % i)
+        Image.fromarray(a, "RGBA").save(p)
+        paths.append(str(p))
+    code = ("const api=require('%s/node/index.js');"
+            "api.stitchFiles(JSON.parse(process.argv[1]),'vertical',{mode:'max',gap:3},process.argv[2]).then(r=>console.log(JSON.stringify([r.width,r.height,r.png.length])),e=>{console.log(e.message);process.exit(3)});") % ROOT
+    out = subprocess.run([NODE, "-e", code, json.dumps(paths), str(tmp_path / "out.png")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    ref, pd, _ = U.oracle_stitch(px, "vertical", {"mode": "max", "gap": 3})
+    got = np.asarray(Image.open(tmp_path / "out.png").convert("RGBA"))
+    assert got.shape == ref.shape and U.max_abs_diff(got, ref) <= 1

@@ -1,0 +1,117 @@
+"""PNG decode (PNG inputs): pinned bit for bit by PIL on files PIL wrote — every colour
+type, bit depth, filter heuristic and tRNS flavour the decoder claims.  CPU only (the decoder is host code)."""
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import imagestitching_amd as ist
+
+RNG = np.random.default_rng(77)
+
+
+def _png(img, **kw):
+    b = io.BytesIO()
+    img.save(b, "PNG", **kw)
+    return b.getvalue()
+
+
+def _smooth(h, w, c):
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.stack([(xx * 3 + yy * 5 + 40 * k) % 256 for k in range(c)], -1).astype(np.uint8)
+    return a
+
+
+@pytest.mark.parametrize("mode,shape", [("RGBA", (37, 53, 4)), ("RGB", (21, 64, 3)), ("L", (19, 33)), ("LA", (16, 17, 2))])
+@pytest.mark.parametrize("content", ["noise", "smooth"])
+def test_8bit_colour_types(mode, shape, content):
+    a = RNG.integers(0, 256, shape, dtype=np.uint8) if content == "noise" else _smooth(shape[0], shape[1], shape[2] if len(shape) == 3 else 1).reshape(shape)
+    img = Image.fromarray(a, mode)
+    for kw in ({}, {"compress_level": 9}, {"optimize": True}):
+        got = ist.decode_png(_png(img, **kw))
+        assert np.array_equal(got, np.asarray(img.convert("RGBA")))
+
+
+@pytest.mark.parametrize("bits", [1, 2, 4, 8])
+def test_palette_and_low_bit_depths(bits):
+    n = 1 << bits
+    idx = RNG.integers(0, n, (23, 45), dtype=np.uint8)
+    img = Image.fromarray(idx, "P")
+    pal = RNG.integers(0, 256, 3 * n, dtype=np.uint8).tolist()
+    img.putpalette(pal + [0] * (768 - len(pal)))
+    data = _png(img, bits=bits)
+    assert np.array_equal(ist.decode_png(data), np.asarray(img.convert("RGBA")))
+    # palette transparency
+    data = _png(img, bits=bits, transparency=bytes(RNG.integers(0, 256, n, dtype=np.uint8).tolist()))
+    assert np.array_equal(ist.decode_png(data), np.asarray(Image.open(io.BytesIO(data)).convert("RGBA")))
+
+
+def test_grey_1bit_and_trns_colour_key():
+    a = (RNG.integers(0, 2, (17, 29)) * 255).astype(np.uint8)
+    img = Image.fromarray(a, "L").convert("1")
+    assert np.array_equal(ist.decode_png(_png(img)), np.asarray(img.convert("RGBA")))
+    rgb = Image.fromarray(RNG.integers(0, 4, (9, 9, 3), dtype=np.uint8) * 60, "RGB")
+    data = _png(rgb, transparency=(60, 120, 180))
+    assert np.array_equal(ist.decode_png(data), np.asarray(Image.open(io.BytesIO(data)).convert("RGBA")))
+
+
+def test_16bit_keeps_high_byte():
+    a = RNG.integers(0, 65536, (11, 13), dtype=np.uint16)
+    img = Image.fromarray(a, "I;16")
+    got = ist.decode_png(_png(img))
+    assert np.array_equal(got[..., 0], (a >> 8).astype(np.uint8)) and (got[..., 3] == 255).all()
+
+
+def _chunk(t, d):
+    return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+
+def test_every_filter_type_by_hand():
+    """Rows filtered by hand with each of the five predictors (PIL picks filters adaptively; this forces them)."""
+    h, w = 10, 14
+    px = RNG.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    raw, prev = b"", np.zeros(w * 4, np.int32)
+    for y in range(h):
+        cur = px[y].reshape(-1).astype(np.int32)
+        ft = y % 5
+        left = np.concatenate([np.zeros(4, np.int32), cur[:-4]])
+        upleft = np.concatenate([np.zeros(4, np.int32), prev[:-4]])
+        if ft == 0: f = cur
+        elif ft == 1: f = cur - left
+        elif ft == 2: f = cur - prev
+        elif ft == 3: f = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = abs(p - left), abs(p - prev), abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            f = cur - pred
+        raw += bytes([ft]) + (f & 255).astype(np.uint8).tobytes()
+        prev = cur
+    comp = zlib.compress(raw)
+    png = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + _chunk(b"IDAT", comp[:20]) + _chunk(b"IDAT", comp[20:]) + _chunk(b"IEND", b"")
+    assert np.array_equal(ist.decode_png(png), px)
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(png)).convert("RGBA")), px)      # PIL agrees the file is valid
+
+
+def test_errors_are_reported_like_decode_failures():
+    good = _png(Image.fromarray(RNG.integers(0, 256, (4, 4, 4), dtype=np.uint8), "RGBA"))
+    with pytest.raises(ist.StitchError) as e:
+        ist.decode_png(b"\xff\xd8\xff\xe0" + b"0" * 100)
+    assert e.value.code == -7 and "JPEG" in str(e.value)
+    with pytest.raises(ist.StitchError) as e:
+        ist.decode_png(good[:40])
+    assert e.value.code == -6
+    bad = bytearray(good)
+    bad[50] ^= 0xFF
+    with pytest.raises(ist.StitchError) as e:
+        ist.decode_png(bytes(bad))
+    assert e.value.code == -6 and "CRC" in str(e.value)
+    inter = _png(Image.fromarray(RNG.integers(0, 256, (8, 8, 3), dtype=np.uint8), "RGB"))
+    inter = bytearray(inter); inter[28] = 1
+    inter[29:33] = struct.pack(">I", zlib.crc32(bytes(inter[12:29])))
+    with pytest.raises(ist.StitchError) as e:
+        ist.decode_png(bytes(inter))
+    assert e.value.code == -7 and "Adam7" in str(e.value)
