@@ -149,14 +149,11 @@ __global__ __launch_bounds__(256) void ist_png_rows_kernel(const PngArgs P) {
     }
     // Adler: byte j of the chunk sits at index q = 1 + p + j of the row stream (length L = row_bytes + 1) and weighs L - q
     uint32_t t1 = 0, t2 = 0;
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};              // bytes past nbytes are zero
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t byte = (w[d] >> (8 * j)) & 0xFF;       // bytes past nbytes are zero
-        t1 += byte; t2 += byte * static_cast<uint32_t>(4 * d + j);
-      }
+    for (int d = 0; d < 4; ++d) {                            // v_dot4_u32_u8: byte sums and index-weighted byte sums
+      t1 = __builtin_amdgcn_udot4(w[d], 0x01010101u, t1, false);
+      t2 = __builtin_amdgcn_udot4(w[d], static_cast<uint32_t>(4 * d) * 0x01010101u + 0x03020100u, t2, false);
     }
     a1 = t1;
     a2 = static_cast<unsigned long long>(P.row_bytes - p) * t1 - t2;
