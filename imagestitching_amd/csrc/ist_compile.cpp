@@ -21,18 +21,25 @@ static inline uint32_t pack_rgba(const uint8_t c[4]) {
 }
 
 // Shared arithmetic contract (DESIGN.md "raster contract"; the oracle implements the same formulas independently).
-int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, int img_h, DevOp* out) {
+int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, int img_h, DevOp* out, bool aa) {
   const double a = op.m[0], b = op.m[1], c = op.m[2], d = op.m[3], e = op.m[4], f = op.m[5];
   const bool straight = (b == 0.0 && c == 0.0 && a != 0.0 && d != 0.0);
   const bool turned = (a == 0.0 && d == 0.0 && b != 0.0 && c != 0.0);
   std::memset(out, 0, sizeof(*out));
   out->image = -1;
-  auto clip_box = [&](double xl, double xh, double yl, double yh) {
+  auto clip_box = [&](double xl, double xh, double yl, double yh, bool edge_aa) {
+    // pixel-centre rule, or (edge AA) every pixel the rectangle touches + the sub-box it covers completely
     double X0 = std::ceil(xl - 0.5), X1 = std::ceil(xh - 0.5), Y0 = std::ceil(yl - 0.5), Y1 = std::ceil(yh - 0.5);
-    X0 = std::max(X0, 0.0); Y0 = std::max(Y0, 0.0);
-    X1 = std::min(X1, static_cast<double>(canvas_w)); Y1 = std::min(Y1, static_cast<double>(canvas_h));
-    out->X0 = static_cast<int32_t>(X0); out->X1 = static_cast<int32_t>(X1);
-    out->Y0 = static_cast<int32_t>(Y0); out->Y1 = static_cast<int32_t>(Y1);
+    double I0 = X0, I1 = X1, J0 = Y0, J1 = Y1;
+    if (edge_aa) {
+      X0 = std::floor(xl); X1 = std::ceil(xh); Y0 = std::floor(yl); Y1 = std::ceil(yh);
+      I0 = std::ceil(xl); I1 = std::floor(xh); J0 = std::ceil(yl); J1 = std::floor(yh);
+    }
+    auto cx = [&](double v) { return static_cast<int32_t>(std::min(std::max(v, 0.0), static_cast<double>(canvas_w))); };
+    auto cy = [&](double v) { return static_cast<int32_t>(std::min(std::max(v, 0.0), static_cast<double>(canvas_h))); };
+    out->X0 = cx(X0); out->X1 = cx(X1); out->Y0 = cy(Y0); out->Y1 = cy(Y1);
+    out->IX0 = cx(I0); out->IX1 = std::max(cx(I1), out->IX0); out->IY0 = cy(J0); out->IY1 = std::max(cy(J1), out->IY0);
+    out->xl = xl; out->xh = xh; out->yl = yl; out->yh = yh;
     return (out->X1 > out->X0 && out->Y1 > out->Y0);
   };
   if (op.kind == IST_OP_FILL || op.kind == IST_OP_HOLE) {
@@ -43,7 +50,7 @@ int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, 
     const double ya = d * op.d[1] + f, yb = d * (op.d[1] + op.d[3]) + f;
     out->flags = (op.kind == IST_OP_HOLE ? OPF_HOLE : OPF_FILL) | OPF_OPAQUE;
     out->rgba = pack_rgba(op.rgba);
-    return clip_box(std::min(xa, xb), std::max(xa, xb), std::min(ya, yb), std::max(ya, yb)) ? 0 : 1;
+    return clip_box(std::min(xa, xb), std::max(xa, xb), std::min(ya, yb), std::max(ya, yb), false) ? 0 : 1;   // fills keep the pixel-centre rule
   }
   if (op.kind != IST_OP_DRAW) return fail(IST_E_INVALID, "unknown op kind");
   if (!straight && !turned) return fail(IST_E_UNSUPPORTED, "drawImage under a non axis-aligned transform is outside the stitch path");
@@ -61,7 +68,7 @@ int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, 
   const double wa = ku * rx + eu, wb = ku * (rx + rw) + eu;
   const double za = kv * ry + ev, zb = kv * (ry + rh) + ev;
   const double wl = std::min(wa, wb), wh = std::max(wa, wb), zl = std::min(za, zb), zh = std::max(za, zb);
-  const bool any = turned ? clip_box(zl, zh, wl, wh) : clip_box(wl, wh, zl, zh);
+  const bool any = turned ? clip_box(zl, zh, wl, wh, aa) : clip_box(wl, wh, zl, zh, aa);
   double t;
   t = std::floor(sx);            out->cx0 = t < 0.0 ? 0 : static_cast<int32_t>(t);
   t = std::ceil(sx + sw) - 1.0;  out->cx1 = t > img_w - 1 ? img_w - 1 : static_cast<int32_t>(t);
@@ -117,9 +124,11 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
   if (canvas_w < 1 || canvas_h < 1 || canvas_w > (1 << 29) || canvas_h > 2147483647LL)
     return fail(IST_E_OUTPUT_SIZE, "输出尺寸计算失败: canvas size out of range");
   if (n_ops < 0 || (n_ops > 0 && !ops)) return fail(IST_E_INVALID, "compile_ops: bad op list");
+  const bool aa = (filter & IST_FILTER_EDGE_AA) != 0;
+  filter &= 0xFF;
   if (filter != IST_FILTER_NEAREST && filter != IST_FILTER_BILINEAR) return fail(IST_E_INVALID, "unknown filter");
   read_tile_knob();
-  out->canvas_w = canvas_w; out->canvas_h = canvas_h; out->filter = filter;
+  out->canvas_w = canvas_w; out->canvas_h = canvas_h; out->filter = filter | (aa ? IST_FILTER_EDGE_AA : 0);
   out->ops.clear(); out->cells.clear(); out->stacks.clear(); out->bands.clear();
   out->lds_words = 0;
   out->img_w.assign(static_cast<size_t>(n_images), 0);
@@ -148,7 +157,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
       if (iw < 1 || ih < 1) return fail(IST_E_DECODE, "图片" + std::to_string(ops[i].image) + "解码异常");
     }
     DevOp r;
-    const int rc = resolve_op(ops[i], canvas_w, canvas_h, iw, ih, &r);
+    const int rc = resolve_op(ops[i], canvas_w, canvas_h, iw, ih, &r, aa);
     if (rc < 0) return rc;
     if (rc > 0) continue;
     if (ops[i].kind == IST_OP_DRAW && images[ops[i].image].opaque) r.flags |= OPF_OPAQUE;
@@ -156,13 +165,18 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     r.X0 = static_cast<int32_t>(std::max<int64_t>(r.X0, RX0)); r.X1 = static_cast<int32_t>(std::min<int64_t>(r.X1, RX1));
     r.Y0 = static_cast<int32_t>(std::max<int64_t>(r.Y0, RY0)); r.Y1 = static_cast<int32_t>(std::min<int64_t>(r.Y1, RY1));
     if (r.X1 <= r.X0 || r.Y1 <= r.Y0) continue;
+    r.IX0 = std::min(std::max(r.IX0, r.X0), r.X1); r.IX1 = std::min(std::max(r.IX1, r.IX0), r.X1);
+    r.IY0 = std::min(std::max(r.IY0, r.Y0), r.Y1); r.IY1 = std::min(std::max(r.IY1, r.IY0), r.Y1);
     out->ops.push_back(r);
   }
   const int n = static_cast<int>(out->ops.size());
 
   // 2. grid of break lines
   std::vector<int32_t> xs{static_cast<int32_t>(RX0), static_cast<int32_t>(RX1)}, ys{static_cast<int32_t>(RY0), static_cast<int32_t>(RY1)};
-  for (const DevOp& r : out->ops) { xs.push_back(r.X0); xs.push_back(r.X1); ys.push_back(r.Y0); ys.push_back(r.Y1); }
+  for (const DevOp& r : out->ops) {
+    xs.push_back(r.X0); xs.push_back(r.X1); ys.push_back(r.Y0); ys.push_back(r.Y1);
+    xs.push_back(r.IX0); xs.push_back(r.IX1); ys.push_back(r.IY0); ys.push_back(r.IY1);     // = the outer edges unless edge AA
+  }
   std::sort(xs.begin(), xs.end()); xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
   std::sort(ys.begin(), ys.end()); ys.erase(std::unique(ys.begin(), ys.end()), ys.end());
 
@@ -192,8 +206,9 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
       for (int k = 0; k < n; ++k) {
         const DevOp& r = out->ops[k];
         if (r.X0 <= X0 && X1 <= r.X1 && r.Y0 <= Y0 && Y1 <= r.Y1) {
-          if (r.flags & OPF_OPAQUE) stack.clear();
-          stack.push_back(k);
+          const bool full = r.IX0 <= X0 && X1 <= r.IX1 && r.IY0 <= Y0 && Y1 <= r.IY1;     // false only on fractional edge strips
+          if ((r.flags & OPF_OPAQUE) && full) stack.clear();
+          stack.push_back(full ? k : ~k);          // ~k marks a partially covering op: the cell goes through the general path
         }
       }
       if (have_prev && stack == prev_stack) {       // extend the previous cell to the right
@@ -202,7 +217,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
         pc.X1 = X1;
         continue;
       }
-      if (!stack.empty() && (out->ops[stack[0]].flags & OPF_HOLE)) {
+      if (!stack.empty() && stack[0] >= 0 && (out->ops[stack[0]].flags & OPF_HOLE)) {
         if (stack.size() > 1) return fail(IST_E_UNSUPPORTED, "drawing over a region reserved for another producer");
         have_prev = false;          // nothing is written here
         continue;
@@ -214,10 +229,12 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
       // the colour under the stack
       uint32_t bg_pm = clear_pm, bg_back = clear_back;
       size_t first = 0;
-      if (!stack.empty() && (out->ops[stack[0]].flags & OPF_FILL)) { bg_pm = bg_back = out->ops[stack[0]].rgba; first = 1; }
-      for (size_t k = first; k < stack.size(); ++k) out->stacks.push_back(stack[k]);
+      if (!stack.empty() && stack[0] >= 0 && (out->ops[stack[0]].flags & OPF_FILL)) { bg_pm = bg_back = out->ops[stack[0]].rgba; first = 1; }
+      bool partial = false;
+      for (size_t k = first; k < stack.size(); ++k) { partial |= stack[k] < 0; out->stacks.push_back(stack[k] < 0 ? ~stack[k] : stack[k]); }
       cell.stack_len = static_cast<int32_t>(stack.size() - first);
       cell.op = cell.stack_len ? out->stacks[cell.stack_off] : -1;
+      cell.tiles_x = partial ? -1 : 0;            // temporary mark, consumed by the classification below
       cell.bg = bg_pm;
       out->cells.push_back(cell);
       prev_stack = stack; have_prev = true;
@@ -227,7 +244,11 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
   // 4. classify + tile each cell
   for (DevCell& cell : out->cells) {
     const bool bg_opaque = (cell.bg >> 24) == 255u;
-    if (cell.stack_len == 0) {
+    const bool partial = cell.tiles_x < 0;
+    cell.tiles_x = 0;
+    if (partial) {
+      cell.path = PATH_GENERAL;                   // fractional edge strip: per-pixel coverage
+    } else if (cell.stack_len == 0) {
       cell.path = PATH_FILL;
       if (!bg_opaque) cell.bg = clear_back;       // reads back un-premultiplied
     } else if (cell.stack_len == 1 && !(out->ops[cell.op].flags & OPF_SWAP) &&
@@ -245,7 +266,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     } else {
       cell.path = PATH_GENERAL;
       // one quarter-turned draw over an opaque colour, bilinear: stage the footprint transposed in LDS
-      if (cell.stack_len == 1 && (out->ops[cell.op].flags & OPF_SWAP) && filter == IST_FILTER_BILINEAR &&
+      if (!partial && cell.stack_len == 1 && (out->ops[cell.op].flags & OPF_SWAP) && filter == IST_FILTER_BILINEAR &&
           (bg_opaque || (out->ops[cell.op].flags & OPF_OPAQUE)) && !std::getenv("IST_NO_LDS")) {
         const DevOp& r = out->ops[cell.op];
         const double akx = std::fabs(r.kx), aky = std::fabs(r.ky);

@@ -36,8 +36,10 @@ struct alignas(16) DevOp {
   int32_t flags;
   int32_t cx0, cy0, cx1, cy1;   // inclusive clamp bounds in the source bitmap
   uint32_t rgba;            // fill colour, packed little-endian R,G,B,A
-  int32_t X0, Y0, X1, Y1;   // covered canvas pixels (clipped); host-side use
+  int32_t X0, Y0, X1, Y1;   // canvas pixels the draw touches (clipped); host-side use
   int32_t pad;
+  double xl, xh, yl, yh;    // continuous canvas-space extent of the destination rectangle (edge anti-aliasing)
+  int32_t IX0, IY0, IX1, IY1;   // pixels covered COMPLETELY (= X0..Y1 when edge AA is off); host-side use
 };
 
 // How a cell (a canvas rectangle whose paint stack is constant) is rendered
@@ -91,7 +93,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
                 const ist_image_desc* images, int n_images, int filter, const ist_region* clip, Compiled* out);
 
 // resolve one op (exposed for tests): returns 0 ok, 1 nothing drawn, <0 error
-int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, int img_h, DevOp* out);
+int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, int img_h, DevOp* out, bool edge_aa = false);
 
 }  // namespace ist
 

@@ -460,23 +460,62 @@ IST_DEV bool tile_swap_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int
 // immediate-mode Canvas with 8-bit premultiplied backing store does call by call)
 IST_DEV uint32_t pixel_general(const LaunchArgs& A, const DevCell c, int X, int Y) {
   uint32_t d = c.bg;
+  const bool nearest = (A.filter & 0xFF) == IST_FILTER_NEAREST;
+  const bool edge_aa = (A.filter & IST_FILTER_EDGE_AA) != 0;
   for (int k = 0; k < c.stack_len; ++k) {
     const DevOp op = A.ops[A.stacks[c.stack_off + k]];
+    // area of this pixel inside the destination rectangle (1 unless edge anti-aliasing is on and the edge is fractional)
+    double cov = 1.0;
+    if (edge_aa) {
+      const double cx = fmin(static_cast<double>(X) + 1.0, op.xh) - fmax(static_cast<double>(X), op.xl);
+      const double cy = fmin(static_cast<double>(Y) + 1.0, op.yh) - fmax(static_cast<double>(Y), op.yl);
+      cov = fmin(fmax(cx, 0.0), 1.0) * fmin(fmax(cy, 0.0), 1.0);
+      if (cov <= 0.0) continue;
+    }
     const bool sw = (op.flags & OPF_SWAP) != 0;
     const int wx = sw ? Y : X, wy = sw ? X : Y;
     const uint8_t* src = A.src[op.image];
     const size_t sp = A.pitch[op.image];
-    if (A.filter == IST_FILTER_NEAREST || (op.flags & OPF_IDENTITY)) {
+    if (nearest || (op.flags & OPF_IDENTITY)) {
       const int ix = nearest_tap(op.kx, op.ox, wx, op.cx0, op.cx1);
       const int iy = nearest_tap(op.ky, op.oy, wy, op.cy0, op.cy1);
-      d = over_int(ld4(src + static_cast<size_t>(iy) * sp + 4 * static_cast<size_t>(ix)), d);
+      const uint32_t s = ld4(src + static_cast<size_t>(iy) * sp + 4 * static_cast<size_t>(ix));
+      if (cov >= 1.0) { d = over_int(s, d); continue; }
+      // fractional edge: coverage-weighted source-over in fp64, the same operations in the same order as the oracle
+      const uint32_t a = s >> 24;
+      const double keep = 1.0 - cov * (static_cast<double>(a) / 255.0);
+      uint32_t o = 0;
+#pragma unroll
+      for (int ch_ = 0; ch_ < 3; ++ch_) {
+        const double P = static_cast<double>(ch(s, ch_) * a) / 255.0;
+        const double v = floor(P * cov + static_cast<double>(ch(d, ch_)) * keep + 0.5);
+        o |= static_cast<uint32_t>(fmin(fmax(v, 0.0), 255.0)) << (8 * ch_);
+      }
+      const double va = floor(static_cast<double>(a) * cov + static_cast<double>(d >> 24) * keep + 0.5);
+      d = o | (static_cast<uint32_t>(fmin(fmax(va, 0.0), 255.0)) << 24);
     } else {
       const Tap tx = bilinear_tap(op.kx, op.ox, wx, op.cx0, op.cx1);
       const Tap ty = bilinear_tap(op.ky, op.oy, wy, op.cy0, op.cy1);
       const uint8_t* r0 = src + static_cast<size_t>(ty.base) * sp + 4 * static_cast<size_t>(tx.base);
       const uint8_t* r1 = r0 + (op.cy1 > op.cy0 ? sp : 0);
       const size_t nx = op.cx1 > op.cx0 ? 4 : 0;
-      d = bilerp_over(ld4(r0), ld4(r0 + nx), ld4(r1), ld4(r1 + nx), tx.t, ty.t, d);
+      const uint32_t p00 = ld4(r0), p01 = ld4(r0 + nx), p10 = ld4(r1), p11 = ld4(r1 + nx);
+      if (cov >= 1.0) { d = bilerp_over(p00, p01, p10, p11, tx.t, ty.t, d); continue; }
+      const float a00 = static_cast<float>(p00 >> 24), a01 = static_cast<float>(p01 >> 24);
+      const float a10 = static_cast<float>(p10 >> 24), a11 = static_cast<float>(p11 >> 24);
+      const double Aa = static_cast<double>(lerpf(lerpf(a00, a01, tx.t), lerpf(a10, a11, tx.t), ty.t));
+      const double keep = 1.0 - cov * (Aa / 255.0);
+      uint32_t o = 0;
+#pragma unroll
+      for (int ch_ = 0; ch_ < 3; ++ch_) {
+        const float top = lerpf(static_cast<float>(ch(p00, ch_)) * a00, static_cast<float>(ch(p01, ch_)) * a01, tx.t);
+        const float bot = lerpf(static_cast<float>(ch(p10, ch_)) * a10, static_cast<float>(ch(p11, ch_)) * a11, tx.t);
+        const double P = static_cast<double>(lerpf(top, bot, ty.t)) / 255.0;
+        const double v = floor(P * cov + static_cast<double>(ch(d, ch_)) * keep + 0.5);
+        o |= static_cast<uint32_t>(fmin(fmax(v, 0.0), 255.0)) << (8 * ch_);
+      }
+      const double va = floor(Aa * cov + static_cast<double>(d >> 24) * keep + 0.5);
+      d = o | (static_cast<uint32_t>(fmin(fmax(va, 0.0), 255.0)) << 24);
     }
   }
   // readback is straight alpha (ImageData): un-premultiply
@@ -541,7 +580,7 @@ IST_DEV void run_tile(const LaunchArgs& A, int64_t tile) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (!tile_swap_lds(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1, lds)) tile_general(A, c, X0, Y0, X1, Y1);
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE) {
-    if (A.filter == IST_FILTER_NEAREST) tile_sample<IST_FILTER_NEAREST>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);
+    if ((A.filter & 0xFF) == IST_FILTER_NEAREST) tile_sample<IST_FILTER_NEAREST>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);
     else tile_sample<IST_FILTER_BILINEAR>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);
   } else if (PATHS & HAS_GENERAL) {
     tile_general(A, c, X0, Y0, X1, Y1);

@@ -63,6 +63,8 @@ class ShardedStitch:
     def __init__(self, images, direction, opts=None, rank=0, world=1, root=0):
         self.rank, self.world, self.root = rank, world, root
         self.opts = S._merge(opts)
+        if self.opts.get("edgeAA"):
+            raise L.StitchError(-7, "edge anti-aliasing blends neighbouring images in one pixel row: stitch on one GPU")
         self.plan = S.plan(images, direction, self.opts)
         if self.plan is None:
             raise ValueError("nothing to stitch")

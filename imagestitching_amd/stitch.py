@@ -17,6 +17,11 @@ from . import _lib as L
 _DIRECTIONS = {"vertical": L.VERTICAL, "horizontal": L.HORIZONTAL}
 _MODES = {"min": L.MODE_MIN, "max": L.MODE_MAX, "original": L.MODE_ORIGINAL}
 _FILTERS = {"nearest": L.FILTER_NEAREST, "bilinear": L.FILTER_BILINEAR}
+FILTER_EDGE_AA = 0x100
+
+
+def _filter_of(o):
+    return _FILTERS[o["filter"]] | (FILTER_EDGE_AA if o.get("edgeAA") else 0)
 _PLATFORMS = {"ios": L.PLATFORM_IOS, "android": L.PLATFORM_ANDROID, "devtools": L.PLATFORM_OTHER,
               "windows": L.PLATFORM_OTHER, "mac": L.PLATFORM_OTHER, "other": L.PLATFORM_OTHER}
 
@@ -28,6 +33,7 @@ DEFAULT_OPTS = {
     "maxSide": None,        # deviceMaxCanvasSize override
     "maxPixels": None,      # deviceMaxCanvasPixels override
     "superSample": None,    # None: 1 when platform is None, reference rule (index.js:1363) otherwise
+    "edgeAA": False,        # anti-alias fractional rectangle edges by area coverage (IST_FILTER_EDGE_AA)
 }
 
 
@@ -173,7 +179,7 @@ def stitch(images, direction, opts=None, device=0):
         data = np.empty((h, w, 4), np.uint8)
         clear = (C.c_uint8 * 4)(0, 0, 0, 0)
         L.check(L.lib.ist_render_rgba8(_ctx(device), w, h, clear, ops, n_ops.value, descs, ptrs, pitches, n,
-                                       _FILTERS[o["filter"]], None, data.ctypes.data, data.strides[0]))
+                                       _filter_of(o), None, data.ctypes.data, data.strides[0]))
     finally:
         L.lib.ist_plan_free(C.byref(cplan))
     return {"width": w, "height": h, "data": data}
@@ -196,7 +202,7 @@ def stitch_via_c_abi(images, direction, opts=None, device=0):
     lim = _limits(o)
     out = C.POINTER(C.c_uint8)()
     rc = L.check(L.lib.ist_stitch_rgba8(_ctx(device), descs, ptrs, pitches, n, _DIRECTIONS[direction], _MODES[o["mode"]],
-                                        float(o["gap"] or 0), C.byref(lim), _FILTERS[o["filter"]], C.byref(cplan), C.byref(out)))
+                                        float(o["gap"] or 0), C.byref(lim), _filter_of(o), C.byref(cplan), C.byref(out)))
     if rc == L.IST_NOTHING_TO_DO:
         return None
     try:
@@ -277,7 +283,7 @@ def stitch_png(images, direction, opts=None, device=0):
     lim = _limits(o)
     out, ln = C.POINTER(C.c_uint8)(), C.c_int64(0)
     rc = L.check(L.lib.ist_stitch_png(_ctx(device), descs, ptrs, pitches, n, _DIRECTIONS[direction], _MODES[o["mode"]],
-                                      float(o["gap"] or 0), C.byref(lim), _FILTERS[o["filter"]], C.byref(cplan), C.byref(out), C.byref(ln)))
+                                      float(o["gap"] or 0), C.byref(lim), _filter_of(o), C.byref(cplan), C.byref(out), C.byref(ln)))
     if rc == L.IST_NOTHING_TO_DO:
         return None
     w, h = int(cplan.canvas_w), int(cplan.canvas_h)
@@ -373,5 +379,5 @@ class Stitcher:
             sel = [ops[0]] + [ops[k] for k in range(1, n_ops) if ops[k].image in keep]
             ops = (L.Op * len(sel))(*sel)
             n_ops = len(sel)
-        job = self.compile_ops(p.canvas_w, p.canvas_h, ops, n_ops, p._descs, len(images), o["filter"])
+        job = self.compile_ops(p.canvas_w, p.canvas_h, ops, n_ops, p._descs, len(images), _filter_of(o))
         return p, job

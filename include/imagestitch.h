@@ -50,6 +50,10 @@ enum { IST_MODE_MIN = 0, IST_MODE_MAX = 1, IST_MODE_ORIGINAL = 2 };/* data.*Stit
 enum { IST_PLATFORM_OTHER = 0, IST_PLATFORM_IOS = 1, IST_PLATFORM_ANDROID = 2 }; /* sys.platform       */
 enum { IST_OP_FILL = 0, IST_OP_DRAW = 1, IST_OP_HOLE = 2 };
 enum { IST_FILTER_NEAREST = 0, IST_FILTER_BILINEAR = 1 };         /* imageSmoothingEnabled false / true (index.js:1416-1418) */
+/* OR-ed into a `filter` argument: anti-alias FRACTIONAL rectangle edges by area coverage, as Canvas rasters do (they
+ * arise from ctx.scale(superSample), index.js:1426-1428, and from the unrounded cursor, :1432).  Off: a pixel belongs
+ * to a draw iff its centre is inside the rectangle.  Integer-edged plans are unaffected either way. */
+enum { IST_FILTER_EDGE_AA = 0x100 };
 
 /* per-image record: the five fields the planner reads (index.js:724-739, 1194, 1211, 1252-1253, 1522-1523, 1532) */
 typedef struct ist_image_desc {

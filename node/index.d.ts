@@ -15,6 +15,7 @@ export interface StitchOptions {
   mode?: StitchMode; gap?: number; filter?: 'bilinear' | 'nearest';
   platform?: 'ios' | 'android' | 'devtools' | 'windows' | 'mac' | 'other';
   maxSide?: number; maxPixels?: number; superSample?: number;
+  edgeAA?: boolean;                         // anti-alias fractional rectangle edges (ctx.scale(superSample), unrounded cursor)
   onProgress?: (percent: number) => void;   // stitchProgress checkpoints (index.js:1193-1611)
 }
 export interface PlanRect { image: number; orientation: number; dx: number; dy: number; dw: number; dh: number; }

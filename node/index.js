@@ -13,7 +13,8 @@
  *              filter: 'bilinear'|'nearest' (imageSmoothingEnabled, index.js:1416), platform: 'ios'|'android'|'devtools'
  *              (reproduces the phone caps, index.js:1323-1336; default: caps lifted, superSample 1),
  *              maxSide, maxPixels (deviceMaxCanvasSize/Pixels), superSample (MAX_SUPER_SAMPLE, index.js:1363),
- *              onProgress: (percent) => void  (the stitchProgress checkpoints of index.js:1193-1611)}
+ *              onProgress: (percent) => void  (the stitchProgress checkpoints of index.js:1193-1611),
+ *              edgeAA: anti-alias fractional rectangle edges by area coverage (default false: pixel-centre rule)}
  * Errors reject with Error('拼图失败：' + reason) like the reference's catch (index.js:1618-1624); err.code is the
  * C-ABI code.  No pixel arithmetic happens in JavaScript; there is no CPU fallback.
  */
@@ -24,7 +25,8 @@ const DIRECTION = { vertical: 0, horizontal: 1 };
 const MODE = { min: 0, max: 1, original: 2 };
 const FILTER = { nearest: 0, bilinear: 1 };
 const PLATFORM = { other: 0, devtools: 0, windows: 0, mac: 0, ios: 1, android: 2 };
-const KNOWN = ['mode', 'gap', 'filter', 'platform', 'maxSide', 'maxPixels', 'superSample', 'onProgress'];
+const KNOWN = ['mode', 'gap', 'filter', 'platform', 'maxSide', 'maxPixels', 'superSample', 'onProgress', 'edgeAA'];
+const FILTER_EDGE_AA = 0x100;    // IST_FILTER_EDGE_AA: anti-alias fractional rectangle edges by area coverage
 
 function limitsOf(opts) {
   const o = opts || {};
@@ -47,7 +49,7 @@ function args(images, direction, opts) {
   if (!(mode in MODE)) throw new TypeError('unknown mode ' + mode);
   const filter = o.filter || 'bilinear';
   if (!(filter in FILTER)) throw new TypeError('unknown filter ' + filter);
-  return [images || [], DIRECTION[direction], MODE[mode], Number(o.gap) || 0, limitsOf(o), FILTER[filter]];
+  return [images || [], DIRECTION[direction], MODE[mode], Number(o.gap) || 0, limitsOf(o), FILTER[filter] | (o.edgeAA ? FILTER_EDGE_AA : 0)];
 }
 
 // The reference reports progress through setData({stitchProgress}): 1 at the start (index.js:1193), 25 when every image

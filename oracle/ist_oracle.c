@@ -34,7 +34,8 @@
  *   bilinear: f = sxf-0.5, i0 = floor(f), t = f-i0, taps clamp(i0), clamp(i0+1) (same in y); taps are
  *             premultiplied (c*a/255, real-valued), filtered, composited, then rounded half up once.
  *   coverage: a canvas pixel belongs to a draw iff its centre lies inside the transformed destination
- *             rectangle (no edge anti-aliasing; fractional edges are SURVEY section 8f rank 4).
+ *             rectangle; with ORC_EDGE_AA fractional edges are anti-aliased instead: cov = area of the pixel
+ *             inside the rectangle, out = floor(P*cov + dst*(1 - cov*A/255) + 0.5) in double.
  */
 #include <math.h>
 #include <pthread.h>
@@ -47,7 +48,7 @@
 enum { ORC_VERTICAL = 0, ORC_HORIZONTAL = 1 };
 enum { ORC_MODE_MIN = 0, ORC_MODE_MAX = 1, ORC_MODE_ORIGINAL = 2 };
 enum { ORC_PLATFORM_OTHER = 0, ORC_PLATFORM_IOS = 1, ORC_PLATFORM_ANDROID = 2 };
-enum { ORC_NEAREST = 0, ORC_BILINEAR = 1 };
+enum { ORC_NEAREST = 0, ORC_BILINEAR = 1, ORC_EDGE_AA = 0x100 };   /* filter | ORC_EDGE_AA: coverage anti-aliasing of fractional edges */
 
 typedef struct {
   int32_t width, height;     /* naturalWidth / naturalHeight (index.js:724-739) */
@@ -248,11 +249,12 @@ typedef struct {
   orc_mat stack[16];
   int sp;
   int smoothing;        /* imageSmoothingEnabled */
+  int aa;               /* anti-alias fractional rectangle edges by area coverage (off: pixel-centre rule) */
   int y0, y1;           /* raster band [y0,y1) for the multithreaded baseline */
 } orc_canvas;
 
 static void cv_init(orc_canvas* cv, int w, int h, uint8_t* px, size_t pitch, int smoothing, int y0, int y1) {
-  cv->w = w; cv->h = h; cv->px = px; cv->pitch = pitch; cv->sp = 0; cv->smoothing = smoothing;
+  cv->w = w; cv->h = h; cv->px = px; cv->pitch = pitch; cv->sp = 0; cv->smoothing = smoothing & 1; cv->aa = (smoothing & ORC_EDGE_AA) != 0;
   cv->m.a = 1; cv->m.b = 0; cv->m.c = 0; cv->m.d = 1; cv->m.e = 0; cv->m.f = 0;
   cv->y0 = y0 < 0 ? 0 : y0; cv->y1 = y1 > h ? h : y1;
 }
@@ -298,11 +300,12 @@ typedef struct {
   double kx, ox, ky, oy;
   int X0, X1, Y0, Y1;          /* covered canvas pixels, clipped */
   int cx0, cx1, cy0, cy1;      /* inclusive clamp bounds in the source */
+  double xl, xh, yl, yh;       /* continuous canvas-space extent of the destination rectangle */
 } orc_resolved;
 
 static int orc_resolve(const orc_mat* m, int cw, int ch, int img_w, int img_h,
                        double sx, double sy, double sw, double sh,
-                       double rx, double ry, double rw, double rh, orc_resolved* o) {
+                       double rx, double ry, double rw, double rh, int aa, orc_resolved* o) {
   int noswap = (m->b == 0.0 && m->c == 0.0 && m->a != 0.0 && m->d != 0.0);
   int swap = (m->a == 0.0 && m->d == 0.0 && m->b != 0.0 && m->c != 0.0);
   if (!noswap && !swap) return -1;
@@ -318,6 +321,8 @@ static int orc_resolve(const orc_mat* m, int cw, int ch, int img_w, int img_h,
   double za = kv * ry + ev, zb = kv * (ry + rh) + ev;        /* extent along the axis that drives source y */
   double wl = dmin(wa, wb), wh = dmax(wa, wb), zl = dmin(za, zb), zh = dmax(za, zb);
   double W0 = ceil(wl - 0.5), W1 = ceil(wh - 0.5), Z0 = ceil(zl - 0.5), Z1 = ceil(zh - 0.5);
+  if (aa) { W0 = floor(wl); W1 = ceil(wh); Z0 = floor(zl); Z1 = ceil(zh); }     /* every pixel the rectangle touches */
+  o->xl = swap ? zl : wl; o->xh = swap ? zh : wh; o->yl = swap ? wl : zl; o->yh = swap ? wh : zh;
   double X0 = swap ? Z0 : W0, X1 = swap ? Z1 : W1, Y0 = swap ? W0 : Z0, Y1 = swap ? W1 : Z1;
   if (X0 < 0) X0 = 0; if (Y0 < 0) Y0 = 0;
   if (X1 > cw) X1 = cw; if (Y1 > ch) Y1 = ch;
@@ -337,7 +342,7 @@ static inline int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ?
 static int cv_draw_image(orc_canvas* cv, const uint8_t* img, int img_w, int img_h, size_t img_pitch,
                          double sx, double sy, double sw, double sh, double rx, double ry, double rw, double rh) {
   orc_resolved R;
-  int rc = orc_resolve(&cv->m, cv->w, cv->h, img_w, img_h, sx, sy, sw, sh, rx, ry, rw, rh, &R);
+  int rc = orc_resolve(&cv->m, cv->w, cv->h, img_w, img_h, sx, sy, sw, sh, rx, ry, rw, rh, cv->aa, &R);
   if (rc != 0) return rc < 0 ? rc : 0;
   int Y0 = R.Y0 < cv->y0 ? cv->y0 : R.Y0, Y1 = R.Y1 > cv->y1 ? cv->y1 : R.Y1;
   if (Y0 >= Y1 || R.X0 >= R.X1) return 0;
@@ -367,6 +372,19 @@ static int cv_draw_image(orc_canvas* cv, const uint8_t* img, int img_w, int img_
       yt[j] = f - fl; yi0[j] = iclamp((int)fl, lo, hi); yi1[j] = iclamp((int)fl + 1, lo, hi);
     } else { yi0[j] = yi1[j] = iclamp((int)floor(s), lo, hi); yt[j] = 0.0; }
   }
+  /* area coverage of each pixel column / row by the rectangle (1 everywhere when edge AA is off) */
+  double* covx = (double*)malloc(sizeof(double) * (size_t)(nX + nY));
+  double* covy = covx + nX;
+  for (int i = 0; i < nX; i++) {
+    double X = (double)(R.X0 + i);
+    double c = cv->aa ? dmin(X + 1.0, R.xh) - dmax(X, R.xl) : 1.0;
+    covx[i] = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+  }
+  for (int j = 0; j < nY; j++) {
+    double Y = (double)(Y0 + j);
+    double c = cv->aa ? dmin(Y + 1.0, R.yh) - dmax(Y, R.yl) : 1.0;
+    covy[j] = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+  }
   /* identity fast path (what BASELINE's uniform configs reduce to): 1:1, no swap, integer offset */
   int identity = !R.swap && R.kx == 1.0 && R.ky == 1.0 && R.ox == floor(R.ox) && R.oy == floor(R.oy);
 
@@ -378,6 +396,19 @@ static int cv_draw_image(orc_canvas* cv, const uint8_t* img, int img_w, int img_
         const uint8_t* s = img + (size_t)iy * img_pitch + 4 * (size_t)ix;
         uint8_t* d = drow + 4 * (size_t)i;
         unsigned a = s[3];
+        const double cov = covx[i] * covy[j];
+        if (cov <= 0.0) continue;
+        if (cov < 1.0) {                          /* fractional edge: coverage-weighted source-over, in double */
+          const double A = (double)a, keep = 1.0 - cov * (A / 255.0);
+          for (int c = 0; c < 3; c++) {
+            const double P = (double)(s[c] * a) / 255.0;
+            double v = floor(P * cov + d[c] * keep + 0.5);
+            d[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+          }
+          double va = floor(A * cov + d[3] * keep + 0.5);
+          d[3] = (uint8_t)(va < 0 ? 0 : (va > 255 ? 255 : va));
+          continue;
+        }
         if (a == 255) { memcpy(d, s, 4); continue; }
         unsigned ia = 255 - a;
         d[0] = (uint8_t)((s[0] * a + d[0] * ia + 127) / 255);   /* d is premultiplied; s is straight */
@@ -397,18 +428,20 @@ static int cv_draw_image(orc_canvas* cv, const uint8_t* img, int img_w, int img_
         uint8_t* d = drow + 4 * (size_t)i;
         double w00 = (1.0 - tx) * (1.0 - ty), w01 = tx * (1.0 - ty), w10 = (1.0 - tx) * ty, w11 = tx * ty;
         double A = w00 * p00[3] + w01 * p01[3] + w10 * p10[3] + w11 * p11[3];
-        double keep = 1.0 - A / 255.0;
+        const double cov = covx[i] * covy[j];
+        if (cov <= 0.0) continue;
+        double keep = 1.0 - cov * (A / 255.0);
         for (int c = 0; c < 3; c++) {
           double P = (w00 * p00[c] * p00[3] + w01 * p01[c] * p01[3] + w10 * p10[c] * p10[3] + w11 * p11[c] * p11[3]) / 255.0;
-          double v = floor(P + d[c] * keep + 0.5);
+          double v = floor(P * cov + d[c] * keep + 0.5);
           d[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
         }
-        double va = floor(A + d[3] * keep + 0.5);
+        double va = floor(A * cov + d[3] * keep + 0.5);
         d[3] = (uint8_t)(va < 0 ? 0 : (va > 255 ? 255 : va));
       }
     }
   }
-  free(xi0); free(xt);
+  free(xi0); free(xt); free(covx);
   return 0;
 }
 
@@ -451,7 +484,7 @@ static int render_band(int cw, int ch, double ss, const orc_rect* rects, int n,
                        const uint8_t* const* src, const orc_image* imgs, const size_t* pitch,
                        int filter, uint8_t* dst, size_t dst_pitch, int y0, int y1) {
   orc_canvas cv;
-  cv_init(&cv, cw, ch, dst, dst_pitch, filter == ORC_BILINEAR, y0, y1);
+  cv_init(&cv, cw, ch, dst, dst_pitch, ((filter & 0xFF) == ORC_BILINEAR) | (filter & ORC_EDGE_AA), y0, y1);
   const uint8_t white[4] = {255, 255, 255, 255};
   cv_fill_rect_opaque(&cv, 0, 0, cw, ch, white);
   if (ss != 1.0) cv_scale(&cv, ss, ss);
@@ -532,7 +565,7 @@ ORC_API int orc_render_ops(int canvas_w, int canvas_h, const uint8_t clear_rgba[
                            const orc_image* imgs, const uint8_t* const* src, const size_t* src_pitch,
                            int filter, uint8_t* dst, size_t dst_pitch) {
   orc_canvas cv;
-  cv_init(&cv, canvas_w, canvas_h, dst, dst_pitch, filter == ORC_BILINEAR, 0, canvas_h);
+  cv_init(&cv, canvas_w, canvas_h, dst, dst_pitch, ((filter & 0xFF) == ORC_BILINEAR) | (filter & ORC_EDGE_AA), 0, canvas_h);
   /* initial canvas colour (premultiplied storage) */
   uint8_t pm[4];
   for (int c = 0; c < 3; c++) pm[c] = (uint8_t)((clear_rgba[c] * clear_rgba[3] + 127) / 255);
@@ -571,7 +604,7 @@ ORC_API int orc_resolve_draw(const double m[6], int cw, int ch, int img_w, int i
                              double out_k[4], int out_box[4], int out_clamp[4], int* out_swap) {
   orc_mat M = { m[0], m[1], m[2], m[3], m[4], m[5] };
   orc_resolved R;
-  int rc = orc_resolve(&M, cw, ch, img_w, img_h, s[0], s[1], s[2], s[3], d[0], d[1], d[2], d[3], &R);
+  int rc = orc_resolve(&M, cw, ch, img_w, img_h, s[0], s[1], s[2], s[3], d[0], d[1], d[2], d[3], 0, &R);
   if (rc) return rc;
   out_k[0] = R.kx; out_k[1] = R.ox; out_k[2] = R.ky; out_k[3] = R.oy;
   out_box[0] = R.X0; out_box[1] = R.Y0; out_box[2] = R.X1; out_box[3] = R.Y1;

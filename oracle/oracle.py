@@ -16,6 +16,7 @@ VERTICAL, HORIZONTAL = 0, 1
 MODE = {"min": 0, "max": 1, "original": 2}
 PLATFORM = {"other": 0, "devtools": 0, "windows": 0, "mac": 0, "ios": 1, "android": 2}
 NEAREST, BILINEAR = 0, 1
+EDGE_AA = 0x100     # OR-ed into a filter: coverage anti-aliasing of fractional rectangle edges
 
 
 class Image(C.Structure):
@@ -120,7 +121,12 @@ def plan(descs, direction, mode="min", gap=0.0, limits=None):
     return 0, pd, rl
 
 
-def render(pd, rl, descs, pixels, filter="bilinear", threads=1, out=None):
+def _filter(filter, edge_aa=False):
+    f = {"nearest": 0, "bilinear": 1}[filter] if isinstance(filter, str) else int(filter)
+    return f | (EDGE_AA if edge_aa else 0)
+
+
+def render(pd, rl, descs, pixels, filter="bilinear", threads=1, out=None, edge_aa=False):
     """Render a plan with the oracle raster.  pixels: list of HxWx4 uint8 arrays (C-contiguous rows)."""
     n = len(rl)
     cw, ch = int(pd["canvas_w"]), int(pd["canvas_h"])
@@ -138,7 +144,7 @@ def render(pd, rl, descs, pixels, filter="bilinear", threads=1, out=None):
         pitches[i] = a.strides[0]
     if out is None:
         out = np.empty((ch, cw, 4), np.uint8)
-    f = {"nearest": 0, "bilinear": 1}[filter] if isinstance(filter, str) else filter
+    f = _filter(filter, edge_aa)
     rc = lib().orc_render(cw, ch, float(pd["super_sample"]), rects, n, imgs, ptrs, pitches, f,
                           out.ctypes.data, out.strides[0], int(threads))
     if rc != 0:
@@ -146,17 +152,17 @@ def render(pd, rl, descs, pixels, filter="bilinear", threads=1, out=None):
     return out
 
 
-def stitch(pixels, direction, mode="min", gap=0.0, limits=None, filter="bilinear", orientations=None, threads=1):
+def stitch(pixels, direction, mode="min", gap=0.0, limits=None, filter="bilinear", orientations=None, threads=1, edge_aa=False):
     """The restated onStitch stages 2-5 for decoded RGBA8 inputs."""
     descs = [{"width": a.shape[1], "height": a.shape[0], "orientation": (orientations[i] if orientations else 1)}
              for i, a in enumerate(pixels)]
     rc, pd, rl = plan(descs, direction, mode, gap, limits)
     if rc != 0:
         raise RuntimeError("oracle plan rc=%d" % rc)
-    return render(pd, rl, descs, pixels, filter, threads), pd, rl
+    return render(pd, rl, descs, pixels, filter, threads, edge_aa=edge_aa), pd, rl
 
 
-def render_ops(canvas_w, canvas_h, ops, descs, pixels, filter="bilinear", clear=(0, 0, 0, 0)):
+def render_ops(canvas_w, canvas_h, ops, descs, pixels, filter="bilinear", clear=(0, 0, 0, 0), edge_aa=False):
     """ops: [{'kind':'fill','m':[6],'rect':[x,y,w,h],'rgba':(r,g,b,a)} | {'kind':'draw','image':i,'m':[6],'s':[4],'d':[4]}]"""
     arr = (Op * max(1, len(ops)))()
     for i, o in enumerate(ops):
@@ -181,7 +187,7 @@ def render_ops(canvas_w, canvas_h, ops, descs, pixels, filter="bilinear", clear=
         pitches[i] = a.strides[0]
     out = np.empty((canvas_h, canvas_w, 4), np.uint8)
     clr = (C.c_uint8 * 4)(*clear)
-    f = {"nearest": 0, "bilinear": 1}[filter] if isinstance(filter, str) else filter
+    f = _filter(filter, edge_aa)
     rc = lib().orc_render_ops(canvas_w, canvas_h, clr, arr, len(ops), imgs, ptrs, pitches, f, out.ctypes.data, out.strides[0])
     if rc != 0:
         raise RuntimeError("oracle render_ops failed rc=%d" % rc)

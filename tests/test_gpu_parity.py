@@ -294,3 +294,47 @@ def test_orientations_at_photo_scale(filt):
         assert U.max_abs_diff(got, ref) <= (0 if filt == "nearest" else 1), o
         # scaled quarter turns next to a plain image
         _check([a, b, a], "horizontal", {"filter": filt, "mode": "max", "gap": 2}, orientations=[o, 1, o])
+
+
+@pytest.mark.parametrize("filt", ["nearest", "bilinear"])
+def test_edge_antialiasing_of_fractional_rectangles(filt):
+    """IST_FILTER_EDGE_AA: fractional edges (gap*scaleDown cursors, ctx.scale(superSample)) blended by area coverage.
+    nearest stays bit-exact (the blend runs in fp64 on both sides), bilinear within 1 LSB."""
+    px = [U.rand_image(170 + i, h, w, opaque=(i % 2 == 0)) for i, (w, h) in enumerate([(40, 30), (40, 20), (37, 25), (64, 48)])]
+    caps = {"platform": "android", "maxSide": 48, "maxPixels": 48 * 40, "gap": 3}
+    for direction in ("vertical", "horizontal"):
+        for mode in ("min", "original"):
+            out, ref = _check(px, direction, dict(caps, filter=filt, mode=mode, edgeAA=True))
+            plain = ist.stitch(U.hip_images(px), direction, dict(caps, filter=filt, mode=mode))["data"]
+            assert not np.array_equal(plain, out), "the plan has fractional edges: AA must change some pixels"
+    # superSample 2.6 / 2.2 on small inputs (reference default for n < 7), with EXIF turns on top
+    small = [U.smooth_image(180 + i, 21, 33) for i in range(3)]
+    for plat in ("devtools", "ios"):
+        _check(small, "vertical", {"filter": filt, "platform": plat, "edgeAA": True})
+        _check(small, "horizontal", {"filter": filt, "platform": plat, "edgeAA": True, "gap": 2}, orientations=[6, 1, 3])
+    # integer-edged plans are unaffected
+    a = ist.stitch(U.hip_images(px), "vertical", {"filter": filt, "gap": 4, "edgeAA": True})["data"]
+    b = ist.stitch(U.hip_images(px), "vertical", {"filter": filt, "gap": 4})["data"]
+    assert np.array_equal(a, b)
+
+
+def test_edge_antialiasing_known_answer():
+    """one black 2x2 image drawn at y = 0.25 .. 2.25 on white (scaleDown makes the cursor fractional): rows get
+    coverage 0.75, 1, 0.25 -> 255*(1-cov)."""
+    import ctypes as C
+    from imagestitching_amd import _lib as L
+    img = np.zeros((2, 2, 4), np.uint8)
+    img[..., 3] = 255
+    ops = (L.Op * 2)()
+    ops[0].kind = 0; ops[0].m[:] = [1, 0, 0, 1, 0, 0]; ops[0].d[:] = [0, 0, 2, 3]; ops[0].rgba[:] = [255, 255, 255, 255]
+    ops[1].kind = 1; ops[1].image = 0; ops[1].m[:] = [1, 0, 0, 1, 0, 0]; ops[1].s[:] = [0, 0, 2, 2]; ops[1].d[:] = [0, 0.25, 2, 2]
+    descs = (L.ImageDesc * 1)(L.ImageDesc(2, 2, 1, 0, 0, 0, 0))
+    out = np.zeros((3, 2, 4), np.uint8)
+    ptrs = (C.c_void_p * 1)(img.ctypes.data)
+    pit = (C.c_size_t * 1)(8)
+    clear = (C.c_uint8 * 4)(0, 0, 0, 0)
+    from imagestitching_amd.stitch import _ctx
+    for filt in (0, 1):
+        L.check(L.lib.ist_render_rgba8(_ctx(0), 2, 3, clear, ops, 2, descs, ptrs, pit, 1, filt | 0x100, None, out.ctypes.data, 8))
+        assert out[:, 0, 0].tolist() == [64, 0, 191], out[:, 0, 0].tolist()      # floor(255*0.25+0.5), 0, floor(255*0.75+0.5)
+        assert (out[..., 3] == 255).all()

@@ -48,7 +48,7 @@ def oracle_stitch(pixels, direction, opts=None, orientations=None, threads=4):
              for i, a in enumerate(pixels)]
     rc, pd, rl = O.plan(descs, direction, opts.get("mode", "min"), opts.get("gap", 0), oracle_limits(opts))
     assert rc == 0, rc
-    img = O.render(pd, rl, descs, pixels, opts.get("filter", "bilinear"), threads)
+    img = O.render(pd, rl, descs, pixels, opts.get("filter", "bilinear"), threads, edge_aa=bool(opts.get("edgeAA")))
     return img, pd, rl
 
 
