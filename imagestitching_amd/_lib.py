@@ -88,6 +88,10 @@ SYMBOLS = [
     ("ist_free", None, [C.c_void_p]),
     ("ist_png_info", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("ist_png_decode_rgba8", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t]),
+    ("ist_jpeg_info", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("ist_jpeg_decode_rgba8", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t]),
+    ("ist_image_info", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("ist_image_decode_rgba8", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t]),
     ("ist_png_bound", C.c_int64, [C.c_int64, C.c_int64]),
     ("ist_png_encode_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                         C.POINTER(C.c_int64), C.c_void_p]),

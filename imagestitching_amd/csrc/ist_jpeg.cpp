@@ -1,0 +1,275 @@
+// ist_jpeg.cpp — baseline / extended-sequential JPEG: container parsing + Huffman entropy decoding on the host.
+//
+// Reference anchor: loadImageFrom (utils/canvas.js:27-121) hands the file to the platform decoder; 'jpg'/'jpeg' head
+// SUPPORTED_IMAGE_TYPES (pages/index/index.js:4) and phone photos are JPEGs, so this is the decode step in front of the
+// stitch path.  The orientation the planner needs (index.js:734) is read from the EXIF
+// APP1 segment here.
+//
+// Split for the hardware: entropy decoding is a serial bit stream (host, this file); everything after it — dequantise,
+// 8x8 inverse DCT, chroma upsampling, YCbCr->RGB — is independent per block / per pixel and runs on the GPU
+// (ist_jpeg_kernels.hip) on the coefficient planes this file produces.
+// Supported: SOF0 / SOF1, 8-bit, 1 or 3 components, any sampling factors h,v in {1,2} with luma >= chroma, interleaved
+// and non-interleaved scans, restart intervals.  Progressive (SOF2), arithmetic coding, 12-bit, CMYK: IST_E_UNSUPPORTED.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ist_internal.h"
+#include "ist_jpeg.h"
+
+namespace ist {
+
+namespace {
+
+const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
+                             15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Huff {
+  bool present = false;
+  uint8_t bits[17] = {0};
+  uint8_t vals[256] = {0};
+  // canonical decoding
+  int32_t maxcode[18];
+  int32_t valptr[17];
+  int32_t mincode[17];
+  // 9-bit lookahead: (length << 8) | symbol, 0 = not resolved
+  uint16_t look[512];
+  void build() {
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) {
+      valptr[l] = k;
+      mincode[l] = code;
+      k += bits[l];
+      code += bits[l];
+      maxcode[l] = bits[l] ? code - 1 : -1;
+      code <<= 1;
+    }
+    maxcode[17] = 0x7FFFFFFF;
+    std::memset(look, 0, sizeof look);
+    code = 0; k = 0;
+    for (int l = 1; l <= 9; ++l) {
+      for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
+        const int lo = code << (9 - l);
+        for (int f = 0; f < (1 << (9 - l)); ++f) look[lo + f] = static_cast<uint16_t>((l << 8) | vals[k]);
+      }
+      code <<= 1;
+    }
+  }
+};
+
+struct BitReader {
+  const uint8_t* p; const uint8_t* end;
+  uint64_t acc = 0; int n = 0;
+  bool hit_marker = false;
+  void fill() {
+    while (n <= 56) {
+      uint32_t b = 0;
+      if (!hit_marker && p < end) {
+        b = *p;
+        if (b == 0xFF) {
+          if (p + 1 < end && p[1] == 0x00) p += 2;            // stuffed zero
+          else { hit_marker = true; b = 0; }                  // a marker: feed zeros, do not consume
+        } else ++p;
+      }
+      acc |= static_cast<uint64_t>(b) << (56 - n);
+      n += 8;
+    }
+  }
+  inline uint32_t peek(int k) { if (n < k) fill(); return static_cast<uint32_t>(acc >> (64 - k)); }
+  inline void skip(int k) { acc <<= k; n -= k; }
+  inline uint32_t get(int k) { if (k == 0) return 0; const uint32_t v = peek(k); skip(k); return v; }
+  void reset() { acc = 0; n = 0; hit_marker = false; }
+};
+
+inline int decode_symbol(BitReader& br, const Huff& h) {
+  const uint32_t v = br.peek(16);
+  const uint16_t e = h.look[v >> 7];
+  if (e) { br.skip(e >> 8); return e & 0xFF; }
+  int l = 10;
+  int32_t code = static_cast<int32_t>(v >> 6);
+  while (l <= 16 && code > h.maxcode[l]) { ++l; code = static_cast<int32_t>(v >> (16 - l)); }
+  if (l > 16) return -1;
+  br.skip(l);
+  return h.vals[h.valptr[l] + code - h.mincode[l]];
+}
+
+inline int extend(uint32_t v, int s) { return (v < (1u << (s - 1))) ? static_cast<int>(v) - (1 << s) + 1 : static_cast<int>(v); }
+
+inline uint32_t be16(const uint8_t* p) { return (uint32_t(p[0]) << 8) | p[1]; }
+
+// EXIF orientation (tag 0x0112) from an APP1 "Exif\0\0" payload
+int exif_orientation(const uint8_t* d, size_t n) {
+  if (n < 14 || std::memcmp(d, "Exif\0\0", 6) != 0) return 0;
+  const uint8_t* t = d + 6; const size_t tn = n - 6;
+  const bool le = t[0] == 'I' && t[1] == 'I';
+  if (!le && !(t[0] == 'M' && t[1] == 'M')) return 0;
+  auto r16 = [&](size_t o) -> uint32_t { return le ? (t[o] | (t[o + 1] << 8)) : ((t[o] << 8) | t[o + 1]); };
+  auto r32 = [&](size_t o) -> uint32_t { return le ? (t[o] | (t[o + 1] << 8) | (t[o + 2] << 16) | (uint32_t(t[o + 3]) << 24))
+                                                  : ((uint32_t(t[o]) << 24) | (t[o + 1] << 16) | (t[o + 2] << 8) | t[o + 3]); };
+  if (tn < 8 || r16(2) != 42) return 0;
+  size_t ifd = r32(4);
+  if (ifd + 2 > tn) return 0;
+  const uint32_t cnt = r16(ifd);
+  for (uint32_t i = 0; i < cnt; ++i) {
+    const size_t e = ifd + 2 + 12 * i;
+    if (e + 12 > tn) break;
+    if (r16(e) == 0x0112) { const uint32_t v = r16(e + 8); return (v >= 1 && v <= 8) ? static_cast<int>(v) : 0; }
+  }
+  return 0;
+}
+
+}  // namespace
+
+int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, bool header_only) {
+  if (!f || n < 4 || f[0] != 0xFF || f[1] != 0xD8) return fail(IST_E_DECODE, "not a JPEG file");
+  Huff dc[4], ac[4];
+  uint16_t qt[4][64]; bool have_q[4] = {false, false, false, false};
+  int restart_interval = 0;
+  bool have_sof = false;
+  int64_t pos = 2;
+  *J = JpegImage();
+  while (pos + 4 <= n) {
+    if (f[pos] != 0xFF) { ++pos; continue; }
+    const int m = f[pos + 1];
+    if (m == 0xFF) { ++pos; continue; }
+    if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { pos += 2; continue; }
+    if (m == 0xD9) break;
+    const int64_t len = be16(f + pos + 2);
+    if (len < 2 || pos + 2 + len > n) return fail(IST_E_DECODE, "truncated JPEG segment");
+    const uint8_t* d = f + pos + 4; const int64_t dl = len - 2;
+    if (m == 0xE1 && J->orientation == 0) J->orientation = exif_orientation(d, static_cast<size_t>(dl));
+    else if (m == 0xDB) {                                           // DQT
+      int64_t o = 0;
+      while (o < dl) {
+        const int pq = d[o] >> 4, tq = d[o] & 15; ++o;
+        if (tq > 3 || o + (pq ? 128 : 64) > dl) return fail(IST_E_DECODE, "bad JPEG quantisation table");
+        for (int i = 0; i < 64; ++i) { qt[tq][kZigzag[i]] = static_cast<uint16_t>(pq ? be16(d + o + 2 * i) : d[o + i]); }
+        o += pq ? 128 : 64;
+        have_q[tq] = true;
+      }
+    } else if (m == 0xC4) {                                         // DHT
+      int64_t o = 0;
+      while (o + 17 <= dl) {
+        const int tc = d[o] >> 4, th = d[o] & 15;
+        if (tc > 1 || th > 3) return fail(IST_E_DECODE, "bad JPEG Huffman table");
+        Huff& h = tc ? ac[th] : dc[th];
+        int cnt = 0;
+        for (int i = 1; i <= 16; ++i) { h.bits[i] = d[o + i]; cnt += h.bits[i]; }
+        if (cnt > 256 || o + 17 + cnt > dl) return fail(IST_E_DECODE, "bad JPEG Huffman table");
+        std::memcpy(h.vals, d + o + 17, static_cast<size_t>(cnt));
+        h.present = true; h.build();
+        o += 17 + cnt;
+      }
+    } else if (m == 0xDD) { if (dl >= 2) restart_interval = static_cast<int>(be16(d)); }
+    else if (m == 0xC0 || m == 0xC1) {                              // SOF0 / SOF1
+      if (dl < 6) return fail(IST_E_DECODE, "bad JPEG frame header");
+      if (d[0] != 8) return fail(IST_E_UNSUPPORTED, "only 8-bit JPEG is supported");
+      J->height = static_cast<int>(be16(d + 1)); J->width = static_cast<int>(be16(d + 3)); J->ncomp = d[5];
+      if (J->width < 1 || J->height < 1) return fail(IST_E_DECODE, "bad JPEG size");
+      if (J->ncomp != 1 && J->ncomp != 3) return fail(IST_E_UNSUPPORTED, "only greyscale and YCbCr JPEG are supported");
+      if (dl < 6 + 3 * J->ncomp) return fail(IST_E_DECODE, "bad JPEG frame header");
+      int hmax = 1, vmax = 1;
+      for (int c = 0; c < J->ncomp; ++c) {
+        JpegComp& C = J->comp[c];
+        C.id = d[6 + 3 * c]; C.h = d[7 + 3 * c] >> 4; C.v = d[7 + 3 * c] & 15; C.tq = d[8 + 3 * c];
+        if (C.h < 1 || C.h > 2 || C.v < 1 || C.v > 2 || C.tq > 3) return fail(IST_E_UNSUPPORTED, "JPEG sampling factors beyond 2 are not supported");
+        hmax = std::max(hmax, C.h); vmax = std::max(vmax, C.v);
+      }
+      // colour: luma carries the sampling (4:4:4, 4:2:2, 4:2:0, 4:4:0), both chroma planes are 1x1
+      if (J->ncomp == 3 && (J->comp[1].h != 1 || J->comp[1].v != 1 || J->comp[2].h != 1 || J->comp[2].v != 1))
+        return fail(IST_E_UNSUPPORTED, "unusual JPEG sampling layout (chroma must be 1x1)");
+      if (J->ncomp == 1) { J->comp[0].h = J->comp[0].v = 1; hmax = vmax = 1; }
+      J->hmax = hmax; J->vmax = vmax;
+      J->mcus_x = (J->width + 8 * hmax - 1) / (8 * hmax); J->mcus_y = (J->height + 8 * vmax - 1) / (8 * vmax);
+      for (int c = 0; c < J->ncomp; ++c) {
+        JpegComp& C = J->comp[c];
+        C.blocks_x = J->mcus_x * C.h; C.blocks_y = J->mcus_y * C.v;
+      }
+      have_sof = true;
+      if (header_only) return IST_OK;
+    } else if (m == 0xC2) return fail(IST_E_UNSUPPORTED, "progressive JPEG is not supported (baseline only)");
+    else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) return fail(IST_E_UNSUPPORTED, "this JPEG process (lossless / arithmetic) is not supported");
+    else if (m == 0xDA) {                                           // SOS
+      if (!have_sof) return fail(IST_E_DECODE, "JPEG scan before frame header");
+      const int ns = d[0];
+      if (ns < 1 || ns > J->ncomp || dl < 1 + 2 * ns + 3) return fail(IST_E_DECODE, "bad JPEG scan header");
+      int ci[3], td[3], ta[3];
+      for (int s = 0; s < ns; ++s) {
+        const int id = d[1 + 2 * s]; ci[s] = -1;
+        for (int c = 0; c < J->ncomp; ++c) if (J->comp[c].id == id) ci[s] = c;
+        if (ci[s] < 0) return fail(IST_E_DECODE, "JPEG scan names an unknown component");
+        td[s] = d[2 + 2 * s] >> 4; ta[s] = d[2 + 2 * s] & 15;
+        if (td[s] > 3 || ta[s] > 3 || !dc[td[s]].present || !ac[ta[s]].present) return fail(IST_E_DECODE, "JPEG scan uses an undefined Huffman table");
+      }
+      // allocate coefficient planes on first use; copy the quantisation tables in use
+      for (int c = 0; c < J->ncomp; ++c) {
+        JpegComp& C = J->comp[c];
+        if (!have_q[C.tq]) return fail(IST_E_DECODE, "JPEG component uses an undefined quantisation table");
+        std::memcpy(C.q, qt[C.tq], sizeof C.q);
+        if (C.coef.empty()) C.coef.assign(static_cast<size_t>(C.blocks_x) * C.blocks_y * 64, 0);
+      }
+      BitReader br; br.p = d + dl; br.end = f + n;
+      int pred[3] = {0, 0, 0};
+      const bool interleaved = ns > 1;
+      int mx, my;
+      if (interleaved) { mx = J->mcus_x; my = J->mcus_y; }
+      else {   // a non-interleaved scan covers only the blocks that hold image samples
+        const JpegComp& C = J->comp[ci[0]];
+        mx = (((J->width * C.h + J->hmax - 1) / J->hmax) + 7) / 8;
+        my = (((J->height * C.v + J->vmax - 1) / J->vmax) + 7) / 8;
+      }
+      int until_restart = restart_interval, next_rst = 0;
+      for (int y = 0; y < my; ++y) {
+        for (int x = 0; x < mx; ++x) {
+          if (restart_interval && until_restart == 0) {
+            // byte-align and expect RSTn
+            br.reset();
+            while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) ++br.p;
+            if (br.p + 1 >= br.end) return fail(IST_E_DECODE, "JPEG restart marker missing");
+            if ((br.p[1] & 7) != next_rst) return fail(IST_E_DECODE, "JPEG restart markers out of order");
+            br.p += 2; next_rst = (next_rst + 1) & 7;
+            pred[0] = pred[1] = pred[2] = 0;
+            until_restart = restart_interval;
+          }
+          for (int s = 0; s < ns; ++s) {
+            JpegComp& C = J->comp[ci[s]];
+            const int bh = interleaved ? C.h : 1, bv = interleaved ? C.v : 1;
+            for (int by = 0; by < bv; ++by) for (int bx = 0; bx < bh; ++bx) {
+              const int gx = x * bh + bx, gy = y * bv + by;
+              int16_t* blk = C.coef.data() + (static_cast<size_t>(gy) * C.blocks_x + gx) * 64;
+              int t = decode_symbol(br, dc[td[s]]);
+              if (t < 0 || t > 11) return fail(IST_E_DECODE, "corrupt JPEG entropy data (DC)");
+              const int diff = t ? extend(br.get(t), t) : 0;
+              pred[s] += diff;
+              blk[0] = static_cast<int16_t>(pred[s]);
+              for (int k = 1; k < 64;) {
+                const int rs = decode_symbol(br, ac[ta[s]]);
+                if (rs < 0) return fail(IST_E_DECODE, "corrupt JPEG entropy data (AC)");
+                const int r = rs >> 4, sz = rs & 15;
+                if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                k += r;
+                if (k > 63) return fail(IST_E_DECODE, "corrupt JPEG entropy data (run)");
+                blk[kZigzag[k]] = static_cast<int16_t>(extend(br.get(sz), sz));
+                ++k;
+              }
+            }
+          }
+          if (restart_interval) --until_restart;
+        }
+      }
+      // continue after the entropy-coded segment: the reader stopped at (or before) the next marker
+      const uint8_t* q = br.p;
+      while (q + 1 < f + n && !(q[0] == 0xFF && q[1] != 0x00 && !(q[1] >= 0xD0 && q[1] <= 0xD7))) ++q;
+      pos = q - f;
+      J->scans++;
+      continue;
+    }
+    pos += 2 + len;
+  }
+  if (!have_sof) return fail(IST_E_DECODE, "JPEG without a frame header");
+  if (!header_only && J->scans == 0) return fail(IST_E_DECODE, "JPEG without image data");
+  return IST_OK;
+}
+
+}  // namespace ist

@@ -12,6 +12,7 @@
 #include <mutex>
 
 #include "ist_internal.h"
+#include "ist_jpeg.h"
 #include "ist_launch.h"
 
 using namespace ist;
@@ -310,6 +311,69 @@ int ist_stitch_png(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* co
                         n_images, filter, out_png, out_len);
   if (rc != IST_OK) ist_plan_free(out_plan);
   return rc;
+}
+
+// ---- JPEG decode: entropy decoding on the host, reconstruction on the GPU (ist_jpeg.cpp / ist_jpeg_kernels.hip) ----------
+int ist_jpeg_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation) {
+  JpegImage J;
+  const int rc = jpeg_parse_and_entropy_decode(file, len, &J, true);
+  if (rc) return rc;
+  if (width) *width = J.width;
+  if (height) *height = J.height;
+  if (orientation) *orientation = J.orientation;
+  return IST_OK;
+}
+
+int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  JpegImage J;
+  int rc = jpeg_parse_and_entropy_decode(file, len, &J, false);
+  if (rc) return rc;
+  if (!out || out_pitch < static_cast<size_t>(J.width) * 4) return fail(IST_E_INVALID, "ist_jpeg_decode_rgba8: output buffer too small");
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  // one device allocation: coefficients + tables + sample planes + RGBA
+  size_t off = 0, o_coef[3] = {0, 0, 0}, o_q[3] = {0, 0, 0}, o_plane[3] = {0, 0, 0};
+  auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
+  for (int c = 0; c < J.ncomp; ++c) {
+    o_coef[c] = take(J.comp[c].coef.size() * 2);
+    o_q[c] = take(128);
+    o_plane[c] = take(static_cast<size_t>(J.comp[c].blocks_x) * 8 * J.comp[c].blocks_y * 8);
+  }
+  const size_t row = static_cast<size_t>(J.width) * 4;
+  const size_t o_out = take(row * J.height);
+  uint8_t* d = nullptr;
+  IST_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
+  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
+  JpegDeviceJob job;
+  job.width = J.width; job.height = J.height; job.ncomp = J.ncomp; job.hmax = J.hmax; job.vmax = J.vmax;
+  for (int c = 0; c < 3; ++c) { job.d_coef[c] = nullptr; job.d_q[c] = nullptr; job.d_plane[c] = nullptr; job.h[c] = job.v[c] = 1; job.blocks_x[c] = job.blocks_y[c] = 0; }
+  for (int c = 0; c < J.ncomp; ++c) {
+    IST_HIP(hipMemcpyAsync(d + o_coef[c], J.comp[c].coef.data(), J.comp[c].coef.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+    IST_HIP(hipMemcpyAsync(d + o_q[c], J.comp[c].q, 128, hipMemcpyHostToDevice, ctx->stream));
+    job.d_coef[c] = reinterpret_cast<const int16_t*>(d + o_coef[c]);
+    job.d_q[c] = reinterpret_cast<const uint16_t*>(d + o_q[c]);
+    job.d_plane[c] = d + o_plane[c];
+    job.h[c] = J.comp[c].h; job.v[c] = J.comp[c].v; job.blocks_x[c] = J.comp[c].blocks_x; job.blocks_y[c] = J.comp[c].blocks_y;
+  }
+  job.out = d + o_out; job.out_pitch = row;
+  rc = jpeg_launch_reconstruct(job, ctx->stream);
+  if (rc) return rc;
+  IST_HIP(hipMemcpy2DAsync(out, out_pitch, d + o_out, row, row, static_cast<size_t>(J.height), hipMemcpyDeviceToHost, ctx->stream));
+  IST_HIP(hipStreamSynchronize(ctx->stream));
+  return IST_OK;
+}
+
+// format-agnostic front door: PNG (host decode) or JPEG (host entropy decode + GPU reconstruction)
+int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation) {
+  if (file && len >= 2 && file[0] == 0xFF && file[1] == 0xD8) return ist_jpeg_info(file, len, width, height, orientation);
+  if (orientation) *orientation = 0;
+  return ist_png_info(file, len, width, height);
+}
+
+int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch) {
+  if (file && len >= 2 && file[0] == 0xFF && file[1] == 0xD8) return ist_jpeg_decode_rgba8(ctx, file, len, out, out_pitch);
+  return ist_png_decode_rgba8(file, len, out, out_pitch);
 }
 
 // PNG of host pixels (H2D, encode, D2H)

@@ -231,18 +231,44 @@ def decode_png(data):
     return out
 
 
+def image_info(data):
+    """(width, height, orientation) of a PNG or JPEG file; orientation = EXIF tag 0x0112 (0 when absent)."""
+    buf = bytes(data)
+    w, h, o = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    L.check(L.lib.ist_image_info(buf, len(buf), C.byref(w), C.byref(h), C.byref(o)))
+    return w.value, h.value, o.value
+
+
+def decode_image(data, device=0):
+    """PNG or JPEG file bytes -> HxWx4 uint8 RGBA.  JPEG: Huffman decoding on the host, IDCT / upsampling / colour
+    conversion on the GPU.  The bitmap is returned as stored (EXIF orientation is applied by the stitch, like the
+    reference's drawWithOrientation)."""
+    buf = bytes(data)
+    w, h, _ = image_info(buf)
+    out = np.empty((h, w, 4), np.uint8)
+    if buf[:2] == b"\xff\xd8":
+        L.check(L.lib.ist_image_decode_rgba8(_ctx(device), buf, len(buf), out.ctypes.data, out.strides[0]))
+    else:
+        L.check(L.lib.ist_png_decode_rgba8(buf, len(buf), out.ctypes.data, out.strides[0]))
+    return out
+
+
 def stitch_files(paths, direction, opts=None, out_path=None, device=0):
-    """File to file for PNG inputs: decode (host) -> stitch -> PNG export (GPU).  Returns the PNG bytes (and writes
-    out_path when given).  The mini-program's whole onStitch for 'png' images: index.js:1441-1581."""
+    """File to file: decode (PNG: host; JPEG: host entropy decode + GPU reconstruction) -> stitch -> PNG export (GPU).
+    EXIF orientation is read from the file like getImageInfo does (index.js:734).  Returns {'width','height','png'} and
+    writes out_path when given.  The mini-program's whole onStitch: index.js:1441-1581."""
     images = []
     for i, p in enumerate(paths):
         with open(p, "rb") as f:
             data = f.read()
         try:
-            px = decode_png(data)
+            w, h, orient = image_info(data)
+            px = decode_image(data, device)
         except L.StitchError as e:
             raise L.StitchError(e.code, "图片%d解码异常: %s" % (i, e.reason))
-        images.append({"width": px.shape[1], "height": px.shape[0], "data": px, "fileSize": len(data)})
+        # the planner sees the size getImageInfo reports; for quarter turns the reference is given the oriented size
+        images.append({"width": px.shape[1], "height": px.shape[0], "data": px, "fileSize": len(data), "orientation": orient or 1,
+                       "opaque": data[:2] == b"\xff\xd8"})
     res = stitch_png(images, direction, opts, device)
     if res is not None and out_path:
         with open(out_path, "wb") as f:

@@ -169,6 +169,14 @@ IST_API void ist_free(void* p);
  * Adam7 return IST_E_UNSUPPORTED; damaged files IST_E_DECODE ('图片N解码异常' analogue). */
 IST_API int ist_png_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height);
 IST_API int ist_png_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch);
+/* JPEG (baseline / extended sequential, 8 bit, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0, restart intervals): Huffman
+ * decoding on the host, dequantise + IDCT + upsampling + colour conversion on the GPU.  *orientation = EXIF tag 0x0112
+ * (0 when absent) - what getImageInfo feeds the planner (index.js:734).  Progressive JPEG: IST_E_UNSUPPORTED. */
+IST_API int ist_jpeg_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation);
+IST_API int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch);
+/* by signature: PNG or JPEG */
+IST_API int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation);
+IST_API int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch);
 
 /* ---- export: lossless PNG (fileType 'png', quality 1; utils/canvas.js:205-242, index.js:1577-1579) --------------- */
 /* upper bound of the file size for a w x h RGBA canvas */

@@ -408,6 +408,33 @@ static napi_value js_encode_png(napi_env env, napi_callback_info info) {
   return buf;
 }
 
+/* decodeImage(file: Buffer) -> {width, height, orientation, data}: PNG (host) or JPEG (host Huffman + GPU reconstruction) */
+static napi_value js_decode_image(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  CHECK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  bool ta = false, isbuf = false; void* p = NULL; size_t len = 0;
+  if (argc < 1) { napi_throw_type_error(env, NULL, "decodeImage(buffer)"); return NULL; }
+  napi_is_buffer(env, argv[0], &isbuf); napi_is_typedarray(env, argv[0], &ta);
+  if (isbuf) napi_get_buffer_info(env, argv[0], &p, &len);
+  else if (ta) { napi_typedarray_type tt; napi_value ab; size_t off; napi_get_typedarray_info(env, argv[0], &tt, &len, &p, &ab, &off); }
+  if (!p) { napi_throw_type_error(env, NULL, "decodeImage expects a Buffer / Uint8Array"); return NULL; }
+  int32_t w = 0, h = 0, orient = 0;
+  int rc = ist_image_info((const uint8_t*)p, (int64_t)len, &w, &h, &orient);
+  if (rc < 0) return throw_ist(env, rc);
+  const int is_jpeg = len >= 2 && ((const uint8_t*)p)[0] == 0xFF && ((const uint8_t*)p)[1] == 0xD8;
+  ist_ctx* ctx = is_jpeg ? get_ctx() : NULL;
+  if (is_jpeg && !ctx) { napi_throw(env, make_error(env, IST_E_NO_DEVICE, g_ctx_err)); return NULL; }
+  void* out_data = NULL; napi_value buf, o;
+  if (napi_create_buffer(env, (size_t)w * (size_t)h * 4, &out_data, &buf) != napi_ok) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+  rc = ist_image_decode_rgba8(ctx, (const uint8_t*)p, (int64_t)len, (uint8_t*)out_data, (size_t)w * 4);
+  if (rc < 0) return throw_ist(env, rc);
+  napi_create_object(env, &o);
+  set_num(env, o, "width", w); set_num(env, o, "height", h); set_num(env, o, "orientation", orient ? orient : 1);
+  napi_value op; napi_get_boolean(env, is_jpeg != 0, &op); napi_set_named_property(env, o, "opaque", op);
+  napi_set_named_property(env, o, "data", buf);
+  return o;
+}
+
 /* decodePng(file: Buffer) -> {width, height, data: Buffer RGBA8}   (host decode, no GPU needed) */
 static napi_value js_decode_png(napi_env env, napi_callback_info info) {
   size_t argc = 1; napi_value argv[1];
@@ -449,6 +476,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"render", NULL, js_render, NULL, NULL, NULL, napi_default, NULL},
       {"encodePng", NULL, js_encode_png, NULL, NULL, NULL, napi_default, NULL},
       {"decodePng", NULL, js_decode_png, NULL, NULL, NULL, napi_default, NULL},
+      {"decodeImage", NULL, js_decode_image, NULL, NULL, NULL, napi_default, NULL},
       {"deviceCount", NULL, js_device_count, NULL, NULL, NULL, napi_default, NULL},
       {"lastError", NULL, js_last_error, NULL, NULL, NULL, napi_default, NULL},
       {"abiVersion", NULL, js_abi_version, NULL, NULL, NULL, napi_default, NULL},

@@ -32,3 +32,4 @@ export function stitchPng(images: StitchImage[], direction: Direction, opts?: St
 export function encodePng(data: Uint8Array, width: number, height: number): Buffer;
 export function decodePng(file: Uint8Array): { width: number; height: number; data: Buffer };
 export function stitchFiles(paths: string[], direction: Direction, opts?: StitchOptions, outPath?: string): Promise<StitchPngResult | null>;
+export function decodeImage(file: Uint8Array): { width: number; height: number; orientation: number; opaque: boolean; data: Buffer };

@@ -81,13 +81,17 @@ function stitchPng(images, direction, opts) {
 /** PNG file bytes -> {width, height, data} (RGBA8, straight alpha). Host decode: the Image.src step for 'png' inputs
  *  (utils/canvas.js:27-121; SUPPORTED_IMAGE_TYPES, index.js:4). JPEG / WebP / HEIC are not built: err.code '-7'. */
 function decodePng(file) { return native.decodePng(file); }
-/** File to file for PNG inputs: decode -> stitch -> PNG export. Resolves {width, height, png, plan}; writes opts-free
+/** PNG or JPEG file bytes -> {width, height, orientation, opaque, data}. JPEG (baseline): Huffman decoding on the host,
+ *  IDCT / chroma upsampling / colour conversion on the GPU; orientation = EXIF tag 0x0112 (what getImageInfo feeds the
+ *  planner, index.js:734). Progressive JPEG / WebP / HEIC reject with err.code '-7'. */
+function decodeImage(file) { return native.decodeImage(file); }
+/** File to file (PNG and JPEG inputs): decode -> stitch -> PNG export. Resolves {width, height, png, plan}; writes
  *  outPath when given. A file that does not decode rejects with '图片N解码异常' like index.js:1512-1514. */
 async function stitchFiles(paths, direction, opts, outPath) {
   const fs = require('fs');
   const images = paths.map((p, i) => {
     const file = fs.readFileSync(p);
-    try { return Object.assign(native.decodePng(file), { fileSize: file.length }); }
+    try { return Object.assign(native.decodeImage(file), { fileSize: file.length }); }
     catch (e) { const err = new Error('拼图失败：图片' + i + '解码异常: ' + String(e.message).replace(/^拼图失败：/, '')); err.code = e.code; throw err; }
   });
   const res = await stitchPng(images, direction, opts);
@@ -101,4 +105,4 @@ function plan(images, direction, opts) {
   return native.plan(a[0], a[1], a[2], a[3], a[4]);
 }
 
-module.exports = { stitch, stitchSync, stitchPng, stitchFiles, encodePng, decodePng, plan, native, DIRECTION, MODE, FILTER, PLATFORM };
+module.exports = { stitch, stitchSync, stitchPng, stitchFiles, encodePng, decodePng, decodeImage, plan, native, DIRECTION, MODE, FILTER, PLATFORM };

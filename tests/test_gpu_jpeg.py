@@ -1,0 +1,105 @@
+"""JPEG decode: Huffman decoding on the host + IDCT / fancy upsampling / colour conversion
+on the GPU, against PIL (libjpeg-turbo, slow integer IDCT, fancy upsampling: the defaults).  The arithmetic is meant to
+be the same, so the bar is bit-exact; a tolerance would hide a wrong rounding constant."""
+import io
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import imagestitching_amd as ist
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _jpeg(a, **kw):
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def _pil(data):
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGBA"))
+
+
+def _photo(seed, h, w):
+    """smooth content + some texture: what JPEG is for (pure noise at quality 75 is mostly clamping)."""
+    a = U.smooth_image(seed, h, w)[..., :3].astype(np.int32)
+    a += np.random.default_rng(seed).integers(-20, 21, a.shape)
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+@pytest.mark.parametrize("size", [(64, 48), (67, 45), (1, 1), (8, 8), (17, 33), (250, 131)])
+def test_jpeg_matches_pil(subsampling, size):
+    w, h = size
+    for q, seed in ((90, 1), (50, 2)):
+        data = _jpeg(_photo(seed, h, w), quality=q, subsampling=subsampling)
+        got = ist.decode_image(data)
+        ref = _pil(data)
+        assert got.shape == ref.shape
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert d.max() == 0, "subsampling %d size %s q%d: max diff %d, %d px differ" % (subsampling, size, q, d.max(), (d.max(-1) > 0).sum())
+
+
+def test_jpeg_greyscale_noise_and_optimised_tables():
+    g = np.random.default_rng(3).integers(0, 256, (37, 53), dtype=np.uint8)
+    for kw in ({"quality": 95}, {"quality": 30, "optimize": True}):
+        data = _jpeg(g, **kw)
+        assert np.array_equal(ist.decode_image(data), _pil(data))
+    noise = np.random.default_rng(4).integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    data = _jpeg(noise, quality=100, subsampling=2, optimize=True)
+    assert np.array_equal(ist.decode_image(data), _pil(data))
+
+
+def test_jpeg_restart_intervals():
+    a = _photo(5, 120, 200)
+    for kw in ({"restart_marker_blocks": 3}, {"restart_marker_rows": 1}):
+        data = _jpeg(a, quality=80, subsampling=2, **kw)
+        assert b"\xff\xdd" in data
+        assert np.array_equal(ist.decode_image(data), _pil(data))
+
+
+def test_jpeg_exif_orientation_feeds_the_planner(tmp_path):
+    a = _photo(6, 48, 64)
+    exif = Image.Exif()
+    exif[0x0112] = 6
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, "JPEG", quality=92, exif=exif)
+    assert ist.image_info(b.getvalue()) == (64, 48, 6)
+    p = tmp_path / "rot.jpg"
+    p.write_bytes(b.getvalue())
+    plain = tmp_path / "plain.jpg"
+    plain.write_bytes(_jpeg(_photo(7, 64, 48), quality=92))
+    res = ist.stitch_files([str(p), str(plain)], "vertical", {"filter": "nearest"})
+    bitmaps = [_pil(b.getvalue()), _pil(plain.read_bytes())]
+    ref, pd, _ = U.oracle_stitch(bitmaps, "vertical", {"filter": "nearest"}, orientations=[6, 1])
+    assert np.array_equal(ist.decode_png(res["png"]), ref)
+
+
+def test_full_size_photo_decode():
+    """a 12 MP 4:2:0 JPEG (what a phone camera writes)."""
+    a = _photo(8, 3024, 4032)
+    data = _jpeg(a, quality=88, subsampling=2)
+    got = ist.decode_image(data)
+    assert np.array_equal(got, _pil(data))
+
+
+def test_jpeg_unsupported_and_damaged_files():
+    a = _photo(9, 40, 40)
+    with pytest.raises(ist.StitchError) as e:
+        ist.decode_image(_jpeg(a, progressive=True))
+    assert e.value.code == -7 and "progressive" in str(e.value)
+    # luma sampling factors beyond 2 (true 4:1:1): patch the frame header of a 4:4:4 file (Y: 0x11 -> 0x41)
+    raw = bytearray(_jpeg(a, quality=80, subsampling=0))
+    sof = raw.find(b"\xff\xc0")
+    assert raw[sof + 11] == 0x11
+    raw[sof + 11] = 0x41
+    with pytest.raises(ist.StitchError) as e:
+        ist.decode_image(bytes(raw))
+    assert e.value.code == -7
+    good = _jpeg(a, quality=80)
+    with pytest.raises(ist.StitchError) as e:
+        ist.decode_image(good[:len(good) // 3])
+    assert e.value.code == -6

@@ -203,3 +203,25 @@ def test_node_stitch_files_png_in_png_out(tmp_path):
     ref, pd, _ = U.oracle_stitch(px, "vertical", {"mode": "max", "gap": 3})
     got = np.asarray(Image.open(tmp_path / "out.png").convert("RGBA"))
     assert got.shape == ref.shape and U.max_abs_diff(got, ref) <= 1
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_stitch_files_with_jpeg_inputs(tmp_path):
+    """JPEG + PNG files in, PNG out, through the Node host; EXIF orientation comes from the file."""
+    from PIL import Image
+    a = U.smooth_image(620, 48, 64)[..., :3]
+    b = U.smooth_image(621, 64, 48)
+    exif = Image.Exif()
+    exif[0x0112] = 3
+    Image.fromarray(a).save(tmp_path / "a.jpg", quality=90, exif=exif)
+    Image.fromarray(b, "RGBA").save(tmp_path / "b.png")
+    paths = [str(tmp_path / "a.jpg"), str(tmp_path / "b.png")]
+    code = ("const api=require('%s/node/index.js');"
+            "api.stitchFiles(JSON.parse(process.argv[1]),'horizontal',{filter:'nearest'},process.argv[2]).then(r=>console.log(JSON.stringify([r.width,r.height])),e=>{console.log(e.message);process.exit(3)});") % ROOT
+    out = subprocess.run([NODE, "-e", code, json.dumps(paths), str(tmp_path / "out.png")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    bitmaps = [np.asarray(Image.open(tmp_path / "a.jpg").convert("RGBA")), b]
+    ref, pd, _ = U.oracle_stitch(bitmaps, "horizontal", {"filter": "nearest"}, orientations=[3, 1])
+    got = np.asarray(Image.open(tmp_path / "out.png").convert("RGBA"))
+    assert np.array_equal(got, ref)

@@ -115,3 +115,19 @@ def test_errors_are_reported_like_decode_failures():
     with pytest.raises(ist.StitchError) as e:
         ist.decode_png(bytes(inter))
     assert e.value.code == -7 and "Adam7" in str(e.value)
+
+
+def test_jpeg_header_and_exif_orientation_on_cpu():
+    """ist_image_info needs no GPU: size + EXIF orientation (what getImageInfo feeds the planner, index.js:734)."""
+    for endian_o in (1, 3, 6, 8):
+        exif = Image.Exif()
+        exif[0x0112] = endian_o
+        b = io.BytesIO()
+        Image.fromarray(RNG.integers(0, 256, (21, 34, 3), dtype=np.uint8)).save(b, "JPEG", exif=exif)
+        assert ist.image_info(b.getvalue()) == (34, 21, endian_o)
+    b = io.BytesIO()
+    Image.fromarray(RNG.integers(0, 256, (5, 7, 3), dtype=np.uint8)).save(b, "JPEG")
+    assert ist.image_info(b.getvalue()) == (7, 5, 0)
+    b = io.BytesIO()
+    Image.fromarray(RNG.integers(0, 256, (5, 7, 4), dtype=np.uint8), "RGBA").save(b, "PNG")
+    assert ist.image_info(b.getvalue()) == (7, 5, 0)
