@@ -10,6 +10,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "ist_internal.h"
 #include "ist_jpeg.h"
@@ -374,6 +375,132 @@ int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* he
 int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch) {
   if (file && len >= 2 && file[0] == 0xFF && file[1] == 0xD8) return ist_jpeg_decode_rgba8(ctx, file, len, out, out_pitch);
   return ist_png_decode_rgba8(file, len, out, out_pitch);
+}
+
+// ---- the whole onStitch for files, device-resident: only file bytes go in and only PNG bytes come out over PCIe -------
+// decode (index.js:1441-1520) -> plan (1251-1386) -> one fused resample+blit launch (1532-1551) -> PNG export (1577-1579).
+// The serial part of decoding (Huffman / inflate) runs on host threads, one per image; JPEG reconstruction, the stitch
+// and the PNG encoder run on the GPU and hand buffers to each other in HBM.
+int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images, int direction, int mode,
+                         double gap, const ist_limits* limits, int filter, ist_plan* out_plan, uint8_t** out_png,
+                         int64_t* out_len) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (!out_plan || !out_png || !out_len) return fail(IST_E_INVALID, "ist_stitch_files_png: NULL output");
+  *out_png = nullptr; *out_len = 0;
+  std::memset(out_plan, 0, sizeof(*out_plan));
+  if (n_images <= 0) return IST_NOTHING_TO_DO;
+  if (!files || !lens) return fail(IST_E_INVALID, "ist_stitch_files_png: NULL input");
+  if (n_images > kMaxImages) return fail(IST_E_UNSUPPORTED, "more than 128 images in one launch");
+  const int n = n_images;
+  // 1. host side of decoding, one thread per image
+  struct Dec { int rc = 0; std::string err; bool jpeg = false; JpegImage J; int w = 0, h = 0, orient = 0; std::vector<uint8_t> px; };
+  std::vector<Dec> dec(static_cast<size_t>(n));
+  {
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; ++i) th.emplace_back([&, i]() {
+      Dec& D = dec[static_cast<size_t>(i)];
+      const uint8_t* f = files[i]; const int64_t len = lens[i];
+      D.jpeg = f && len >= 2 && f[0] == 0xFF && f[1] == 0xD8;
+      if (D.jpeg) {
+        D.rc = jpeg_parse_and_entropy_decode(f, len, &D.J, false);
+        D.w = D.J.width; D.h = D.J.height; D.orient = D.J.orientation;
+      } else {
+        int32_t w = 0, h = 0;
+        D.rc = ist_png_info(f, len, &w, &h);
+        if (D.rc == IST_OK) { D.w = w; D.h = h; D.px.resize(static_cast<size_t>(w) * h * 4); D.rc = ist_png_decode_rgba8(f, len, D.px.data(), static_cast<size_t>(w) * 4); }
+      }
+      if (D.rc != IST_OK) D.err = g_last_error;        // thread-local in the worker: carry it out
+    });
+    for (auto& t : th) t.join();
+  }
+  for (int i = 0; i < n; ++i)
+    if (dec[static_cast<size_t>(i)].rc != IST_OK)
+      return fail(dec[static_cast<size_t>(i)].rc, "图片" + std::to_string(i) + "解码异常: " + dec[static_cast<size_t>(i)].err);   // index.js:1512-1514
+
+  // 2. plan (orientation from the file, like getImageInfo -> index.js:734)
+  std::vector<ist_image_desc> descs(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) {
+    const Dec& D = dec[static_cast<size_t>(i)];
+    ist_image_desc& d = descs[static_cast<size_t>(i)];
+    std::memset(&d, 0, sizeof d);
+    d.width = D.w; d.height = D.h; d.orientation = D.orient ? D.orient : 1; d.opaque = D.jpeg ? 1 : 0; d.file_size = lens[i];
+  }
+  ist_limits lim;
+  if (limits) lim = *limits; else ist_limits_unlimited(&lim);
+  int rc = ist_plan_compute(descs.data(), n, direction, mode, gap, &lim, out_plan);
+  if (rc != IST_OK) return rc;
+  struct PlanGuard { ist_plan* p; bool keep = false; ~PlanGuard() { if (!keep) ist_plan_free(p); } } pg{out_plan};
+  std::vector<ist_op> ops(static_cast<size_t>(out_plan->n_rects) + 1);
+  int n_ops = 0;
+  rc = ist_plan_ops(out_plan, descs.data(), n, ops.data(), &n_ops);
+  if (rc != IST_OK) return rc;
+
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  // 3. one device arena: bitmaps, JPEG coefficient planes + sample planes, canvas, PNG
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
+  std::vector<size_t> o_img(static_cast<size_t>(n));
+  struct JOff { size_t coef[3], q[3], plane[3]; };
+  std::vector<JOff> jo(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) {
+    const Dec& D = dec[static_cast<size_t>(i)];
+    o_img[static_cast<size_t>(i)] = take(static_cast<size_t>(D.w) * 4 * D.h);
+    if (D.jpeg) for (int c = 0; c < D.J.ncomp; ++c) {
+      jo[static_cast<size_t>(i)].coef[c] = take(D.J.comp[c].coef.size() * 2);
+      jo[static_cast<size_t>(i)].q[c] = take(128);
+      jo[static_cast<size_t>(i)].plane[c] = take(static_cast<size_t>(D.J.comp[c].blocks_x) * 8 * D.J.comp[c].blocks_y * 8);
+    }
+  }
+  const size_t canvas_pitch = static_cast<size_t>(out_plan->canvas_w) * 4;
+  const size_t o_canvas = take(canvas_pitch * static_cast<size_t>(out_plan->canvas_h));
+  const int64_t png_cap = ist_png_bound(out_plan->canvas_w, out_plan->canvas_h);
+  const size_t o_png = take(static_cast<size_t>(png_cap));
+  uint8_t* d = nullptr;
+  IST_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
+  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
+  std::vector<const void*> dsrc(static_cast<size_t>(n));
+  std::vector<size_t> dpitch(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) {
+    const Dec& D = dec[static_cast<size_t>(i)];
+    uint8_t* img = d + o_img[static_cast<size_t>(i)];
+    const size_t row = static_cast<size_t>(D.w) * 4;
+    dsrc[static_cast<size_t>(i)] = img; dpitch[static_cast<size_t>(i)] = row;
+    if (!D.jpeg) { IST_HIP(hipMemcpyAsync(img, D.px.data(), D.px.size(), hipMemcpyHostToDevice, ctx->stream)); continue; }
+    JpegDeviceJob job;
+    job.width = D.w; job.height = D.h; job.ncomp = D.J.ncomp; job.hmax = D.J.hmax; job.vmax = D.J.vmax;
+    for (int c = 0; c < 3; ++c) { job.d_coef[c] = nullptr; job.d_q[c] = nullptr; job.d_plane[c] = nullptr; job.h[c] = job.v[c] = 1; job.blocks_x[c] = job.blocks_y[c] = 0; }
+    for (int c = 0; c < D.J.ncomp; ++c) {
+      const JOff& o = jo[static_cast<size_t>(i)];
+      IST_HIP(hipMemcpyAsync(d + o.coef[c], D.J.comp[c].coef.data(), D.J.comp[c].coef.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+      IST_HIP(hipMemcpyAsync(d + o.q[c], D.J.comp[c].q, 128, hipMemcpyHostToDevice, ctx->stream));
+      job.d_coef[c] = reinterpret_cast<const int16_t*>(d + o.coef[c]);
+      job.d_q[c] = reinterpret_cast<const uint16_t*>(d + o.q[c]);
+      job.d_plane[c] = d + o.plane[c];
+      job.h[c] = D.J.comp[c].h; job.v[c] = D.J.comp[c].v; job.blocks_x[c] = D.J.comp[c].blocks_x; job.blocks_y[c] = D.J.comp[c].blocks_y;
+    }
+    job.out = img; job.out_pitch = row;
+    rc = jpeg_launch_reconstruct(job, ctx->stream);
+    if (rc) return rc;
+  }
+  // 4. the stitch: one fused launch from the decoded bitmaps (HBM) into the canvas (HBM)
+  static const uint8_t transparent[4] = {0, 0, 0, 0};
+  ist_job* job = ist_job_create(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, descs.data(), n, filter, nullptr);
+  if (!job) return g_last_code ? g_last_code : IST_E_INVALID;
+  struct JobFree { ist_job* j; ~JobFree() { ist_job_destroy(j); } } jf{job};
+  rc = ist_job_launch(job, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, ctx->stream);
+  if (rc) return rc;
+  // 5. PNG export on the device, then the only D2H of the call
+  int64_t len = 0;
+  rc = ist_png_encode_device(ctx, d + o_canvas, canvas_pitch, out_plan->canvas_w, out_plan->canvas_h, d + o_png, png_cap, &len, ctx->stream);
+  if (rc) return rc;
+  uint8_t* host = static_cast<uint8_t*>(std::malloc(static_cast<size_t>(len)));
+  if (!host) return fail(IST_E_NOMEM, "out of memory for the PNG");
+  if (hipMemcpyAsync(host, d + o_png, static_cast<size_t>(len), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) { std::free(host); return fail(IST_E_HIP, "PNG readback failed"); }
+  *out_png = host; *out_len = len;
+  pg.keep = true;
+  return IST_OK;
 }
 
 // PNG of host pixels (H2D, encode, D2H)

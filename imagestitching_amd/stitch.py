@@ -254,23 +254,31 @@ def decode_image(data, device=0):
 
 
 def stitch_files(paths, direction, opts=None, out_path=None, device=0):
-    """File to file: decode (PNG: host; JPEG: host entropy decode + GPU reconstruction) -> stitch -> PNG export (GPU).
-    EXIF orientation is read from the file like getImageInfo does (index.js:734).  Returns {'width','height','png'} and
-    writes out_path when given.  The mini-program's whole onStitch: index.js:1441-1581."""
-    images = []
-    for i, p in enumerate(paths):
+    """File to file, device-resident (ist_stitch_files_png): decode (Huffman / inflate on host threads, JPEG
+    reconstruction on the GPU) -> plan (EXIF orientation from the file, like getImageInfo, index.js:734) -> one fused
+    stitch launch -> PNG export on the GPU.  Only file bytes go in and PNG bytes come out over PCIe.
+    Returns {'width','height','png'} and writes out_path when given.  The mini-program's whole onStitch: index.js:1441-1581."""
+    o = _merge(opts)
+    n = len(paths)
+    if n == 0:
+        return None
+    blobs = []
+    for p in paths:
         with open(p, "rb") as f:
-            data = f.read()
-        try:
-            w, h, orient = image_info(data)
-            px = decode_image(data, device)
-        except L.StitchError as e:
-            raise L.StitchError(e.code, "图片%d解码异常: %s" % (i, e.reason))
-        # the planner sees the size getImageInfo reports; for quarter turns the reference is given the oriented size
-        images.append({"width": px.shape[1], "height": px.shape[0], "data": px, "fileSize": len(data), "orientation": orient or 1,
-                       "opaque": data[:2] == b"\xff\xd8"})
-    res = stitch_png(images, direction, opts, device)
-    if res is not None and out_path:
+            blobs.append(f.read())
+    files = (C.c_char_p * n)(*blobs)
+    lens = (C.c_int64 * n)(*[len(b) for b in blobs])
+    cplan = L.Plan()
+    lim = _limits(o)
+    out, ln = C.POINTER(C.c_uint8)(), C.c_int64(0)
+    rc = L.check(L.lib.ist_stitch_files_png(_ctx(device), files, lens, n, _DIRECTIONS[direction], _MODES[o["mode"]], float(o["gap"] or 0),
+                                            C.byref(lim), _filter_of(o), C.byref(cplan), C.byref(out), C.byref(ln)))
+    if rc == L.IST_NOTHING_TO_DO:
+        return None
+    w, h = int(cplan.canvas_w), int(cplan.canvas_h)
+    L.lib.ist_plan_free(C.byref(cplan))
+    res = {"width": w, "height": h, "png": _take_png(out, ln)}
+    if out_path:
         with open(out_path, "wb") as f:
             f.write(res["png"])
     return res

@@ -178,6 +178,14 @@ IST_API int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len
 IST_API int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation);
 IST_API int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch);
 
+/* ---- files in, file out: the whole onStitch (decode -> plan -> resample+blit -> PNG export; index.js:1441-1581) ---- */
+/* files[i] = PNG or JPEG file bytes.  Huffman / inflate on host threads (one per image), everything else on the GPU;
+ * decoded bitmaps, canvas and PNG stay in HBM - only file bytes go in and PNG bytes come out.  A file that does not
+ * decode fails with IST_E_DECODE / IST_E_UNSUPPORTED and the message '图片N解码异常: ...' (index.js:1512-1514). */
+IST_API int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images,
+                                 int direction, int mode, double gap, const ist_limits* limits, int filter,
+                                 ist_plan* out_plan, uint8_t** out_png, int64_t* out_len);
+
 /* ---- export: lossless PNG (fileType 'png', quality 1; utils/canvas.js:205-242, index.js:1577-1579) --------------- */
 /* upper bound of the file size for a w x h RGBA canvas */
 IST_API int64_t ist_png_bound(int64_t w, int64_t h);

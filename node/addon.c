@@ -299,6 +299,80 @@ static napi_value js_stitch(napi_env env, napi_callback_info info) {
   return promise;
 }
 
+/* stitchFiles(files: Buffer[], direction, mode, gap, limits, filter) -> Promise<{width,height,png,plan}>
+ * the device-resident pipeline (ist_stitch_files_png): only file bytes go in, only PNG bytes come out */
+typedef struct {
+  int n; const uint8_t** files; int64_t* lens; napi_ref* refs;
+  int direction, mode, filter; double gap; ist_limits lim;
+  ist_plan plan; uint8_t* png; int64_t png_len; int rc; char err[256];
+  napi_deferred deferred; napi_async_work work;
+} files_job;
+
+static void files_execute(napi_env env, void* data) {
+  (void)env;
+  files_job* j = (files_job*)data;
+  ist_ctx* ctx = get_ctx();
+  if (!ctx) { j->rc = IST_E_NO_DEVICE; snprintf(j->err, sizeof j->err, "%s", g_ctx_err); return; }
+  j->rc = ist_stitch_files_png(ctx, j->files, j->lens, j->n, j->direction, j->mode, j->gap, &j->lim, j->filter, &j->plan, &j->png, &j->png_len);
+  if (j->rc < 0) snprintf(j->err, sizeof j->err, "%s", ist_last_error());
+}
+
+static void files_complete(napi_env env, napi_status status, void* data) {
+  files_job* j = (files_job*)data;
+  (void)status;
+  if (j->rc < 0) napi_reject_deferred(env, j->deferred, make_error(env, j->rc, j->err));
+  else if (j->rc == IST_NOTHING_TO_DO) { napi_value u; napi_get_null(env, &u); napi_resolve_deferred(env, j->deferred, u); }
+  else {
+    napi_value o, buf;
+    napi_create_object(env, &o);
+    if (napi_create_external_buffer(env, (size_t)j->png_len, j->png, free_pixels, NULL, &buf) != napi_ok) {
+      ist_free(j->png); napi_reject_deferred(env, j->deferred, make_error(env, IST_E_NOMEM, "could not wrap the PNG buffer"));
+    } else {
+      set_num(env, o, "width", (double)j->plan.canvas_w); set_num(env, o, "height", (double)j->plan.canvas_h);
+      napi_set_named_property(env, o, "png", buf);
+      napi_set_named_property(env, o, "plan", plan_to_js(env, &j->plan));
+      napi_resolve_deferred(env, j->deferred, o);
+    }
+    ist_plan_free(&j->plan);
+  }
+  napi_delete_async_work(env, j->work);
+  for (int i = 0; i < j->n; i++) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
+  free(j->files); free(j->lens); free(j->refs); free(j);
+}
+
+static napi_value js_stitch_files(napi_env env, napi_callback_info info) {
+  size_t argc = 6; napi_value argv[6];
+  if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < 6) { napi_throw_type_error(env, NULL, "stitchFiles(files, direction, mode, gap, limits, filter)"); return NULL; }
+  bool is_arr = false; uint32_t n = 0;
+  if (napi_is_array(env, argv[0], &is_arr) != napi_ok || !is_arr) { napi_throw_type_error(env, NULL, "files must be an array of Buffers"); return NULL; }
+  napi_get_array_length(env, argv[0], &n);
+  files_job* j = (files_job*)calloc(1, sizeof *j);
+  j->n = (int)n;
+  j->files = (const uint8_t**)calloc(n ? n : 1, sizeof(uint8_t*)); j->lens = (int64_t*)calloc(n ? n : 1, sizeof(int64_t)); j->refs = (napi_ref*)calloc(n ? n : 1, sizeof(napi_ref));
+  for (uint32_t i = 0; i < n; i++) {
+    napi_value e; void* p = NULL; size_t len = 0; bool isbuf = false, ta = false;
+    napi_get_element(env, argv[0], i, &e);
+    napi_is_buffer(env, e, &isbuf); napi_is_typedarray(env, e, &ta);
+    if (isbuf) napi_get_buffer_info(env, e, &p, &len);
+    else if (ta) { napi_typedarray_type tt; napi_value ab; size_t off; napi_get_typedarray_info(env, e, &tt, &len, &p, &ab, &off); }
+    if (!p) { napi_throw_type_error(env, NULL, "files[i] must be a Buffer / Uint8Array"); for (uint32_t k = 0; k < i; k++) napi_delete_reference(env, j->refs[k]); free(j->files); free(j->lens); free(j->refs); free(j); return NULL; }
+    j->files[i] = (const uint8_t*)p; j->lens[i] = (int64_t)len;
+    napi_create_reference(env, e, 1, &j->refs[i]);
+  }
+  int32_t v = 0;
+  napi_get_value_int32(env, argv[1], &v); j->direction = v;
+  napi_get_value_int32(env, argv[2], &v); j->mode = v;
+  napi_get_value_double(env, argv[3], &j->gap);
+  limits_parse(env, argv[4], &j->lim);
+  napi_get_value_int32(env, argv[5], &v); j->filter = v;
+  napi_value promise, name;
+  CHECK(napi_create_promise(env, &j->deferred, &promise));
+  napi_create_string_utf8(env, "imagestitch.stitchFiles", NAPI_AUTO_LENGTH, &name);
+  CHECK(napi_create_async_work(env, NULL, name, files_execute, files_complete, j, &j->work));
+  CHECK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+
 static napi_value js_stitch_sync(napi_env env, napi_callback_info info) {
   stitch_job* j = stitch_parse(env, info, 0);
   if (!j) return NULL;
@@ -473,6 +547,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"plan", NULL, js_plan, NULL, NULL, NULL, napi_default, NULL},
       {"stitch", NULL, js_stitch, NULL, NULL, NULL, napi_default, NULL},
       {"stitchSync", NULL, js_stitch_sync, NULL, NULL, NULL, napi_default, NULL},
+      {"stitchFiles", NULL, js_stitch_files, NULL, NULL, NULL, napi_default, NULL},
       {"render", NULL, js_render, NULL, NULL, NULL, napi_default, NULL},
       {"encodePng", NULL, js_encode_png, NULL, NULL, NULL, napi_default, NULL},
       {"decodePng", NULL, js_decode_png, NULL, NULL, NULL, napi_default, NULL},

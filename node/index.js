@@ -89,12 +89,11 @@ function decodeImage(file) { return native.decodeImage(file); }
  *  outPath when given. A file that does not decode rejects with '图片N解码异常' like index.js:1512-1514. */
 async function stitchFiles(paths, direction, opts, outPath) {
   const fs = require('fs');
-  const images = paths.map((p, i) => {
-    const file = fs.readFileSync(p);
-    try { return Object.assign(native.decodeImage(file), { fileSize: file.length }); }
-    catch (e) { const err = new Error('拼图失败：图片' + i + '解码异常: ' + String(e.message).replace(/^拼图失败：/, '')); err.code = e.code; throw err; }
-  });
-  const res = await stitchPng(images, direction, opts);
+  const a = args([], direction, opts);
+  if (!paths || !paths.length) return null;
+  const files = paths.map((p) => fs.readFileSync(p));
+  // one native call: Huffman / inflate on host threads, reconstruction + stitch + PNG on the GPU, buffers stay in HBM
+  const res = await withProgress(opts, () => native.stitchFiles(files, a[1], a[2], a[3], a[4], a[5]));
   if (res && outPath) fs.writeFileSync(outPath, res.png);
   return res;
 }

@@ -14,7 +14,7 @@ import torch  # noqa: E402
 
 import imagestitching_amd as ist  # noqa: E402
 
-what = sys.argv[1:] or ["config5", "host", "png"]
+what = sys.argv[1:] or ["config5", "host", "png", "files"]
 dev = torch.device("cuda", 0)
 
 if "config5" in what:
@@ -69,3 +69,30 @@ if "png" in what:
     t = sorted(ts)[len(ts) // 2]
     print("png device-resident 4032x27216: %d bytes (%.4f x raw), %.3f ms per encode incl. host checksum combine = %.0f MP/s, %.0f GB/s read+write"
           % (n, n / canvas.numel(), t * 1e3, 109.734912 / t, (canvas.numel() + n) / t / 1e9), flush=True)
+
+if "files" in what:
+    import io
+    import tempfile
+    from PIL import Image
+    tmp = tempfile.mkdtemp()
+    paths = []
+    yy, xx = np.mgrid[0:3024, 0:4032]
+    for k in range(9):
+        a = np.stack([(xx * (k + 1) // 7 + yy) % 256, (xx + yy * (k + 2) // 5) % 256, (xx * 3 + yy * 2 + 31 * k) % 256], -1).astype(np.uint8)
+        a = np.clip(a.astype(np.int16) + np.random.default_rng(k).integers(-12, 13, a.shape), 0, 255).astype(np.uint8)
+        p = os.path.join(tmp, "in%d.jpg" % k)
+        Image.fromarray(a).save(p, "JPEG", quality=90, subsampling=2)
+        paths.append(p)
+    size = sum(os.path.getsize(p) for p in paths)
+    res = ist.stitch_files(paths, "vertical")            # warm-up
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res = ist.stitch_files(paths, "vertical", out_path=os.path.join(tmp, "out.png"))
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[1]
+    print("files: 9 x 12 MP JPEG (%.1f MB total) -> %dx%d PNG (%.0f MB): %.0f ms end to end (file read, Huffman on %d host threads, GPU "
+          "reconstruct + stitch + PNG, PNG write) = %.0f MP/s" % (size / 1e6, res["width"], res["height"], len(res["png"]) / 1e6, t * 1e3, 9, 109.734912 / t), flush=True)
+    t0 = time.perf_counter()
+    one = ist.decode_image(open(paths[0], "rb").read())
+    print("one 12 MP JPEG decode (host Huffman + H2D + GPU + D2H): %.0f ms" % ((time.perf_counter() - t0) * 1e3))
