@@ -72,6 +72,7 @@ SYMBOLS = [
     ("ist_plan_compute", C.c_int, [C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Limits), C.POINTER(Plan)]),
     ("ist_plan_free", None, [C.POINTER(Plan)]),
     ("ist_plan_ops", C.c_int, [C.POINTER(Plan), C.POINTER(ImageDesc), C.c_int, C.POINTER(Op), C.POINTER(C.c_int)]),
+    ("ist_op_box", C.c_int, [C.POINTER(Op), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int32)]),
     ("ist_ctx_create", C.c_void_p, [C.c_int]),
     ("ist_ctx_destroy", None, [C.c_void_p]),
     ("ist_job_create", C.c_void_p, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(Op), C.c_int,

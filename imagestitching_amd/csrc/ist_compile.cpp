@@ -353,3 +353,14 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
 }
 
 }  // namespace ist
+
+extern "C" int ist_op_box(const ist_op* op, int64_t canvas_w, int64_t canvas_h, int filter, int32_t box[4]) {
+  if (!op || !box) return ist::fail(IST_E_INVALID, "ist_op_box: NULL argument");
+  ist::DevOp r;
+  // the source clamp box does not matter for the destination box: pretend the bitmap is as large as the source rect
+  const int iw = static_cast<int>(std::min(std::max(op->s[0] + op->s[2], 1.0), 2147483647.0));
+  const int ih = static_cast<int>(std::min(std::max(op->s[1] + op->s[3], 1.0), 2147483647.0));
+  const int rc = ist::resolve_op(*op, canvas_w, canvas_h, iw, ih, &r, (filter & IST_FILTER_EDGE_AA) != 0);
+  box[0] = r.X0; box[1] = r.Y0; box[2] = r.X1; box[3] = r.Y1;
+  return rc;
+}

@@ -564,13 +564,11 @@ IST_DEV void run_tile(const LaunchArgs& A, int64_t tile) {
   const int path = c.path;
   if ((PATHS & HAS_COPY) && path == PATH_COPY) {
     const DevOp op = A.ops[c.op];
-    if (V == 0) tile_copy<2, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);      // production: 256x8 tile, 2 rows per wave
-    else if (V == 1) tile_copy<8, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
-    else if (V == 2) tile_copy<4, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
-    else if (V == 3) tile_copy<16, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
-    else if (V == 4) tile_copy<8, true, false, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
-    else if (V == 5) tile_copy<8, true, true, false>(A, op, c.bg, lg, X0, Y0, X1, Y1);
-    else tile_copy<8, false, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);
+    // V = 0 is what ships; 1..3 are kept as measured alternatives for tools/sweep_variants.py (IST_TUNING=1)
+    if (V == 0) tile_copy<2, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);        // 256x8 tile: 2 rows per wave in flight
+    else if (V == 1) tile_copy<8, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);   // 8 rows per wave in flight
+    else if (V == 2) tile_copy<8, false, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);  // a wave owns consecutive rows
+    else tile_copy<8, true, false, false>(A, op, c.bg, lg, X0, Y0, X1, Y1);             // no non-temporal hints
   } else if ((PATHS & HAS_FILL) && path == PATH_FILL) {
     tile_fill(A, c.bg, lg, X0, Y0, X1, Y1);
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE_LDS) {
@@ -609,9 +607,13 @@ static void launch_one(const LaunchArgs& args, int64_t n_tiles, hipStream_t stre
 
 template <int PATHS>
 static void launch_variant(int v, bool persist, const LaunchArgs& a, int64_t n, hipStream_t s, int pb) {
-#define IST_CASE(N) case N: if (persist) launch_one<PATHS, N, true>(a, n, s, pb); else launch_one<PATHS, N, false>(a, n, s, pb); break;
-  switch (v) { IST_CASE(0) IST_CASE(1) IST_CASE(2) IST_CASE(3) IST_CASE(4) IST_CASE(5) default: IST_CASE(6) }
-#undef IST_CASE
+  if (persist) { launch_one<PATHS, 0, true>(a, n, s, pb); return; }      // grid-stride form of the shipped variant
+  switch (v) {
+    case 1: launch_one<PATHS, 1, false>(a, n, s, pb); break;
+    case 2: launch_one<PATHS, 2, false>(a, n, s, pb); break;
+    case 3: launch_one<PATHS, 3, false>(a, n, s, pb); break;
+    default: launch_one<PATHS, 0, false>(a, n, s, pb); break;
+  }
 }
 
 int launch_stitch(const LaunchArgs& args, int64_t n_tiles, bool lean, void* stream) {

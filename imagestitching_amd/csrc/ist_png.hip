@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "ist_internal.h"
@@ -240,8 +241,8 @@ int ist_png_encode_device(ist_ctx* ctx, const void* canvas, size_t pitch, int64_
   (void)hipGetDevice(&dev);
 
   static CrcTables T;
-  static bool have_tables = false;
-  if (!have_tables) { make_tables(&T); have_tables = true; }
+  static std::once_flag tables_once;
+  std::call_once(tables_once, []() { make_tables(&T); });
   // x^(32 i): the register after 4 i zero bytes, starting from the polynomial "1"
   const int64_t n_pow = kBlockData / 4 + 1;
   std::vector<uint32_t> xpow(static_cast<size_t>(n_pow));

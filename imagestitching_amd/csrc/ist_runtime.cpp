@@ -68,6 +68,13 @@ struct PinScope {
   ~PinScope() { for (void* p : pinned) (void)hipHostUnregister(p); }
 };
 
+// rows that are contiguous on both sides are ONE linear copy: the 2-D (rect) path of the runtime is only taken when a
+// pitch really differs (it has its own size limits and is slower for tall, narrow images)
+hipError_t copy_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t row, size_t rows, hipMemcpyKind kind, hipStream_t st) {
+  if (dpitch == row && spitch == row) return hipMemcpyAsync(dst, src, row * rows, kind, st);
+  return hipMemcpy2DAsync(dst, dpitch, src, spitch, row, rows, kind, st);
+}
+
 int grow(void** p, size_t* have, size_t need) {
   if (*have >= need) return IST_OK;
   if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
@@ -228,7 +235,7 @@ static int render_to_scratch(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, c
     if (hp < row) return fail(IST_E_INVALID, "src_pitch too small");
     pins->pin(src[i], hp * static_cast<size_t>(job->host.img_h[i] - 1) + row);
     uint8_t* d = static_cast<uint8_t*>(ctx->scratch_src) + off[i];
-    IST_HIP(hipMemcpy2DAsync(d, row, src[i], hp, row, static_cast<size_t>(job->host.img_h[i]), hipMemcpyHostToDevice, ctx->stream));
+    IST_HIP(copy_rows(d, row, src[i], hp, row, static_cast<size_t>(job->host.img_h[i]), hipMemcpyHostToDevice, ctx->stream));
     dsrc[i] = d; dpitch[i] = row;
   }
   rc = ist_job_launch(job, dsrc.data(), dpitch.data(), n_images, ctx->scratch_dst, canvas_pitch, ctx->stream);
@@ -260,7 +267,7 @@ int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uin
   if (dst_pitch < static_cast<size_t>(rw) * 4) return fail(IST_E_INVALID, "dst_pitch too small");
   pins.pin(dst, dst_pitch * static_cast<size_t>(rh - 1) + static_cast<size_t>(rw) * 4);
   const uint8_t* from = static_cast<const uint8_t*>(ctx->scratch_dst) + static_cast<size_t>(ry) * canvas_pitch + static_cast<size_t>(rx) * 4;
-  IST_HIP(hipMemcpy2DAsync(dst, dst_pitch, from, canvas_pitch, static_cast<size_t>(rw) * 4, static_cast<size_t>(rh), hipMemcpyDeviceToHost, ctx->stream));
+  IST_HIP(copy_rows(dst, dst_pitch, from, canvas_pitch, static_cast<size_t>(rw) * 4, static_cast<size_t>(rh), hipMemcpyDeviceToHost, ctx->stream));
   IST_HIP(hipStreamSynchronize(ctx->stream));
   return IST_OK;
 }
@@ -360,7 +367,7 @@ int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_
   job.out = d + o_out; job.out_pitch = row;
   rc = jpeg_launch_reconstruct(job, ctx->stream);
   if (rc) return rc;
-  IST_HIP(hipMemcpy2DAsync(out, out_pitch, d + o_out, row, row, static_cast<size_t>(J.height), hipMemcpyDeviceToHost, ctx->stream));
+  IST_HIP(copy_rows(out, out_pitch, d + o_out, row, row, static_cast<size_t>(J.height), hipMemcpyDeviceToHost, ctx->stream));
   IST_HIP(hipStreamSynchronize(ctx->stream));
   return IST_OK;
 }
@@ -515,7 +522,7 @@ int ist_png_encode_rgba8(ist_ctx* ctx, const uint8_t* pixels, size_t pitch, int6
   if (rc) return rc;
   PinScope pins;
   pins.pin(pixels, pitch * static_cast<size_t>(h - 1) + row);
-  IST_HIP(hipMemcpy2DAsync(ctx->scratch_dst, row, pixels, pitch, row, static_cast<size_t>(h), hipMemcpyHostToDevice, ctx->stream));
+  IST_HIP(copy_rows(ctx->scratch_dst, row, pixels, pitch, row, static_cast<size_t>(h), hipMemcpyHostToDevice, ctx->stream));
   const int64_t cap = ist_png_bound(w, h);
   void* dpng = nullptr;
   IST_HIP(hipMalloc(&dpng, static_cast<size_t>(cap)));

@@ -29,27 +29,16 @@ def owner_of(image_index, world):
 
 
 def _boxes(plan, filter_name):
-    """Canvas-space pixel boxes of every draw, from the C-ABI's own resolve step (a clip-free compile would need a
-    device; the boxes only need the CPU planner): ceil(lo-0.5)..ceil(hi-0.5) of the transformed destination rect."""
-    import math
+    """Canvas-space pixel boxes of every draw, from the C-ABI's own resolve step (ist_op_box: pure CPU)."""
+    import ctypes as C
     ops, n_ops = plan.ops()
     boxes = {}
+    box = (C.c_int32 * 4)()
+    f = {"nearest": L.FILTER_NEAREST, "bilinear": L.FILTER_BILINEAR}[filter_name]
     for k in range(1, n_ops):
-        o = ops[k]
-        a, b, c, d, e, f = list(o.m)
-        rx, ry, rw, rh = list(o.d)
-        if b == 0.0 and c == 0.0:
-            xa, xb = a * rx + e, a * (rx + rw) + e
-            ya, yb = d * ry + f, d * (ry + rh) + f
-        else:
-            xa, xb = c * ry + e, c * (ry + rh) + e
-            ya, yb = b * rx + f, b * (rx + rw) + f
-        X0, X1 = math.ceil(min(xa, xb) - 0.5), math.ceil(max(xa, xb) - 0.5)
-        Y0, Y1 = math.ceil(min(ya, yb) - 0.5), math.ceil(max(ya, yb) - 0.5)
-        X0, Y0 = max(X0, 0), max(Y0, 0)
-        X1, Y1 = min(X1, plan.canvas_w), min(Y1, plan.canvas_h)
-        if X1 > X0 and Y1 > Y0:          # a draw clipped away entirely (the reference's orientation-7 first image) has no band
-            boxes[o.image] = (X0, Y0, X1, Y1, k)
+        rc = L.check(L.lib.ist_op_box(C.byref(ops[k]), plan.canvas_w, plan.canvas_h, f, box))
+        if rc == 0 and box[2] > box[0] and box[3] > box[1]:      # a draw clipped away entirely (the reference's orientation-7 first image) has no band
+            boxes[ops[k].image] = (box[0], box[1], box[2], box[3], k)
     return boxes
 
 

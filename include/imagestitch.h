@@ -134,6 +134,10 @@ IST_API void ist_plan_free(ist_plan* plan);
  * ctx.scale(ss,ss) folded into every CTM (1426-1428), one drawWithOrientation per rect (utils/canvas.js:153-202).
  * ops must hold n_rects + 1 entries. */
 IST_API int ist_plan_ops(const ist_plan* plan, const ist_image_desc* images, int n_images, ist_op* ops, int* n_ops);
+/* canvas pixels one op touches: box = {X0, Y0, X1, Y1} (half open, clipped to the canvas) under the coverage rule of
+ * `filter` (pixel centre, or every touched pixel with IST_FILTER_EDGE_AA).  Returns 1 when the op draws nothing.
+ * Pure CPU; what the multi-GPU layer uses to cut a stitch into per-image bands. */
+IST_API int ist_op_box(const ist_op* op, int64_t canvas_w, int64_t canvas_h, int filter, int32_t box[4]);
 
 /* ---- device path: inputs and output already resident in HBM ------------------------------------------------- */
 IST_API ist_ctx* ist_ctx_create(int device);

@@ -15,8 +15,11 @@ import imagestitching_amd as ist  # noqa: E402
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 directions = sys.argv[2].split(",") if len(sys.argv) > 2 else ["vertical", "horizontal"]
 # (label, tile, variant, persist_blocks, full_kernel)
-CONFIGS = [("U2 256x8 bands", "256x8", 0, 0, 0, 0), ("U2 256x8 nobands", "256x8", 0, 0, 0, 0),
-           ("U2 512x4 bands", "512x4", 0, 0, 0, 0), ("U2 256x16 bands", "256x16", 2, 0, 0, 0)]
+# (label, IST_COPY_TILE, IST_VARIANT (0 shipped, 1 = 8 rows/wave, 2 = consecutive rows, 3 = no nt hints; +100 persistent),
+#  IST_PERSIST_BLOCKS, IST_FULL_KERNEL, IST_DYN_LDS)
+CONFIGS = [("shipped 256x8", "256x8", 0, 0, 0, 0), ("8 rows/wave 256x32", "256x32", 1, 0, 0, 0), ("consecutive 256x32", "256x32", 2, 0, 0, 0),
+           ("no nt 256x32", "256x32", 3, 0, 0, 0), ("persistent 256x8", "256x8", 100, 2048, 0, 0), ("shipped, full kernel", "256x8", 0, 0, 1, 0),
+           ("shipped 512x4", "512x4", 0, 0, 0, 0), ("1 row/wave 256x4", "256x4", 0, 0, 0, 0), ("4 rows/wave 256x16", "256x16", 1, 0, 0, 0)]
 dev = torch.device("cuda", 0)
 st = ist.Stitcher(0)
 imgs = [{"width": 4032, "height": 3024, "opaque": True} for _ in range(9)]
