@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # debugging aid: a native backtrace on SIGABRT / SIGSEGV (tools/abrt_trace.c), so that a crash inside a native
+    # library says where instead of only "Fatal Python error: Aborted"
+    so = os.path.join(ROOT, "tools", "libabrt.so")
+    if os.path.exists(so):
+        try:
+            import ctypes
+            ctypes.CDLL(so)
+        except OSError:
+            pass
 
 
 @pytest.fixture(scope="session")
