@@ -75,6 +75,7 @@ struct PngArgs {
   unsigned long long* s1; unsigned long long* s2;   // Adler partials per row
   uint32_t* crc;                 // raw CRC per (row, block)
   int64_t row_bytes; int32_t h; int32_t nb;
+  uint32_t segs;                 // 16-KiB segments per row
 };
 
 __global__ __launch_bounds__(256) void ist_png_rows_kernel(const PngArgs P) {
@@ -82,13 +83,15 @@ __global__ __launch_bounds__(256) void ist_png_rows_kernel(const PngArgs P) {
   const int tid = threadIdx.x, lane = tid & 63;
   for (int i = tid; i < 1024; i += 256) T[i >> 8][i & 255] = P.tables[i];
   __syncthreads();
-  const int r = blockIdx.y;
+  // one workgroup per 16-KiB row segment, numbered along the row first (contiguous file bytes for neighbouring workgroups)
+  const int r = static_cast<int>(blockIdx.x / P.segs);
+  const int seg = static_cast<int>(blockIdx.x - static_cast<unsigned>(r) * P.segs);
   const int64_t tab = P.row_tab[r];
   const int64_t pix_off = tab & ~15ll;
   const int k = static_cast<int>(tab & 15);
 
   // ---- the row's framing bytes: k empty stored blocks + block header + filter byte, then 80 bytes between blocks
-  if (blockIdx.x == 0 && tid < 64) {
+  if (seg == 0 && tid < 64) {
     const bool last_row = r == P.h - 1;
     const int lead = 5 * k + 6;
     for (int i = lane; i < lead; i += 64) {
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void ist_png_rows_kernel(const PngArgs P) {
   // checksums.  Several passes per workgroup amortise the table staging above.
 #pragma unroll 1
   for (int u = 0; u < kChunks; ++u) {
-  const int64_t p = ((static_cast<int64_t>(blockIdx.x) * kChunks + u) * 256 + tid) * 16;   // byte position of this lane's chunk in the row
+  const int64_t p = ((static_cast<int64_t>(seg) * kChunks + u) * 256 + tid) * 16;   // byte position of this lane's chunk in the row
   unsigned long long a1 = 0, a2 = 0;
   uint32_t c = 0;
   int b = 0;
@@ -278,16 +281,10 @@ int ist_png_encode_device(ist_ctx* ctx, const void* canvas, size_t pitch, int64_
   A.crc = reinterpret_cast<uint32_t*>(scratch + o_crc);
   A.row_bytes = L.row_bytes; A.h = static_cast<int32_t>(h); A.nb = L.nb;
   const unsigned gx = static_cast<unsigned>((L.row_bytes + 4096 * kChunks - 1) / (4096 * kChunks));
-  // grid.y is limited to 65535: walk the rows in slabs
-  for (int64_t r0 = 0; r0 < h; r0 += 65535) {
-    const unsigned gy = static_cast<unsigned>(std::min<int64_t>(65535, h - r0));
-    PngArgs S = A;
-    S.canvas += static_cast<size_t>(r0) * pitch;
-    S.row_tab += r0; S.s1 += r0; S.s2 += r0; S.crc += static_cast<size_t>(r0) * L.nb;
-    S.h = static_cast<int32_t>(h - r0);            // "last row" test is relative to the slab
-    hipLaunchKernelGGL(ist_png_rows_kernel, dim3(gx, gy), dim3(256), 0, stream, S);
-    PNG_HIP(hipGetLastError());
-  }
+  if (static_cast<int64_t>(gx) * h > 2147483647ll) return fail(IST_E_OUTPUT_SIZE, "image too large for one PNG launch");
+  A.segs = gx;
+  hipLaunchKernelGGL(ist_png_rows_kernel, dim3(static_cast<unsigned>(gx * static_cast<unsigned>(h))), dim3(256), 0, stream, A);
+  PNG_HIP(hipGetLastError());
   // ---- combine the partials on the host
   std::vector<unsigned long long> s1(static_cast<size_t>(h)), s2(static_cast<size_t>(h));
   std::vector<uint32_t> crc(n_acc);

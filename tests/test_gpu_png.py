@@ -59,7 +59,7 @@ def test_png_rows_longer_than_one_stored_block():
     _check(U.rand_image(411, 3, 16129))       # 64516 bytes: one byte over a block
 
 
-def test_png_more_rows_than_one_grid_slab():
+def test_png_more_rows_than_65535():
     _check(U.rand_image(412, 70000, 8))
 
 
