@@ -31,8 +31,8 @@ int parse(const uint8_t* f, int64_t n, Header* H, std::vector<uint8_t>* idat, st
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   if (!f || n < 8 + 25 + 12) return fail(IST_E_DECODE, "not a PNG file (too short)");
   if (std::memcmp(f, sig, 8) != 0) {
-    if (f[0] == 0xFF && f[1] == 0xD8) return fail(IST_E_UNSUPPORTED, "JPEG decode is not built (PNG inputs only)");
-    if (n >= 12 && !std::memcmp(f, "RIFF", 4) && !std::memcmp(f + 8, "WEBP", 4)) return fail(IST_E_UNSUPPORTED, "WebP decode is not built (PNG inputs only)");
+    if (f[0] == 0xFF && f[1] == 0xD8) return fail(IST_E_UNSUPPORTED, "this is a JPEG file: use ist_image_decode_rgba8");
+    if (n >= 12 && !std::memcmp(f, "RIFF", 4) && !std::memcmp(f + 8, "WEBP", 4)) return fail(IST_E_UNSUPPORTED, "WebP decode is not built (PNG, JPEG, BMP and GIF inputs are)");
     return fail(IST_E_DECODE, "not a PNG file");
   }
   int64_t pos = 8;

@@ -374,14 +374,21 @@ int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_
 }
 
 // format-agnostic front door: PNG (host decode) or JPEG (host entropy decode + GPU reconstruction)
+extern "C" int ist_misc_info(const uint8_t* file, int64_t len, int32_t* w, int32_t* h);
+extern "C" int ist_misc_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t pitch);
+static bool is_jpeg(const uint8_t* f, int64_t n) { return f && n >= 2 && f[0] == 0xFF && f[1] == 0xD8; }
+static bool is_misc(const uint8_t* f, int64_t n) { return f && n >= 4 && ((f[0] == 'B' && f[1] == 'M') || !std::memcmp(f, "GIF8", 4)); }
+
 int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation) {
-  if (file && len >= 2 && file[0] == 0xFF && file[1] == 0xD8) return ist_jpeg_info(file, len, width, height, orientation);
+  if (is_jpeg(file, len)) return ist_jpeg_info(file, len, width, height, orientation);
   if (orientation) *orientation = 0;
+  if (is_misc(file, len)) return ist_misc_info(file, len, width, height);
   return ist_png_info(file, len, width, height);
 }
 
 int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch) {
-  if (file && len >= 2 && file[0] == 0xFF && file[1] == 0xD8) return ist_jpeg_decode_rgba8(ctx, file, len, out, out_pitch);
+  if (is_jpeg(file, len)) return ist_jpeg_decode_rgba8(ctx, file, len, out, out_pitch);
+  if (is_misc(file, len)) return ist_misc_decode_rgba8(file, len, out, out_pitch);
   return ist_png_decode_rgba8(file, len, out, out_pitch);
 }
 
@@ -412,10 +419,10 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
       if (D.jpeg) {
         D.rc = jpeg_parse_and_entropy_decode(f, len, &D.J, false);
         D.w = D.J.width; D.h = D.J.height; D.orient = D.J.orientation;
-      } else {
-        int32_t w = 0, h = 0;
-        D.rc = ist_png_info(f, len, &w, &h);
-        if (D.rc == IST_OK) { D.w = w; D.h = h; D.px.resize(static_cast<size_t>(w) * h * 4); D.rc = ist_png_decode_rgba8(f, len, D.px.data(), static_cast<size_t>(w) * 4); }
+      } else {                 // PNG, BMP, GIF: host decoders
+        int32_t w = 0, h = 0, o = 0;
+        D.rc = ist_image_info(f, len, &w, &h, &o);
+        if (D.rc == IST_OK) { D.w = w; D.h = h; D.px.resize(static_cast<size_t>(w) * h * 4); D.rc = ist_image_decode_rgba8(nullptr, f, len, D.px.data(), static_cast<size_t>(w) * 4); }
       }
       if (D.rc != IST_OK) D.err = g_last_error;        // thread-local in the worker: carry it out
     });

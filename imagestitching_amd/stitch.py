@@ -246,10 +246,8 @@ def decode_image(data, device=0):
     buf = bytes(data)
     w, h, _ = image_info(buf)
     out = np.empty((h, w, 4), np.uint8)
-    if buf[:2] == b"\xff\xd8":
-        L.check(L.lib.ist_image_decode_rgba8(_ctx(device), buf, len(buf), out.ctypes.data, out.strides[0]))
-    else:
-        L.check(L.lib.ist_png_decode_rgba8(buf, len(buf), out.ctypes.data, out.strides[0]))
+    ctx = _ctx(device) if buf[:2] == b"\xff\xd8" else None          # only JPEG needs the GPU
+    L.check(L.lib.ist_image_decode_rgba8(ctx, buf, len(buf), out.ctypes.data, out.strides[0]))
     return out
 
 

@@ -86,7 +86,7 @@ class ShimImage {
     this._src = v;
     if (!v) { this._pixels = null; this.width = 0; this.height = 0; return; }     // `bmp.src = ''` releases (index.js:1569)
     let f = this._files[v];
-    if (!f && /\.(png|jpe?g)$/i.test(v)) {  // a real file on disk: decode it (the platform's Image.src does the same)
+    if (!f && /\.(png|jpe?g|bmp|gif)$/i.test(v)) {  // a real file on disk: decode it (the platform's Image.src does the same)
       try { f = this._files[v] = native.decodeImage(require('fs').readFileSync(v)); } catch (e) { f = null; }
     }
     setImmediate(() => {

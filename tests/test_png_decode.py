@@ -131,3 +131,49 @@ def test_jpeg_header_and_exif_orientation_on_cpu():
     b = io.BytesIO()
     Image.fromarray(RNG.integers(0, 256, (5, 7, 4), dtype=np.uint8), "RGBA").save(b, "PNG")
     assert ist.image_info(b.getvalue()) == (7, 5, 0)
+
+
+def _save(img, fmt, **kw):
+    b = io.BytesIO()
+    img.save(b, fmt, **kw)
+    return b.getvalue()
+
+
+def test_bmp_decode_matches_pil():
+    rgb = Image.fromarray(RNG.integers(0, 256, (19, 31, 3), dtype=np.uint8), "RGB")          # odd width: row padding
+    for img in (rgb, rgb.convert("L"), rgb.convert("P", palette=Image.ADAPTIVE, colors=16), rgb.convert("1"),
+                Image.fromarray(RNG.integers(0, 256, (7, 5, 4), dtype=np.uint8), "RGBA")):
+        data = _save(img, "BMP")
+        ref = np.asarray(Image.open(io.BytesIO(data)).convert("RGBA"))
+        got = ist.decode_image(data)
+        assert ist.image_info(data)[:2] == (img.width, img.height)
+        assert np.array_equal(got, ref), img.mode
+
+
+def test_gif_first_frame_matches_pil():
+    idx = RNG.integers(0, 200, (33, 47), dtype=np.uint8)
+    img = Image.fromarray(idx, "P")
+    img.putpalette(RNG.integers(0, 256, 768, dtype=np.uint8).tolist())
+    for kw in ({}, {"transparency": 7}, {"interlace": True}):
+        data = _save(img, "GIF", **kw)
+        ref = np.array(Image.open(io.BytesIO(data)).convert("RGBA"))
+        ref[ref[..., 3] == 0] = 0          # a canvas holds transparent pixels as (0,0,0,0); PIL keeps the palette colour
+        assert np.array_equal(ist.decode_image(data), ref), kw
+    # a smooth image (long LZW strings, code-size growth up to 12 bits, dictionary resets)
+    yy, xx = np.mgrid[0:300, 0:400]
+    big = Image.fromarray(((xx // 3 + yy // 5) % 256).astype(np.uint8), "P")
+    big.putpalette(list(range(256)) * 3)
+    data = _save(big, "GIF")
+    assert np.array_equal(ist.decode_image(data), np.asarray(Image.open(io.BytesIO(data)).convert("RGBA")))
+    noise = Image.fromarray(RNG.integers(0, 256, (120, 130), dtype=np.uint8), "P")
+    noise.putpalette(RNG.integers(0, 256, 768, dtype=np.uint8).tolist())
+    data = _save(noise, "GIF")
+    assert np.array_equal(ist.decode_image(data), np.asarray(Image.open(io.BytesIO(data)).convert("RGBA")))
+
+
+def test_webp_and_garbage_are_named():
+    with pytest.raises(ist.StitchError) as e:
+        ist.decode_image(b"RIFF\x00\x00\x00\x00WEBPVP8 " + b"\x00" * 64)
+    assert e.value.code == -7 and "WebP" in str(e.value)
+    with pytest.raises(ist.StitchError):
+        ist.decode_image(b"GIF89a" + b"\x00" * 3)
