@@ -27,6 +27,9 @@ int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, 
   const bool turned = (a == 0.0 && d == 0.0 && b != 0.0 && c != 0.0);
   std::memset(out, 0, sizeof(*out));
   out->image = -1;
+  // every later step (clip boxes, clamp boxes, the device's tap arithmetic) assumes finite numbers
+  for (int i = 0; i < 6; ++i) if (!std::isfinite(op.m[i])) return fail(IST_E_INVALID, "op transform is not finite");
+  for (int i = 0; i < 4; ++i) if (!std::isfinite(op.d[i]) || (op.kind == IST_OP_DRAW && !std::isfinite(op.s[i]))) return fail(IST_E_INVALID, "op rectangle is not finite");
   auto clip_box = [&](double xl, double xh, double yl, double yh, bool edge_aa) {
     // pixel-centre rule, or (edge AA) every pixel the rectangle touches + the sub-box it covers completely
     double X0 = std::ceil(xl - 0.5), X1 = std::ceil(xh - 0.5), Y0 = std::ceil(yl - 0.5), Y1 = std::ceil(yh - 0.5);
@@ -65,24 +68,28 @@ int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, 
   out->ox = sx - (eu / ku + rx) * gx;
   out->ky = gy / kv;
   out->oy = sy - (ev / kv + ry) * gy;
+  if (!std::isfinite(out->kx) || !std::isfinite(out->ky) || !std::isfinite(out->ox) || !std::isfinite(out->oy) || out->kx == 0.0 || out->ky == 0.0)
+    return fail(IST_E_INVALID, "op scale overflows");
   const double wa = ku * rx + eu, wb = ku * (rx + rw) + eu;
   const double za = kv * ry + ev, zb = kv * (ry + rh) + ev;
   const double wl = std::min(wa, wb), wh = std::max(wa, wb), zl = std::min(za, zb), zh = std::max(za, zb);
   const bool any = turned ? clip_box(zl, zh, wl, wh, aa) : clip_box(wl, wh, zl, zh, aa);
+  // clamp box = the source rectangle's pixels that exist in the bitmap (empty: the rectangle lies outside it)
   double t;
-  t = std::floor(sx);            out->cx0 = t < 0.0 ? 0 : static_cast<int32_t>(t);
-  t = std::ceil(sx + sw) - 1.0;  out->cx1 = t > img_w - 1 ? img_w - 1 : static_cast<int32_t>(t);
-  t = std::floor(sy);            out->cy0 = t < 0.0 ? 0 : static_cast<int32_t>(t);
-  t = std::ceil(sy + sh) - 1.0;  out->cy1 = t > img_h - 1 ? img_h - 1 : static_cast<int32_t>(t);
+  t = std::floor(sx);            if (t > img_w - 1) return 1;  out->cx0 = t < 0.0 ? 0 : static_cast<int32_t>(t);
+  t = std::ceil(sx + sw) - 1.0;  if (t < 0.0) return 1;        out->cx1 = t > img_w - 1 ? img_w - 1 : static_cast<int32_t>(t);
+  t = std::floor(sy);            if (t > img_h - 1) return 1;  out->cy0 = t < 0.0 ? 0 : static_cast<int32_t>(t);
+  t = std::ceil(sy + sh) - 1.0;  if (t < 0.0) return 1;        out->cy1 = t > img_h - 1 ? img_h - 1 : static_cast<int32_t>(t);
   if (out->cx1 < out->cx0 || out->cy1 < out->cy0) return 1;
   out->image = op.image;
   out->flags = turned ? OPF_SWAP : 0;
-  if (!turned && std::fabs(out->kx) == 1.0 && std::fabs(out->ky) == 1.0 && out->ox == std::floor(out->ox) && out->oy == std::floor(out->oy)) {
+  const bool small_off = std::fabs(out->ox) < 4.0e9 && std::fabs(out->oy) < 4.0e9;      // the fast paths hold offsets as integers
+  if (!turned && small_off && std::fabs(out->kx) == 1.0 && std::fabs(out->ky) == 1.0 && out->ox == std::floor(out->ox) && out->oy == std::floor(out->oy)) {
     out->flags |= OPF_IDENTITY;
     if (out->kx < 0.0) out->flags |= OPF_FLIPX;
     if (out->ky < 0.0) out->flags |= OPF_FLIPY;
   }
-  if (turned && std::fabs(out->kx) == 1.0 && std::fabs(out->ky) == 1.0 && out->ox == std::floor(out->ox) && out->oy == std::floor(out->oy))
+  if (turned && small_off && std::fabs(out->kx) == 1.0 && std::fabs(out->ky) == 1.0 && out->ox == std::floor(out->ox) && out->oy == std::floor(out->oy))
     out->flags |= OPF_UNIT_SWAP;
   return any ? 0 : 1;
 }
@@ -270,7 +277,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
           (bg_opaque || (out->ops[cell.op].flags & OPF_OPAQUE)) && !std::getenv("IST_NO_LDS")) {
         const DevOp& r = out->ops[cell.op];
         const double akx = std::fabs(r.kx), aky = std::fabs(r.ky);
-        if (r.cx1 > r.cx0 && r.cy1 > r.cy0) {
+        if (r.cx1 > r.cx0 && r.cy1 > r.cy0 && akx <= 128.0 && aky <= 128.0) {
           for (int th = 64; th >= 16; th >>= 1) {
             const int64_t fw = static_cast<int64_t>(std::floor((th - 1) * akx)) + 3;     // source columns (driven by canvas Y)
             const int64_t fh = static_cast<int64_t>(std::floor(63.0 * aky)) + 3;         // source rows (driven by canvas X)

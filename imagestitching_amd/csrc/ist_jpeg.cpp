@@ -35,13 +35,14 @@ struct Huff {
   int32_t mincode[17];
   // 9-bit lookahead: (length << 8) | symbol, 0 = not resolved
   uint16_t look[512];
-  void build() {
+  bool build() {                        // false: the code lengths over-subscribe the code space (a corrupt table)
     int code = 0, k = 0;
     for (int l = 1; l <= 16; ++l) {
       valptr[l] = k;
       mincode[l] = code;
       k += bits[l];
       code += bits[l];
+      if (code > (1 << l)) return false;
       maxcode[l] = bits[l] ? code - 1 : -1;
       code <<= 1;
     }
@@ -55,6 +56,7 @@ struct Huff {
       }
       code <<= 1;
     }
+    return true;
   }
 };
 
@@ -88,13 +90,12 @@ inline int decode_symbol(BitReader& br, const Huff& h) {
   if (e) { br.skip(e >> 8); return e & 0xFF; }
   int l = 10;
   int32_t code = static_cast<int32_t>(v >> 6);
-  while (l <= 16 && code > h.maxcode[l]) { ++l; code = static_cast<int32_t>(v >> (16 - l)); }
-  if (l > 16) return -1;
+  while (code > h.maxcode[l]) { if (++l > 16) return -1; code = static_cast<int32_t>(v >> (16 - l)); }
   br.skip(l);
-  return h.vals[h.valptr[l] + code - h.mincode[l]];
+  return h.vals[(h.valptr[l] + code - h.mincode[l]) & 255];
 }
 
-inline int extend(uint32_t v, int s) { return (v < (1u << (s - 1))) ? static_cast<int>(v) - (1 << s) + 1 : static_cast<int>(v); }
+inline int extend(uint32_t v, int s) { if (s <= 0) return 0; return (v < (1u << (s - 1))) ? static_cast<int>(v) - (1 << s) + 1 : static_cast<int>(v); }
 
 inline uint32_t be16(const uint8_t* p) { return (uint32_t(p[0]) << 8) | p[1]; }
 
@@ -158,7 +159,8 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
         for (int i = 1; i <= 16; ++i) { h.bits[i] = d[o + i]; cnt += h.bits[i]; }
         if (cnt > 256 || o + 17 + cnt > dl) return fail(IST_E_DECODE, "bad JPEG Huffman table");
         std::memcpy(h.vals, d + o + 17, static_cast<size_t>(cnt));
-        h.present = true; h.build();
+        h.present = true;
+        if (!h.build()) return fail(IST_E_DECODE, "bad JPEG Huffman table");
         o += 17 + cnt;
       }
     } else if (m == 0xDD) { if (dl >= 2) restart_interval = static_cast<int>(be16(d)); }

@@ -1,0 +1,56 @@
+"""Mutation fuzzing of the host-side file parsers under AddressSanitizer + UBSan (CPU build only; tools/run_fuzz.sh).
+A malformed PNG / JPEG / BMP / GIF must come back as an error code, never as a crash or an out-of-bounds access."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _seeds(d):
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:48, 0:64]
+    a = np.stack([(xx * 4) % 256, (yy * 5) % 256, ((xx + yy) * 3) % 256], -1)
+    a = (a + rng.integers(-20, 20, a.shape)).clip(0, 255).astype(np.uint8)
+    im = Image.fromarray(a, "RGB")
+    ex = Image.Exif()
+    ex[0x0112] = 6
+    todo = [("rgb.png", im, "PNG", {}), ("rgba.png", im.convert("RGBA"), "PNG", {}), ("pal.png", im.convert("P"), "PNG", {}),
+            ("g16.png", Image.fromarray(a[..., 0].astype(np.uint16) * 257), "PNG", {}),
+            ("444.jpg", im, "JPEG", {"subsampling": 0}), ("420.jpg", im, "JPEG", {"subsampling": 2, "quality": 70}),
+            ("422.jpg", im, "JPEG", {"subsampling": 1}), ("grey.jpg", im.convert("L"), "JPEG", {}),
+            ("rst.jpg", im, "JPEG", {"restart_marker_blocks": 2}), ("exif.jpg", im, "JPEG", {"exif": ex}),
+            ("24.bmp", im, "BMP", {}), ("8.bmp", im.convert("P"), "BMP", {}), ("1.bmp", im.convert("1"), "BMP", {}),
+            ("a.gif", im.convert("P"), "GIF", {}), ("i.gif", im.convert("P"), "GIF", {"interlace": True}),
+            ("t.gif", im.convert("P"), "GIF", {"transparency": 3})]
+    out = []
+    for name, img, fmt, kw in todo:
+        p = os.path.join(d, name)
+        img.save(p, fmt, **kw)
+        out.append(p)
+    return out
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++ for the sanitizer build")
+def test_decoders_survive_mutated_files(tmp_path):
+    seeds = _seeds(str(tmp_path))
+    env = dict(os.environ, IST_FUZZ_BIN=str(tmp_path / "fuzz"))
+    r = subprocess.run([os.path.join(ROOT, "tools", "run_fuzz.sh"), "400"] + seeds, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "0 crashes" in r.stdout
+    decoded = int(r.stdout.split("fuzz:")[1].split("decoded")[0])
+    assert decoded >= len(seeds)          # every unmutated seed decodes
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++ for the sanitizer build")
+def test_compiler_invariants_under_hostile_op_lists(tmp_path):
+    """tools/fuzz_compile.cpp: NaN / infinite / huge transforms and rectangles, hostile caps through the planner; the
+    clamp boxes, cells, bands and LDS sizes the kernel trusts must stay in range (or the list is refused)."""
+    env = dict(os.environ, IST_FUZZ_BIN=str(tmp_path / "fuzzc"))
+    r = subprocess.run([os.path.join(ROOT, "tools", "run_fuzz.sh"), "compile", "16000"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("all invariants hold") == 2
