@@ -111,6 +111,30 @@ def run_single(args):
         del sets, outs, job
         torch.cuda.empty_cache()
     head = results["uniform_vertical"]
+    # yardstick: the runtime's own device-to-device copy (torch copy_ = hipMemcpyDtoD kernel) of the same number of
+    # bytes, on the same box in the same process: what a plain copy reaches next to the stitch kernel
+    yard = None
+    try:
+        nbytes = head["algorithmic_bytes"] // 2
+        a = [torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 256) for _ in range(2)]
+        b = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        for i in range(5):
+            b[i % 2].copy_(a[i % 2])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        e0.record()
+        for i in range(reps):
+            b[i % 2].copy_(a[i % 2])
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        yard = {"us": round(us, 2), "GBs": round(2 * nbytes / (us * 1e-6) / 1e9, 1), "frac": round(2 * nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "what": "torch Tensor.copy_ device-to-device, %d bytes read + as many written" % nbytes}
+        del a, b
+        torch.cuda.empty_cache()
+    except Exception as ex:       # informational only
+        yard = {"error": repr(ex)}
     cpu = None if args.no_cpu else cpu_baseline()
     # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE
     # doubled per MI355X_MICROARCH.md): collected by profiles/summarize.py, committed as profiles/r01_pmc.json
@@ -134,6 +158,7 @@ def run_single(args):
                      "kernel": "ist_stitch_kernel", "kernel_us": round(head["kernel_us"], 2),
                      "algorithmic_bytes_per_launch": head["algorithmic_bytes"]},
         "cpu_baseline": cpu,
+        "d2d_copy_yardstick": yard,
         "extra": {k: {"MPs": round(v["MPs"], 1), "kernel_us": round(v["kernel_us"], 2), "GBs": round(v["GBs"], 1),
                       "frac": round(v["GBs"] / HBM_PEAK_GBS, 4), "canvas": v["canvas"], "tiles": v["tiles"]}
                   for k, v in results.items()},

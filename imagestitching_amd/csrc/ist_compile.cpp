@@ -119,6 +119,7 @@ static int64_t distinct_taps(double k, double o, int lo, int hi, int clo, int ch
 
 // FILL / COPY tile shape.  IST_COPY_TILE=WxH is a tuning knob for benchmarks (W = 256, 512, 1024, ...).
 static int g_tile_w = 256, g_tile_h = 8;      // measured optimum on MI355X: ~64 KB of loads in flight per CU
+static const int g_lds_run = 2;                    // pipeline stages per workgroup on the SAMPLE_LDS path
 static const int64_t g_lds_budget_words = 6144;    // 24 KiB footprint budget per workgroup: measured optimum (IST_LDS_BUDGET bytes overrides)
 static void read_tile_knob() {
   const char* e = std::getenv("IST_COPY_TILE");
@@ -136,8 +137,8 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
   if (filter != IST_FILTER_NEAREST && filter != IST_FILTER_BILINEAR) return fail(IST_E_INVALID, "unknown filter");
   read_tile_knob();
   out->canvas_w = canvas_w; out->canvas_h = canvas_h; out->filter = filter | (aa ? IST_FILTER_EDGE_AA : 0);
-  out->ops.clear(); out->cells.clear(); out->stacks.clear(); out->bands.clear();
-  out->lds_words = 0;
+  out->ops.clear(); out->cells.clear(); out->stacks.clear(); out->bands.clear(); out->tiles.clear();
+  out->lds_words = 0; out->lds_half = 0;
   out->img_w.assign(static_cast<size_t>(n_images), 0);
   out->img_h.assign(static_cast<size_t>(n_images), 0);
   for (int i = 0; i < n_images; ++i) {
@@ -305,8 +306,11 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
           if (wl * fh <= budget) { th = t; need = wl * fh; break; }
         }
         if (th) {
-          cell.path = PATH_SAMPLE_LDS; cell.tile_w = 256; cell.tile_h = th;
-          out->lds_words = std::max<int32_t>(out->lds_words, static_cast<int32_t>(need));
+          // a workgroup walks `run` stages down its 256-pixel column (see tile_sample_lds)
+          const int run = std::getenv("IST_LDS_RUN") ? std::min(16, std::max(1, std::atoi(std::getenv("IST_LDS_RUN")))) : g_lds_run;
+          cell.path = PATH_SAMPLE_LDS; cell.tile_w = 256; cell.sub_h = th; cell.tile_h = th * run;
+          out->lds_half = std::max<int32_t>(out->lds_half, static_cast<int32_t>(need));
+          out->lds_words = std::max<int32_t>(out->lds_words, out->lds_half);
         }
       }
     }
@@ -352,6 +356,22 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     }
   }
   if (tiles > 2147483647LL) return fail(IST_E_OUTPUT_SIZE, "canvas needs more than 2^31 tiles");
+  // the table pays when tiles have a long set-up (resample paths: -3..5 % measured); pure fill/copy jobs keep the
+  // prefix search, whose few cache lines stay hot in the scalar cache (a per-tile entry is a cold miss: +3 % measured)
+  const bool resamples = info.tiles_sample + info.tiles_general > 0;
+  if (resamples && tiles <= kMaxTileTable && !std::getenv("IST_NO_TILE_TABLE")) {
+    out->tiles.reserve(static_cast<size_t>(tiles));
+    for (const DevBand& b : out->bands) {
+      const DevCell& f = out->cells[b.first_cell];
+      const int32_t rows = (f.Y1 - f.Y0 + f.tile_h - 1) / f.tile_h;
+      for (int32_t tr = 0; tr < rows; ++tr)
+        for (int32_t k = 0; k < b.n_cells; ++k) {
+          const DevCell& c = out->cells[b.first_cell + k];
+          for (int32_t tc = 0; tc < c.tiles_x; ++tc)
+            out->tiles.push_back(DevTile{b.first_cell + k, c.op, c.X0 + tc * c.tile_w, c.Y0 + tr * c.tile_h});
+        }
+    }
+  }
   info.canvas_w = canvas_w; info.canvas_h = canvas_h;
   info.n_ops = n; info.n_cells = static_cast<int32_t>(out->cells.size());
   info.n_tiles = tiles;

@@ -62,6 +62,7 @@ struct alignas(16) DevCell {
   int32_t tile_w, tile_h;
   int32_t tiles_x;
   int32_t band_x;           // tiles of this band's earlier cells in one tile row (prefix of tiles_x inside the band)
+  int32_t sub_h;            // SAMPLE_LDS: rows per pipeline stage (tile_h = sub_h * stages); 0 otherwise
   int64_t tile_begin;       // host-side bookkeeping
 };
 
@@ -75,14 +76,22 @@ struct alignas(16) DevBand {
   int32_t pad[3];
 };
 
+// One entry per tile, in launch order: what a workgroup needs to start (one 16-byte scalar load instead of two binary
+// searches over the band / cell prefix tables).  Built for jobs that resample and have at most kMaxTileTable tiles;
+// fill/copy-only jobs and gigapixel canvases search the prefix tables instead.
+struct alignas(16) DevTile { int32_t cell, op, X0, Y0; };
+constexpr int64_t kMaxTileTable = 4 << 20;
+
 struct Compiled {
   int64_t canvas_w = 0, canvas_h = 0;
   int64_t rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;   // rendered region (the clip, or the whole canvas)
   int filter = IST_FILTER_BILINEAR;
-  int32_t lds_words = 0;               // LDS footprint buffer the SAMPLE_LDS cells need (32-bit words)
+  int32_t lds_words = 0;               // dynamic LDS per workgroup (32-bit words): max(SWAP_LDS patch, lds_half)
+  int32_t lds_half = 0;                // the SAMPLE_LDS footprint buffer (the largest footprint any stage needs)
   std::vector<DevOp> ops;
   std::vector<DevCell> cells;
   std::vector<DevBand> bands;
+  std::vector<DevTile> tiles;          // empty when the job has more than kMaxTileTable tiles
   std::vector<int32_t> stacks;
   std::vector<int32_t> img_w, img_h;   // bitmap sizes per image (for launch-time validation)
   ist_job_info info{};

@@ -59,24 +59,46 @@ IST_DEV uint32_t over_int(uint32_t s, uint32_t d) {
 
 IST_DEV float lerpf(float a, float b, float t) { return __fmaf_rn(t, b - a, a); }
 
-IST_DEV uint32_t to_u8(float v) {
-  v = floorf(v + 0.5f);
-  v = fminf(fmaxf(v, 0.0f), 255.0f);
-  return static_cast<uint32_t>(v);
+// round half up to a byte.  Every caller's v lies in [0, 255] (blends of bytes with weights in [0, 1]), where
+// floor(v + 0.5) clamped to [0, 255] — what the oracle writes — equals the truncating, saturating conversion of v + 0.5
+IST_DEV uint32_t to_u8(float v) { return static_cast<uint32_t>(v + 0.5f); }
+
+// Four opaque pixels of one lane at once, two channels per instruction: the packed fp32 ALU (v_pk_add_f32 /
+// v_pk_fma_f32) does the same IEEE operations in the same order as lerpf on each half, so the bytes do not change.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+IST_DEV f32x2 lerp2(f32x2 a, f32x2 b, f32x2 t) { return __builtin_elementwise_fma(t, b - a, a); }
+// (the empty asm keeps the compiler from rewriting float(b) - float(a) as float(b - a): exact either way, but the
+// integer form needs a scalar subtract + a second conversion per channel where the float form is half a v_pk_add_f32)
+IST_DEV f32x2 chan2(uint32_t p, uint32_t q, int c) { f32x2 r; r.x = static_cast<float>(ch(p, c)); r.y = static_cast<float>(ch(q, c)); asm("" : "+v"(r)); return r; }
+IST_DEV f32x2 rg(uint32_t p) { f32x2 r; r.x = static_cast<float>(ch(p, 0)); r.y = static_cast<float>(ch(p, 1)); asm("" : "+v"(r)); return r; }
+IST_DEV void bilerp4_opaque(const uint32_t p00[4], const uint32_t p01[4], const uint32_t p10[4], const uint32_t p11[4],
+                            const float tx[4], float ty, uint32_t o[4]) {
+  const f32x2 ty2 = {ty, ty}, half = {0.5f, 0.5f};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {                   // red + green of pixel p
+    const f32x2 t = {tx[p], tx[p]};
+    const f32x2 v = lerp2(lerp2(rg(p00[p]), rg(p01[p]), t), lerp2(rg(p10[p]), rg(p11[p]), t), ty2) + half;
+    o[p] = 0xFF000000u | static_cast<uint32_t>(v.x) | (static_cast<uint32_t>(v.y) << 8);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; p += 2) {                // blue of pixels p and p + 1
+    const f32x2 t = {tx[p], tx[p + 1]};
+    const f32x2 v = lerp2(lerp2(chan2(p00[p], p00[p + 1], 2), chan2(p01[p], p01[p + 1], 2), t),
+                          lerp2(chan2(p10[p], p10[p + 1], 2), chan2(p11[p], p11[p + 1], 2), t), ty2) + half;
+    o[p] |= static_cast<uint32_t>(v.x) << 16;
+    o[p + 1] |= static_cast<uint32_t>(v.y) << 16;
+  }
 }
 
 // bilinear blend of four straight-alpha taps, composited over a premultiplied destination pixel
 // `opaque` (wave-uniform, the caller's hint for JPEG-decoded bitmaps) skips the per-pixel alpha test
 IST_DEV uint32_t bilerp_over(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, float tx, float ty, uint32_t d, bool opaque = false) {
   if (opaque || ((p00 & p01 & p10 & p11) >> 24) == 255u) {   // all taps opaque: plain bilinear, result replaces the destination
-    uint32_t o = 0xFF000000u;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float top = lerpf(static_cast<float>(ch(p00, c)), static_cast<float>(ch(p01, c)), tx);
-      const float bot = lerpf(static_cast<float>(ch(p10, c)), static_cast<float>(ch(p11, c)), tx);
-      o |= to_u8(lerpf(top, bot, ty)) << (8 * c);
-    }
-    return o;
+    const f32x2 t2 = {tx, tx}, ty2 = {ty, ty}, half = {0.5f, 0.5f};
+    const f32x2 v = lerp2(lerp2(rg(p00), rg(p01), t2), lerp2(rg(p10), rg(p11), t2), ty2) + half;       // red, green
+    const float top = lerpf(static_cast<float>(ch(p00, 2)), static_cast<float>(ch(p01, 2)), tx);
+    const float bot = lerpf(static_cast<float>(ch(p10, 2)), static_cast<float>(ch(p11, 2)), tx);
+    return 0xFF000000u | static_cast<uint32_t>(v.x) | (static_cast<uint32_t>(v.y) << 8) | (to_u8(lerpf(top, bot, ty)) << 16);
   }
   const float a00 = static_cast<float>(p00 >> 24), a01 = static_cast<float>(p01 >> 24);
   const float a10 = static_cast<float>(p10 >> 24), a11 = static_cast<float>(p11 >> 24);
@@ -246,18 +268,24 @@ IST_DEV void tile_sample(const LaunchArgs& A, const DevOp op, uint32_t bg, int X
     const Tap ty = bilinear_tap(op.ky, op.oy, Y, op.cy0, op.cy1);
     const uint8_t* r0 = src + static_cast<size_t>(ty.base) * sp;
     const uint8_t* r1 = r0 + row_step;
-    uint32_t o[4];
+    uint32_t o[4], p00[4], p01[4], p10[4], p11[4], all = 0xFFFFFFFFu;
+    float wx[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      uint32_t p00, p01, p10, p11;
       const size_t off = 4 * static_cast<size_t>(tx[p].base);
       if (pair_x) {
         const u32x2 a = ld8(r0 + off), b = ld8(r1 + off);
-        p00 = a.x; p01 = a.y; p10 = b.x; p11 = b.y;
+        p00[p] = a.x; p01[p] = a.y; p10[p] = b.x; p11[p] = b.y;
       } else {
-        p00 = p01 = ld4(r0 + off); p10 = p11 = ld4(r1 + off);
+        p00[p] = p01[p] = ld4(r0 + off); p10[p] = p11[p] = ld4(r1 + off);
       }
-      o[p] = bilerp_over(p00, p01, p10, p11, tx[p].t, ty.t, bg, (op.flags & OPF_OPAQUE) != 0);
+      wx[p] = tx[p].t;
+      all &= p00[p] & p01[p] & p10[p] & p11[p];
+    }
+    if ((op.flags & OPF_OPAQUE) || (all >> 24) == 255u) bilerp4_opaque(p00, p01, p10, p11, wx, ty.t, o);
+    else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) o[p] = bilerp_over(p00[p], p01[p], p10[p], p11[p], wx[p], ty.t, bg, false);
     }
     uint8_t* dp = d + static_cast<size_t>(Y) * A.dst_pitch;
     if (nv >= 4) { const u32x4 v = {o[0], o[1], o[2], o[3]}; st16(dp, v); }
@@ -289,83 +317,118 @@ IST_DEV Tap row_tap(const RowTaps& r, int j) {
 // memory path ONCE, as coalesced 16-B loads (the direct path above issues 8-byte gathers whose lanes straddle ~3x
 // as many cache lines), and the 16 taps per lane then come from LDS (ds_read2_b32).  The host sizes tile_h so that
 // the footprint fits kLdsWords; the kernel re-checks and falls back to the direct path if it ever does not.
-// The footprint buffer is dynamic LDS sized by the host (LaunchArgs.lds_words = the largest footprint any cell needs).
+// The footprint buffer is dynamic LDS sized by the host (LaunchArgs.lds_half words = the largest footprint any stage
+// of any cell needs).
 
-IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int X0, int Y0, int X1, int Y1, uint32_t* lds) {
+IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int X0, int Y0, int X1, int Y1, int sub_h, uint32_t* lds) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  // footprint of the tile (wave-uniform): the taps are monotonic in X and in Y, so the corners bound it
+  // The tile is a column of stages of sub_h rows, each loaded (LDS-DMA, no VGPRs) and then resampled: the per-tile
+  // set-up (tile look-up, op fetch, the fp64 column taps) is paid once per column instead of once per stage.
+  // Measured on MI355X (tools/exp_mixed.py): 2 stages per workgroup beat 1 by ~4 %; more stages leave too few
+  // workgroups for the tail; a double-buffered variant (stage s+1 loading under stage s's arithmetic) lost 10-20 %
+  // because the second buffer halves the workgroups per CU.
+  // x footprint (wave-uniform, shared by all stages): the taps are monotonic in X, so the tile's corners bound it
   const Tap xa = bilinear_tap(op.kx, op.ox, X0, op.cx0, op.cx1), xb = bilinear_tap(op.kx, op.ox, X1 - 1, op.cx0, op.cx1);
-  const Tap ya = bilinear_tap(op.ky, op.oy, Y0, op.cy0, op.cy1), yb = bilinear_tap(op.ky, op.oy, Y1 - 1, op.cy0, op.cy1);
   const int fx0 = __builtin_amdgcn_readfirstlane(min(xa.base, xb.base)), fx1 = __builtin_amdgcn_readfirstlane(max(xa.base, xb.base) + 1);
-  const int fy0 = __builtin_amdgcn_readfirstlane(min(ya.base, yb.base)), fy1 = __builtin_amdgcn_readfirstlane(max(ya.base, yb.base) + 1);
-  const int fh = fy1 - fy0 + 1;
   const int wl = (fx1 - fx0 + 4) & ~3;            // LDS row stride in pixels (multiple of 4: 16-B aligned rows)
-  if (wl * fh > A.lds_words || op.cx1 <= op.cx0 || op.cy1 <= op.cy0) {   // uniform; not expected (host sizes the tile)
+  const int nsub = (Y1 - Y0 + sub_h - 1) / sub_h;
+  // y footprint of stage s: first source row + row count (wave-uniform)
+  auto foot = [&](int s, int* fy0, int* fh) {
+    const int Ya = Y0 + s * sub_h, Yb = min(Ya + sub_h, Y1);
+    const Tap ya = bilinear_tap(op.ky, op.oy, Ya, op.cy0, op.cy1), yb = bilinear_tap(op.ky, op.oy, Yb - 1, op.cy0, op.cy1);
+    const int lo = __builtin_amdgcn_readfirstlane(min(ya.base, yb.base)), hi = __builtin_amdgcn_readfirstlane(max(ya.base, yb.base) + 1);
+    *fy0 = lo; *fh = hi - lo + 1;
+  };
+  bool fits = sub_h > 0 && op.cx1 > op.cx0 && op.cy1 > op.cy0;
+  for (int s = 0; s < nsub && fits; ++s) { int y, h; foot(s, &y, &h); fits = wl * h <= A.lds_half; }
+  if (!fits) {                                    // uniform; not expected (the host sizes the stages)
     tile_sample<IST_FILTER_BILINEAR>(A, op, bg, X0, Y0, X1, Y1);
     return;
   }
   const size_t sp = A.pitch[op.image];
   const uint8_t* src = A.src[op.image];
-  __syncthreads();                                // a previous tile of this workgroup may still be reading the LDS
   // ---- stage: wave w takes footprint rows w, w+4, ...; a pass moves 64 lanes x 16 B = 256 px of one row.
   // LDS-DMA (global_load_lds_dwordx4): per-lane global address, LDS destination = uniform base + lane*16, no VGPR
-  // staging, so every pass of the wave is in flight at once; one vmcnt(0) + barrier at the end.
+  // staging, so every pass of the wave is in flight at once.
   const int chunks = wl >> 2;
-  for (int r = wave; r < fh; r += 4) {
-    const uint8_t* grow = src + static_cast<size_t>(fy0 + r) * sp;
-    uint32_t* lrow = lds + r * wl;
-    // reading up to 12 B past the last sampled column is harmless (next row of the same bitmap) except on the last
-    // sampled row, where it could leave the allocation: that row's edge pass goes through registers instead
-    const bool last_row = (fy0 + r) >= op.cy1;
-    for (int c0 = 0; c0 < chunks; c0 += 64) {
-      const int c = c0 + lane;
-      const int col = fx0 + 4 * c;
-      const bool edge = last_row && (fx0 + 4 * min(c0 + 63, chunks - 1) + 3 > op.cx1);    // wave-uniform
-      if (!edge) {
-        if (c < chunks)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t*)(grow + static_cast<size_t>(col) * 4),
-                                           (__attribute__((address_space(3))) uint32_t*)(lrow + 4 * c0), 16, 0, 0);
-      } else if (c < chunks) {
-        u32x4 v;
-        if (col + 3 <= op.cx1) v = ld16(grow + static_cast<size_t>(col) * 4);
-        else {
-          v.x = ld4(grow + static_cast<size_t>(min(col, op.cx1)) * 4);
-          v.y = ld4(grow + static_cast<size_t>(min(col + 1, op.cx1)) * 4);
-          v.z = ld4(grow + static_cast<size_t>(min(col + 2, op.cx1)) * 4);
-          v.w = ld4(grow + static_cast<size_t>(min(col + 3, op.cx1)) * 4);
+  auto stage = [&](int fy0, int fh, uint32_t* buf) {
+    for (int r = wave; r < fh; r += 4) {
+      const uint8_t* grow = src + static_cast<size_t>(fy0 + r) * sp;
+      uint32_t* lrow = buf + r * wl;
+      // reading up to 12 B past the last sampled column is harmless (next row of the same bitmap) except on the last
+      // sampled row, where it could leave the allocation: that row's edge pass goes through registers instead
+      const bool last_row = (fy0 + r) >= op.cy1;
+      for (int c0 = 0; c0 < chunks; c0 += 64) {
+        const int c = c0 + lane;
+        const int col = fx0 + 4 * c;
+        const bool edge = last_row && (fx0 + 4 * min(c0 + 63, chunks - 1) + 3 > op.cx1);    // wave-uniform
+        if (!edge) {
+          if (c < chunks)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t*)(grow + static_cast<size_t>(col) * 4),
+                                             (__attribute__((address_space(3))) uint32_t*)(lrow + 4 * c0), 16, 0, 0);
+        } else if (c < chunks) {
+          u32x4 v;
+          if (col + 3 <= op.cx1) v = ld16(grow + static_cast<size_t>(col) * 4);
+          else {
+            v.x = ld4(grow + static_cast<size_t>(min(col, op.cx1)) * 4);
+            v.y = ld4(grow + static_cast<size_t>(min(col + 1, op.cx1)) * 4);
+            v.z = ld4(grow + static_cast<size_t>(min(col + 2, op.cx1)) * 4);
+            v.w = ld4(grow + static_cast<size_t>(min(col + 3, op.cx1)) * 4);
+          }
+          *reinterpret_cast<u32x4*>(lrow + 4 * c) = v;
         }
-        *reinterpret_cast<u32x4*>(lrow + 4 * c) = v;
       }
     }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA is tracked by vmcnt only
-  __syncthreads();
-  // ---- resample from LDS.  Lane l owns pixels X0 + l + 64 p (p = 0..3), NOT 4 neighbours: consecutive lanes then read
-  // LDS words |kx| apart instead of 4|kx| apart (measured: 77 % of the LDS cycles were bank conflicts with the
-  // neighbour mapping), and each of the 4 stores of a wave is still 256 contiguous bytes.
-  const RowTaps rows = row_taps(op.ky, op.oy, Y0, Y1, op.cy0, op.cy1);   // all 64 lanes still active here (readlane source)
+  };
+  // Lane l owns pixels X0 + l + 64 p (p = 0..3), NOT 4 neighbours: consecutive lanes then read LDS words |kx| apart
+  // instead of 4|kx| apart (measured: 77 % of the LDS cycles were bank conflicts with the neighbour mapping), and each
+  // of the 4 stores of a wave is still 256 contiguous bytes.  Lanes past a ragged right edge keep computing (on the
+  // last column) and only skip their stores: the row taps below are exchanged with v_readlane and the barriers of
+  // later stages need every wave.
   const int Xl = X0 + lane;
-  if (Xl >= X1) return;
   int lx[4]; float wx[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const Tap t = bilinear_tap(op.kx, op.ox, min(Xl + 64 * p, X1 - 1), op.cx0, op.cx1);   // columns past the edge reuse the last one
+    const Tap t = bilinear_tap(op.kx, op.ox, min(Xl + 64 * p, X1 - 1), op.cx0, op.cx1);
     lx[p] = t.base - fx0; wx[p] = t.t;
   }
   uint8_t* d = A.dst + static_cast<size_t>(Xl) * 4;
   const bool opaque = (op.flags & OPF_OPAQUE) != 0;
-  for (int Y = Y0 + wave; Y < Y1; Y += 4) {
-    const Tap ty = row_tap(rows, Y - Y0);
-    const uint32_t* r0 = lds + (ty.base - fy0) * wl;
-    const uint32_t* r1 = r0 + wl;
-    uint32_t o[4];
+  int fy0, fh;
+  foot(0, &fy0, &fh);
+  for (int s = 0; s < nsub; ++s) {
+    __syncthreads();                                      // every wave is done reading the previous stage (or tile)
+    stage(fy0, fh, lds);
+    int ny0 = 0, nh = 0;
+    if (s + 1 < nsub) foot(s + 1, &ny0, &nh);             // (tap arithmetic under the loads)
+    const int Ya = Y0 + s * sub_h, Yb = min(Ya + sub_h, Y1);
+    const RowTaps rows = row_taps(op.ky, op.oy, Ya, Yb, op.cy0, op.cy1);   // all 64 lanes active (readlane source)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA is tracked by vmcnt only
+    __syncthreads();
+    const uint32_t* buf = lds;
+    for (int Y = Ya + wave; Y < Yb; Y += 4) {
+      const Tap ty = row_tap(rows, Y - Ya);
+      const uint32_t* r0 = buf + (ty.base - fy0) * wl;
+      const uint32_t* r1 = r0 + wl;
+      uint32_t o[4];
+      uint32_t p00[4], p01[4], p10[4], p11[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) o[p] = bilerp_over(r0[lx[p]], r0[lx[p] + 1], r1[lx[p]], r1[lx[p] + 1], wx[p], ty.t, bg, opaque);
-    uint8_t* dp = d + static_cast<size_t>(Y) * A.dst_pitch;
+      for (int p = 0; p < 4; ++p) { p00[p] = r0[lx[p]]; p01[p] = r0[lx[p] + 1]; p10[p] = r1[lx[p]]; p11[p] = r1[lx[p] + 1]; }
+      uint32_t all = 0xFFFFFFFFu;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      if (Xl + 64 * p < X1) st4(dp + 256 * p, o[p]);
+      for (int p = 0; p < 4; ++p) all &= p00[p] & p01[p] & p10[p] & p11[p];
+      if (opaque || (all >> 24) == 255u) bilerp4_opaque(p00, p01, p10, p11, wx, ty.t, o);
+      else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[p] = bilerp_over(p00[p], p01[p], p10[p], p11[p], wx[p], ty.t, bg, false);
+      }
+      uint8_t* dp = d + static_cast<size_t>(Y) * A.dst_pitch;
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (Xl + 64 * p < X1) st4(dp + 256 * p, o[p]);
+    }
+    fy0 = ny0; fh = nh;
   }
 }
 
@@ -542,28 +605,38 @@ enum : int { HAS_FILL = 1, HAS_COPY = 2, HAS_SAMPLE = 4, HAS_GENERAL = 8 };
 
 template <int PATHS, int V>
 IST_DEV void run_tile(const LaunchArgs& A, int64_t tile) {
-  // bands and cells are few (tens): binary search on the tile prefix with wave-uniform (scalar) loads
-  int lo = 0, hi = A.n_bands - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (A.bands[mid].tile_begin <= tile) lo = mid; else hi = mid - 1;
+  int ci, oi, X0, Y0;
+  if (A.tiles) {                       // one 16-byte scalar load; the cell and the op are then fetched side by side
+    const DevTile t = A.tiles[tile];
+    ci = t.cell; oi = t.op; X0 = t.X0; Y0 = t.Y0;
+  } else {
+    // gigapixel jobs: binary search on the tile prefixes of the bands, then of the band's cells (wave-uniform loads)
+    int lo = 0, hi = A.n_bands - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (A.bands[mid].tile_begin <= tile) lo = mid; else hi = mid - 1;
+    }
+    const DevBand b = A.bands[lo];
+    const int local = static_cast<int>(tile - b.tile_begin);
+    const int trow = local / b.tiles_per_row, rem = local - trow * b.tiles_per_row;
+    lo = b.first_cell; hi = b.first_cell + b.n_cells - 1;
+    while (lo < hi) {                      // the cell of this band that holds tile column `rem`
+      const int mid = (lo + hi + 1) >> 1;
+      if (A.cells[mid].band_x <= rem) lo = mid; else hi = mid - 1;
+    }
+    ci = lo;
+    const DevCell c0 = A.cells[lo];
+    oi = c0.op;
+    X0 = c0.X0 + (rem - c0.band_x) * c0.tile_w; Y0 = c0.Y0 + trow * c0.tile_h;
   }
-  const DevBand b = A.bands[lo];
-  const int local = static_cast<int>(tile - b.tile_begin);
-  const int trow = local / b.tiles_per_row, rem = local - trow * b.tiles_per_row;
-  lo = b.first_cell; hi = b.first_cell + b.n_cells - 1;
-  while (lo < hi) {                      // the cell of this band that holds tile column `rem`
-    const int mid = (lo + hi + 1) >> 1;
-    if (A.cells[mid].band_x <= rem) lo = mid; else hi = mid - 1;
-  }
-  const DevCell c = A.cells[lo];       // by value: scalar loads once; a reference would be re-read after every store
-  const int tcol = rem - c.band_x;
-  const int X0 = c.X0 + tcol * c.tile_w, Y0 = c.Y0 + trow * c.tile_h;
+  const DevCell c = A.cells[ci];       // by value: scalar loads once; a reference would be re-read after every store
+  DevOp op_;                           // fetched together with the cell (both indices come from the tile entry)
+  if (oi >= 0) op_ = A.ops[oi]; else __builtin_memset(&op_, 0, sizeof(op_));
   const int X1 = min(X0 + c.tile_w, c.X1), Y1 = min(Y0 + c.tile_h, c.Y1);
   const int lg = 31 - __builtin_clz(c.tile_w >> 8);
   const int path = c.path;
   if ((PATHS & HAS_COPY) && path == PATH_COPY) {
-    const DevOp op = A.ops[c.op];
+    const DevOp op = op_;
     // V = 0 is what ships; 1..3 are kept as measured alternatives for tools/sweep_variants.py (IST_TUNING=1)
     if (V == 0) tile_copy<2, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);        // 256x8 tile: 2 rows per wave in flight
     else if (V == 1) tile_copy<8, true, true, true>(A, op, c.bg, lg, X0, Y0, X1, Y1);   // 8 rows per wave in flight
@@ -573,13 +646,13 @@ IST_DEV void run_tile(const LaunchArgs& A, int64_t tile) {
     tile_fill(A, c.bg, lg, X0, Y0, X1, Y1);
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE_LDS) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    tile_sample_lds(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1, lds);
+    tile_sample_lds(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds);
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SWAP_LDS) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    if (!tile_swap_lds(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1, lds)) tile_general(A, c, X0, Y0, X1, Y1);
+    if (!tile_swap_lds(A, op_, c.bg, X0, Y0, X1, Y1, lds)) tile_general(A, c, X0, Y0, X1, Y1);
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE) {
-    if ((A.filter & 0xFF) == IST_FILTER_NEAREST) tile_sample<IST_FILTER_NEAREST>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);
-    else tile_sample<IST_FILTER_BILINEAR>(A, A.ops[c.op], c.bg, X0, Y0, X1, Y1);
+    if ((A.filter & 0xFF) == IST_FILTER_NEAREST) tile_sample<IST_FILTER_NEAREST>(A, op_, c.bg, X0, Y0, X1, Y1);
+    else tile_sample<IST_FILTER_BILINEAR>(A, op_, c.bg, X0, Y0, X1, Y1);
   } else if (PATHS & HAS_GENERAL) {
     tile_general(A, c, X0, Y0, X1, Y1);
   }

@@ -18,10 +18,13 @@ struct LaunchArgs {
   const DevCell* cells;
   const DevBand* bands;
   const int32_t* stacks;
+  const DevTile* tiles;     // per-tile table, or NULL (then the band / cell prefixes are searched)
   int32_t n_cells;
   int32_t filter;
   int32_t lds_words;        // dynamic LDS the SAMPLE_LDS cells need (32-bit words); 0 when the job has none
   int32_t n_bands;
+  int32_t lds_half;         // SAMPLE_LDS footprint buffer (32-bit words)
+  int32_t pad_;
   const uint8_t* src[kMaxImages];
   size_t pitch[kMaxImages];
 };

@@ -39,6 +39,7 @@ struct ist_job {
   DevCell* d_cells = nullptr;
   DevBand* d_bands = nullptr;
   int32_t* d_stacks = nullptr;
+  DevTile* d_tiles = nullptr;
   int max_image = -1;
 };
 
@@ -140,7 +141,8 @@ ist_job* ist_job_create(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const 
   const bool ok = upload(reinterpret_cast<void**>(&job->d_ops), h.ops.data(), h.ops.size() * sizeof(DevOp)) &&
                   upload(reinterpret_cast<void**>(&job->d_cells), h.cells.data(), h.cells.size() * sizeof(DevCell)) &&
                   upload(reinterpret_cast<void**>(&job->d_bands), h.bands.data(), h.bands.size() * sizeof(DevBand)) &&
-                  upload(reinterpret_cast<void**>(&job->d_stacks), h.stacks.data(), h.stacks.size() * sizeof(int32_t));
+                  upload(reinterpret_cast<void**>(&job->d_stacks), h.stacks.data(), h.stacks.size() * sizeof(int32_t)) &&
+                  upload(reinterpret_cast<void**>(&job->d_tiles), h.tiles.data(), h.tiles.size() * sizeof(DevTile));
   if (!ok) {
     fail(IST_E_HIP, "uploading the op tables failed");
     ist_job_destroy(job.release());
@@ -169,10 +171,13 @@ int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch
   a.dst = static_cast<uint8_t*>(dst);
   a.dst_pitch = dst_pitch;
   a.ops = job->d_ops; a.cells = job->d_cells; a.bands = job->d_bands; a.stacks = job->d_stacks;
+  a.tiles = h.tiles.empty() ? nullptr : job->d_tiles;
   a.n_bands = static_cast<int32_t>(h.bands.size());
   a.n_cells = static_cast<int32_t>(h.cells.size());
   a.filter = h.filter;
   a.lds_words = h.lds_words;
+  a.lds_half = h.lds_half;
+  a.pad_ = 0;
   for (const DevOp& o : h.ops) {
     if (o.image < 0) continue;
     const int i = o.image;
@@ -197,6 +202,7 @@ void ist_job_destroy(ist_job* job) {
     if (job->d_cells) (void)hipFree(job->d_cells);
     if (job->d_bands) (void)hipFree(job->d_bands);
     if (job->d_stacks) (void)hipFree(job->d_stacks);
+    if (job->d_tiles) (void)hipFree(job->d_tiles);
   }
   delete job;
 }
