@@ -127,7 +127,7 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
   Huff dc[4], ac[4];
   uint16_t qt[4][64]; bool have_q[4] = {false, false, false, false};
   int restart_interval = 0;
-  bool have_sof = false;
+  bool have_sof = false, progressive = false;
   int64_t pos = 2;
   *J = JpegImage();
   while (pos + 4 <= n) {
@@ -164,7 +164,8 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
         o += 17 + cnt;
       }
     } else if (m == 0xDD) { if (dl >= 2) restart_interval = static_cast<int>(be16(d)); }
-    else if (m == 0xC0 || m == 0xC1) {                              // SOF0 / SOF1
+    else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {                 // SOF0 / SOF1 (sequential), SOF2 (progressive)
+      progressive = (m == 0xC2);
       if (dl < 6) return fail(IST_E_DECODE, "bad JPEG frame header");
       if (d[0] != 8) return fail(IST_E_UNSUPPORTED, "only 8-bit JPEG is supported");
       J->height = static_cast<int>(be16(d + 1)); J->width = static_cast<int>(be16(d + 3)); J->ncomp = d[5];
@@ -190,8 +191,7 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
       }
       have_sof = true;
       if (header_only) return IST_OK;
-    } else if (m == 0xC2) return fail(IST_E_UNSUPPORTED, "progressive JPEG is not supported (baseline only)");
-    else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) return fail(IST_E_UNSUPPORTED, "this JPEG process (lossless / arithmetic) is not supported");
+    } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) return fail(IST_E_UNSUPPORTED, "this JPEG process (lossless / arithmetic) is not supported");
     else if (m == 0xDA) {                                           // SOS
       if (!have_sof) return fail(IST_E_DECODE, "JPEG scan before frame header");
       const int ns = d[0];
@@ -202,7 +202,17 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
         for (int c = 0; c < J->ncomp; ++c) if (J->comp[c].id == id) ci[s] = c;
         if (ci[s] < 0) return fail(IST_E_DECODE, "JPEG scan names an unknown component");
         td[s] = d[2 + 2 * s] >> 4; ta[s] = d[2 + 2 * s] & 15;
-        if (td[s] > 3 || ta[s] > 3 || !dc[td[s]].present || !ac[ta[s]].present) return fail(IST_E_DECODE, "JPEG scan uses an undefined Huffman table");
+        if (td[s] > 3 || ta[s] > 3) return fail(IST_E_DECODE, "JPEG scan uses an undefined Huffman table");
+      }
+      // spectral selection Ss..Se and successive approximation Ah/Al (T.81 Annex G); a sequential scan is 0..63, 0/0
+      const int Ss = d[1 + 2 * ns], Se = d[2 + 2 * ns], Ah = d[3 + 2 * ns] >> 4, Al = d[3 + 2 * ns] & 15;
+      if (progressive) {
+        if (Ss > Se || Se > 63 || Al > 13 || Ah > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || (Ah != 0 && Ah != Al + 1))
+          return fail(IST_E_DECODE, "bad progressive JPEG scan parameters");
+      } else if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) return fail(IST_E_DECODE, "bad JPEG scan parameters");
+      const bool dc_scan = Ss == 0, need_ac = !progressive || !dc_scan, need_dc = dc_scan && Ah == 0;
+      for (int s = 0; s < ns; ++s) {
+        if ((need_dc && !dc[td[s]].present) || (need_ac && !ac[ta[s]].present)) return fail(IST_E_DECODE, "JPEG scan uses an undefined Huffman table");
       }
       // allocate coefficient planes on first use; copy the quantisation tables in use
       for (int c = 0; c < J->ncomp; ++c) {
@@ -212,7 +222,7 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
         if (C.coef.empty()) C.coef.assign(static_cast<size_t>(C.blocks_x) * C.blocks_y * 64, 0);
       }
       BitReader br; br.p = d + dl; br.end = f + n;
-      int pred[3] = {0, 0, 0};
+      int pred[3] = {0, 0, 0}, eobrun = 0;
       const bool interleaved = ns > 1;
       int mx, my;
       if (interleaved) { mx = J->mcus_x; my = J->mcus_y; }
@@ -231,7 +241,7 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
             if (br.p + 1 >= br.end) return fail(IST_E_DECODE, "JPEG restart marker missing");
             if ((br.p[1] & 7) != next_rst) return fail(IST_E_DECODE, "JPEG restart markers out of order");
             br.p += 2; next_rst = (next_rst + 1) & 7;
-            pred[0] = pred[1] = pred[2] = 0;
+            pred[0] = pred[1] = pred[2] = 0; eobrun = 0;
             until_restart = restart_interval;
           }
           for (int s = 0; s < ns; ++s) {
@@ -240,20 +250,81 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
             for (int by = 0; by < bv; ++by) for (int bx = 0; bx < bh; ++bx) {
               const int gx = x * bh + bx, gy = y * bv + by;
               int16_t* blk = C.coef.data() + (static_cast<size_t>(gy) * C.blocks_x + gx) * 64;
-              int t = decode_symbol(br, dc[td[s]]);
-              if (t < 0 || t > 11) return fail(IST_E_DECODE, "corrupt JPEG entropy data (DC)");
-              const int diff = t ? extend(br.get(t), t) : 0;
-              pred[s] += diff;
-              blk[0] = static_cast<int16_t>(pred[s]);
-              for (int k = 1; k < 64;) {
-                const int rs = decode_symbol(br, ac[ta[s]]);
-                if (rs < 0) return fail(IST_E_DECODE, "corrupt JPEG entropy data (AC)");
-                const int r = rs >> 4, sz = rs & 15;
-                if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
-                k += r;
-                if (k > 63) return fail(IST_E_DECODE, "corrupt JPEG entropy data (run)");
-                blk[kZigzag[k]] = static_cast<int16_t>(extend(br.get(sz), sz));
-                ++k;
+              if (!progressive) {
+                int t = decode_symbol(br, dc[td[s]]);
+                if (t < 0 || t > 11) return fail(IST_E_DECODE, "corrupt JPEG entropy data (DC)");
+                const int diff = t ? extend(br.get(t), t) : 0;
+                pred[s] += diff;
+                blk[0] = static_cast<int16_t>(pred[s]);
+                for (int k = 1; k < 64;) {
+                  const int rs = decode_symbol(br, ac[ta[s]]);
+                  if (rs < 0) return fail(IST_E_DECODE, "corrupt JPEG entropy data (AC)");
+                  const int r = rs >> 4, sz = rs & 15;
+                  if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                  k += r;
+                  if (k > 63) return fail(IST_E_DECODE, "corrupt JPEG entropy data (run)");
+                  blk[kZigzag[k]] = static_cast<int16_t>(extend(br.get(sz), sz));
+                  ++k;
+                }
+              } else if (dc_scan && Ah == 0) {               // DC first pass: the difference, scaled by 2^Al
+                const int t = decode_symbol(br, dc[td[s]]);
+                if (t < 0 || t > 11) return fail(IST_E_DECODE, "corrupt JPEG entropy data (DC)");
+                pred[s] += t ? extend(br.get(t), t) : 0;
+                blk[0] = static_cast<int16_t>(pred[s] * (1 << Al));
+              } else if (dc_scan) {                          // DC refinement: one more bit of every DC coefficient
+                if (br.get(1)) blk[0] = static_cast<int16_t>(blk[0] | (1 << Al));
+              } else if (Ah == 0) {                          // AC first pass over the band Ss..Se
+                if (eobrun > 0) { --eobrun; continue; }
+                for (int k = Ss; k <= Se;) {
+                  const int rs = decode_symbol(br, ac[ta[s]]);
+                  if (rs < 0) return fail(IST_E_DECODE, "corrupt JPEG entropy data (AC)");
+                  const int r = rs >> 4, sz = rs & 15;
+                  if (sz == 0) {
+                    if (r == 15) { k += 16; continue; }
+                    eobrun = (1 << r) - 1;
+                    if (r) eobrun += static_cast<int>(br.get(r));
+                    break;
+                  }
+                  k += r;
+                  if (k > Se) return fail(IST_E_DECODE, "corrupt JPEG entropy data (run)");
+                  blk[kZigzag[k]] = static_cast<int16_t>(extend(br.get(sz), sz) * (1 << Al));
+                  ++k;
+                }
+              } else {                                       // AC refinement (T.81 G.1.2.3)
+                const int p1 = 1 << Al, m1 = -(1 << Al);
+                auto refine = [&](int16_t* c) {              // a correction bit for a coefficient that is already non-zero
+                  if (br.get(1) && (*c & p1) == 0) *c = static_cast<int16_t>(*c + (*c >= 0 ? p1 : m1));
+                };
+                int k = Ss;
+                if (eobrun == 0) {
+                  for (; k <= Se; ++k) {
+                    const int rs = decode_symbol(br, ac[ta[s]]);
+                    if (rs < 0) return fail(IST_E_DECODE, "corrupt JPEG entropy data (AC)");
+                    int r = rs >> 4, val = 0;
+                    const int sz = rs & 15;
+                    if (sz) {
+                      if (sz != 1) return fail(IST_E_DECODE, "corrupt JPEG entropy data (refinement)");
+                      val = br.get(1) ? p1 : m1;
+                    } else if (r != 15) {
+                      eobrun = 1 << r;
+                      if (r) eobrun += static_cast<int>(br.get(r));
+                      break;                                 // the rest of this block is handled as part of the EOB run
+                    }
+                    for (; k <= Se; ++k) {                   // pass already-non-zero coefficients, skip r zero ones
+                      int16_t* c = blk + kZigzag[k];
+                      if (*c != 0) refine(c);
+                      else if (--r < 0) break;
+                    }
+                    if (val) {
+                      if (k > Se) return fail(IST_E_DECODE, "corrupt JPEG entropy data (run)");
+                      blk[kZigzag[k]] = static_cast<int16_t>(val);
+                    }
+                  }
+                }
+                if (eobrun > 0) {
+                  for (; k <= Se; ++k) { int16_t* c = blk + kZigzag[k]; if (*c != 0) refine(c); }
+                  --eobrun;
+                }
               }
             }
           }

@@ -62,7 +62,7 @@ int parse(const uint8_t* f, int64_t n, Header* H, std::vector<uint8_t>* idat, st
                   ((c == 2 || c == 4 || c == 6) && (d == 8 || d == 16));
   if (!ok) return fail(IST_E_DECODE, "bad PNG colour type / bit depth");
   if (c == 3 && plte->size() < 3) return fail(IST_E_DECODE, "palette PNG without PLTE");
-  if (H->interlace != 0) return fail(IST_E_UNSUPPORTED, "Adam7-interlaced PNG is not supported");
+  if (H->interlace > 1) return fail(IST_E_DECODE, "unknown PNG interlace method");
   return IST_OK;
 }
 
@@ -92,68 +92,87 @@ int ist_png_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t 
   const int channels = H.ctype == 0 ? 1 : H.ctype == 2 ? 3 : H.ctype == 3 ? 1 : H.ctype == 4 ? 2 : 4;
   const int bpp_bits = channels * H.depth;
   const size_t bpp = size_t(bpp_bits + 7) / 8;                          // filter unit in bytes (>= 1)
-  const size_t stride = (size_t(H.w) * bpp_bits + 7) / 8;
-  const size_t raw_len = (stride + 1) * size_t(H.h);
+  // passes: the whole image, or the seven Adam7 sub-images (x0, y0, dx, dy), each filtered on its own
+  struct Pass { uint32_t x0, y0, dx, dy; };
+  static const Pass whole[1] = {{0, 0, 1, 1}};
+  static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+  const Pass* passes = H.interlace ? adam7 : whole;
+  const int n_passes = H.interlace ? 7 : 1;
+  auto pass_w = [&](const Pass& P) { return H.w > P.x0 ? (H.w - P.x0 + P.dx - 1) / P.dx : 0u; };
+  auto pass_h = [&](const Pass& P) { return H.h > P.y0 ? (H.h - P.y0 + P.dy - 1) / P.dy : 0u; };
+  size_t raw_len = 0;
+  for (int k = 0; k < n_passes; ++k) {
+    const uint32_t pw = pass_w(passes[k]), ph = pass_h(passes[k]);
+    if (pw && ph) raw_len += ((size_t(pw) * bpp_bits + 7) / 8 + 1) * size_t(ph);
+  }
   std::vector<uint8_t> raw(raw_len);
   uLongf got = static_cast<uLongf>(raw_len);
   const int zr = uncompress(raw.data(), &got, idat.data(), static_cast<uLong>(idat.size()));
   if (zr != Z_OK || got != raw_len) return fail(IST_E_DECODE, "PNG image data does not inflate to the declared size");
 
-  std::vector<uint8_t> prev(stride, 0), cur(stride);
   // tRNS for grey / RGB: one colour is fully transparent
   int t_grey = -1, t_r = -1, t_g = -1, t_b = -1;
   if (H.ctype == 0 && trns.size() >= 2) t_grey = (trns[0] << 8) | trns[1];
   if (H.ctype == 2 && trns.size() >= 6) { t_r = (trns[0] << 8) | trns[1]; t_g = (trns[2] << 8) | trns[3]; t_b = (trns[4] << 8) | trns[5]; }
   const int scale = H.depth < 8 ? 255 / ((1 << H.depth) - 1) : 1;        // 1,2,4-bit greys expand by replication
-  for (uint32_t y = 0; y < H.h; ++y) {
-    const uint8_t* in = raw.data() + size_t(y) * (stride + 1);
-    const int ft = in[0];
-    ++in;
-    switch (ft) {
-      case 0: std::memcpy(cur.data(), in, stride); break;
-      case 1: for (size_t i = 0; i < stride; ++i) cur[i] = uint8_t(in[i] + (i >= bpp ? cur[i - bpp] : 0)); break;
-      case 2: for (size_t i = 0; i < stride; ++i) cur[i] = uint8_t(in[i] + prev[i]); break;
-      case 3: for (size_t i = 0; i < stride; ++i) cur[i] = uint8_t(in[i] + (((i >= bpp ? cur[i - bpp] : 0) + prev[i]) >> 1)); break;
-      case 4: for (size_t i = 0; i < stride; ++i) cur[i] = uint8_t(in[i] + paeth(i >= bpp ? cur[i - bpp] : 0, prev[i], i >= bpp ? prev[i - bpp] : 0)); break;
-      default: return fail(IST_E_DECODE, "unknown PNG filter type");
-    }
-    uint8_t* o = out + size_t(y) * out_pitch;
-    const uint8_t* s = cur.data();
-    for (uint32_t x = 0; x < H.w; ++x, o += 4) {
-      if (H.depth == 8) {
-        switch (H.ctype) {
-          case 6: o[0] = s[4 * x]; o[1] = s[4 * x + 1]; o[2] = s[4 * x + 2]; o[3] = s[4 * x + 3]; break;
-          case 2: o[0] = s[3 * x]; o[1] = s[3 * x + 1]; o[2] = s[3 * x + 2];
-                  o[3] = (o[0] == t_r && o[1] == t_g && o[2] == t_b) ? 0 : 255; break;
-          case 4: o[0] = o[1] = o[2] = s[2 * x]; o[3] = s[2 * x + 1]; break;
-          case 0: o[0] = o[1] = o[2] = s[x]; o[3] = (int(s[x]) == t_grey) ? 0 : 255; break;
-          default: {
-            const size_t idx = s[x];
-            if (idx * 3 + 2 >= plte.size()) return fail(IST_E_DECODE, "palette index out of range");
-            o[0] = plte[idx * 3]; o[1] = plte[idx * 3 + 1]; o[2] = plte[idx * 3 + 2]; o[3] = idx < trns.size() ? trns[idx] : 255;
+  const uint8_t* in = raw.data();
+  for (int k = 0; k < n_passes; ++k) {
+    const Pass& P = passes[k];
+    const uint32_t pw = pass_w(P), ph = pass_h(P);
+    if (!pw || !ph) continue;
+    const size_t stride = (size_t(pw) * bpp_bits + 7) / 8;
+    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    for (uint32_t py = 0; py < ph; ++py) {
+      const int ft = in[0];
+      ++in;
+      switch (ft) {
+        case 0: std::memcpy(cur.data(), in, stride); break;
+        case 1: for (size_t i = 0; i < stride; ++i) cur[i] = uint8_t(in[i] + (i >= bpp ? cur[i - bpp] : 0)); break;
+        case 2: for (size_t i = 0; i < stride; ++i) cur[i] = uint8_t(in[i] + prev[i]); break;
+        case 3: for (size_t i = 0; i < stride; ++i) cur[i] = uint8_t(in[i] + (((i >= bpp ? cur[i - bpp] : 0) + prev[i]) >> 1)); break;
+        case 4: for (size_t i = 0; i < stride; ++i) cur[i] = uint8_t(in[i] + paeth(i >= bpp ? cur[i - bpp] : 0, prev[i], i >= bpp ? prev[i - bpp] : 0)); break;
+        default: return fail(IST_E_DECODE, "unknown PNG filter type");
+      }
+      in += stride;
+      uint8_t* o = out + size_t(P.y0 + py * P.dy) * out_pitch + size_t(P.x0) * 4;
+      const size_t ostep = size_t(P.dx) * 4;
+      const uint8_t* s = cur.data();
+      for (uint32_t x = 0; x < pw; ++x, o += ostep) {
+        if (H.depth == 8) {
+          switch (H.ctype) {
+            case 6: o[0] = s[4 * x]; o[1] = s[4 * x + 1]; o[2] = s[4 * x + 2]; o[3] = s[4 * x + 3]; break;
+            case 2: o[0] = s[3 * x]; o[1] = s[3 * x + 1]; o[2] = s[3 * x + 2];
+                    o[3] = (o[0] == t_r && o[1] == t_g && o[2] == t_b) ? 0 : 255; break;
+            case 4: o[0] = o[1] = o[2] = s[2 * x]; o[3] = s[2 * x + 1]; break;
+            case 0: o[0] = o[1] = o[2] = s[x]; o[3] = (int(s[x]) == t_grey) ? 0 : 255; break;
+            default: {
+              const size_t idx = s[x];
+              if (idx * 3 + 2 >= plte.size()) return fail(IST_E_DECODE, "palette index out of range");
+              o[0] = plte[idx * 3]; o[1] = plte[idx * 3 + 1]; o[2] = plte[idx * 3 + 2]; o[3] = idx < trns.size() ? trns[idx] : 255;
+            }
+          }
+        } else if (H.depth == 16) {                                        // keep the high byte (what 8-bit canvases do)
+          const uint8_t* q = s + size_t(x) * channels * 2;
+          auto v16 = [&](int ch) { return (q[2 * ch] << 8) | q[2 * ch + 1]; };
+          switch (H.ctype) {
+            case 6: o[0] = q[0]; o[1] = q[2]; o[2] = q[4]; o[3] = q[6]; break;
+            case 2: o[0] = q[0]; o[1] = q[2]; o[2] = q[4]; o[3] = (v16(0) == t_r && v16(1) == t_g && v16(2) == t_b) ? 0 : 255; break;
+            case 4: o[0] = o[1] = o[2] = q[0]; o[3] = q[2]; break;
+            default: o[0] = o[1] = o[2] = q[0]; o[3] = (v16(0) == t_grey) ? 0 : 255;
+          }
+        } else {                                                           // 1, 2, 4 bits: grey or palette index
+          const int per = 8 / H.depth, shift = (per - 1 - int(x % per)) * H.depth;
+          const int v = (s[x / per] >> shift) & ((1 << H.depth) - 1);
+          if (H.ctype == 3) {
+            if (size_t(v) * 3 + 2 >= plte.size()) return fail(IST_E_DECODE, "palette index out of range");
+            o[0] = plte[v * 3]; o[1] = plte[v * 3 + 1]; o[2] = plte[v * 3 + 2]; o[3] = size_t(v) < trns.size() ? trns[v] : 255;
+          } else {
+            o[0] = o[1] = o[2] = uint8_t(v * scale); o[3] = (v == t_grey) ? 0 : 255;
           }
         }
-      } else if (H.depth == 16) {                                        // keep the high byte (what 8-bit canvases do)
-        const uint8_t* q = s + size_t(x) * channels * 2;
-        auto v16 = [&](int ch) { return (q[2 * ch] << 8) | q[2 * ch + 1]; };
-        switch (H.ctype) {
-          case 6: o[0] = q[0]; o[1] = q[2]; o[2] = q[4]; o[3] = q[6]; break;
-          case 2: o[0] = q[0]; o[1] = q[2]; o[2] = q[4]; o[3] = (v16(0) == t_r && v16(1) == t_g && v16(2) == t_b) ? 0 : 255; break;
-          case 4: o[0] = o[1] = o[2] = q[0]; o[3] = q[2]; break;
-          default: o[0] = o[1] = o[2] = q[0]; o[3] = (v16(0) == t_grey) ? 0 : 255;
-        }
-      } else {                                                           // 1, 2, 4 bits: grey or palette index
-        const int per = 8 / H.depth, shift = (per - 1 - int(x % per)) * H.depth;
-        const int v = (s[x / per] >> shift) & ((1 << H.depth) - 1);
-        if (H.ctype == 3) {
-          if (size_t(v) * 3 + 2 >= plte.size()) return fail(IST_E_DECODE, "palette index out of range");
-          o[0] = plte[v * 3]; o[1] = plte[v * 3 + 1]; o[2] = plte[v * 3 + 2]; o[3] = size_t(v) < trns.size() ? trns[v] : 255;
-        } else {
-          o[0] = o[1] = o[2] = uint8_t(v * scale); o[3] = (v == t_grey) ? 0 : 255;
-        }
       }
+      prev.swap(cur);
     }
-    prev.swap(cur);
   }
   return IST_OK;
 }

@@ -169,13 +169,13 @@ IST_API int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, c
 IST_API void ist_free(void* p);
 
 /* ---- decode: PNG file -> RGBA8 (host; the Image.src step, utils/canvas.js:27-121, for 'png' inputs, index.js:4) ---- */
-/* colour types 0/2/3/4/6, bit depths 1-16 (16-bit keeps the high byte), tRNS, non-interlaced.  JPEG / WebP / HEIC and
- * Adam7 return IST_E_UNSUPPORTED; damaged files IST_E_DECODE ('图片N解码异常' analogue). */
+/* colour types 0/2/3/4/6, bit depths 1-16 (16-bit keeps the high byte), tRNS, plain or Adam7-interlaced.  JPEG / WebP /
+ * HEIC return IST_E_UNSUPPORTED; damaged files IST_E_DECODE ('图片N解码异常' analogue). */
 IST_API int ist_png_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height);
 IST_API int ist_png_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch);
-/* JPEG (baseline / extended sequential, 8 bit, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0, restart intervals): Huffman
- * decoding on the host, dequantise + IDCT + upsampling + colour conversion on the GPU.  *orientation = EXIF tag 0x0112
- * (0 when absent) - what getImageInfo feeds the planner (index.js:734).  Progressive JPEG: IST_E_UNSUPPORTED. */
+/* JPEG (baseline / extended sequential / progressive, 8 bit, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0, restart
+ * intervals): Huffman decoding on the host, dequantise + IDCT + upsampling + colour conversion on the GPU.  *orientation = EXIF tag 0x0112
+ * (0 when absent) - what getImageInfo feeds the planner (index.js:734).  Lossless / arithmetic-coded JPEG: IST_E_UNSUPPORTED. */
 IST_API int ist_jpeg_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation);
 IST_API int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch);
 /* by signature: PNG, JPEG, BMP (uncompressed, 1-32 bit) or GIF (first frame) - SUPPORTED_IMAGE_TYPES (index.js:4) minus

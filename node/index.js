@@ -83,7 +83,7 @@ function stitchPng(images, direction, opts) {
 function decodePng(file) { return native.decodePng(file); }
 /** PNG or JPEG file bytes -> {width, height, orientation, opaque, data}. JPEG (baseline): Huffman decoding on the host,
  *  IDCT / chroma upsampling / colour conversion on the GPU; orientation = EXIF tag 0x0112 (what getImageInfo feeds the
- *  planner, index.js:734). Progressive JPEG / WebP / HEIC reject with err.code '-7'. */
+ *  planner, index.js:734). WebP / HEIC reject with err.code '-7'. */
 function decodeImage(file) { return native.decodeImage(file); }
 /** File to file (PNG and JPEG inputs): decode -> stitch -> PNG export. Resolves {width, height, png, plan}; writes
  *  outPath when given. A file that does not decode rejects with '图片N解码异常' like index.js:1512-1514. */

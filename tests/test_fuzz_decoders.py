@@ -24,10 +24,15 @@ def _seeds(d):
             ("444.jpg", im, "JPEG", {"subsampling": 0}), ("420.jpg", im, "JPEG", {"subsampling": 2, "quality": 70}),
             ("422.jpg", im, "JPEG", {"subsampling": 1}), ("grey.jpg", im.convert("L"), "JPEG", {}),
             ("rst.jpg", im, "JPEG", {"restart_marker_blocks": 2}), ("exif.jpg", im, "JPEG", {"exif": ex}),
+            ("prog.jpg", im, "JPEG", {"progressive": True, "subsampling": 2}), ("prog444.jpg", im, "JPEG", {"progressive": True, "subsampling": 0}),
             ("24.bmp", im, "BMP", {}), ("8.bmp", im.convert("P"), "BMP", {}), ("1.bmp", im.convert("1"), "BMP", {}),
             ("a.gif", im.convert("P"), "GIF", {}), ("i.gif", im.convert("P"), "GIF", {"interlace": True}),
             ("t.gif", im.convert("P"), "GIF", {"transparency": 3})]
     out = []
+    from test_png_decode import _adam7_png
+    with open(os.path.join(d, "adam7.png"), "wb") as f:
+        f.write(_adam7_png(np.concatenate([a, a[..., :1]], -1), 6))
+    out.append(os.path.join(d, "adam7.png"))
     for name, img, fmt, kw in todo:
         p = os.path.join(d, name)
         img.save(p, fmt, **kw)
@@ -54,3 +59,28 @@ def test_compiler_invariants_under_hostile_op_lists(tmp_path):
     r = subprocess.run([os.path.join(ROOT, "tools", "run_fuzz.sh"), "compile", "16000"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("all invariants hold") == 2
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_progressive_jpeg_gives_the_coefficients_of_its_sequential_twin(tmp_path):
+    """PIL writes the same quantised coefficients whether a file is saved sequential or progressive; the host entropy
+    decoder must recover the same planes from both (the GPU stages after it are shared)."""
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:203, 0:317]
+    a = np.stack([(xx * 2 + yy) % 256, (yy * 3) % 256, ((xx + yy) * 2) % 256], -1) + rng.integers(-25, 25, (203, 317, 3))
+    im = Image.fromarray(a.clip(0, 255).astype(np.uint8), "RGB")
+    files = []
+    for name, kw in (("444", {"subsampling": 0}), ("422", {"subsampling": 1}), ("420", {"subsampling": 2}), ("grey", None)):
+        img = im.convert("L") if kw is None else im
+        for tag, extra in (("b", {"optimize": True}), ("p", {"progressive": True})):
+            p = str(tmp_path / ("%s_%s.jpg" % (name, tag)))
+            img.save(p, "JPEG", quality=83, **dict(kw or {}, **extra))
+            files.append(p)
+    env = dict(os.environ, IST_FUZZ_BIN=str(tmp_path / "fuzz"))
+    r = subprocess.run([os.path.join(ROOT, "tools", "run_fuzz.sh"), "coefs"] + files, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rows = [l.split() for l in r.stdout.strip().splitlines()]
+    assert len(rows) == 8 and all("error" not in l for l in r.stdout.splitlines())
+    for b, p in zip(rows[0::2], rows[1::2]):
+        assert b[-1] == p[-1], (b, p)                 # same coefficient hash
+        assert b[2] == "scans=1" and int(p[2].split("=")[1]) > 1

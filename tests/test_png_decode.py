@@ -112,9 +112,63 @@ def test_errors_are_reported_like_decode_failures():
     inter = _png(Image.fromarray(RNG.integers(0, 256, (8, 8, 3), dtype=np.uint8), "RGB"))
     inter = bytearray(inter); inter[28] = 1
     inter[29:33] = struct.pack(">I", zlib.crc32(bytes(inter[12:29])))
-    with pytest.raises(ist.StitchError) as e:
+    with pytest.raises(ist.StitchError) as e:          # flagged interlaced, but the data is one plain image
         ist.decode_png(bytes(inter))
-    assert e.value.code == -7 and "Adam7" in str(e.value)
+    assert e.value.code == -6
+
+
+def _adam7_png(a, ctype, filters=(0, 1, 2, 3, 4)):
+    """An Adam7-interlaced 8-bit PNG of array a (H x W x C) written by hand (PIL cannot write one): seven sub-images,
+    every scanline with one of the five filter types."""
+    h, w, c = a.shape
+    passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+    raw = bytearray()
+    k = 0
+    for x0, y0, dx, dy in passes:
+        sub = a[y0::dy, x0::dx]
+        if sub.size == 0:
+            continue
+        prev = np.zeros(sub.shape[1] * c, np.int32)
+        for row in sub.reshape(sub.shape[0], -1).astype(np.int32):
+            ft = filters[k % len(filters)]
+            k += 1
+            left = np.concatenate([np.zeros(c, np.int32), row[:-c]])
+            ul = np.concatenate([np.zeros(c, np.int32), prev[:-c]])
+            if ft == 0:
+                pred = 0
+            elif ft == 1:
+                pred = left
+            elif ft == 2:
+                pred = prev
+            elif ft == 3:
+                pred = (left + prev) >> 1
+            else:
+                pp = left + prev - ul
+                pa, pb, pc = abs(pp - left), abs(pp - prev), abs(pp - ul)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            raw.append(ft)
+            raw += ((row - pred) & 255).astype(np.uint8).tobytes()
+            prev = row
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 1)
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (8, 8), (9, 9), (33, 17), (2, 70)])
+def test_adam7_interlaced_png(shape):
+    h, w = shape
+    rgba = RNG.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    data = _adam7_png(rgba, 6)
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGBA")), rgba)      # the hand-written file is valid
+    assert np.array_equal(ist.decode_png(data), rgba)
+    rgb = RNG.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got = ist.decode_png(_adam7_png(rgb, 2))
+    assert np.array_equal(got[..., :3], rgb) and (got[..., 3] == 255).all()
+    grey = RNG.integers(0, 256, (h, w, 1), dtype=np.uint8)
+    got = ist.decode_png(_adam7_png(grey, 0))
+    assert np.array_equal(got[..., 0], grey[..., 0]) and np.array_equal(got[..., 1], got[..., 2])
 
 
 def test_jpeg_header_and_exif_orientation_on_cpu():

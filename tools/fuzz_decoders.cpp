@@ -36,7 +36,26 @@ static void one(const std::vector<uint8_t>& f, long* ok, long* bad) {
   (rc == IST_OK ? *ok : *bad)++;
 }
 
+// "coefs file...": print a hash of the quantised DCT coefficients the entropy decoder produced for each JPEG (the
+// CPU-side check that a progressive file and its sequential twin decode to the same coefficients)
+static int coef_hashes(int argc, char** argv) {
+  for (int a = 2; a < argc; ++a) {
+    FILE* fp = fopen(argv[a], "rb"); if (!fp) return 2;
+    std::vector<uint8_t> f; uint8_t buf[65536]; size_t r;
+    while ((r = fread(buf, 1, sizeof buf, fp)) > 0) f.insert(f.end(), buf, buf + r);
+    fclose(fp);
+    ist::JpegImage J;
+    const int rc = ist::jpeg_parse_and_entropy_decode(f.data(), int64_t(f.size()), &J, false);
+    if (rc != IST_OK) { printf("%s error %d %s\n", argv[a], rc, ist_last_error()); continue; }
+    uint64_t h = 1469598103934665603ull;
+    for (int c = 0; c < J.ncomp; ++c) for (int16_t v : J.comp[c].coef) { h ^= uint16_t(v); h *= 1099511628211ull; }
+    printf("%s %dx%d scans=%d %016llx\n", argv[a], J.width, J.height, J.scans, (unsigned long long)h);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "coefs")) return coef_hashes(argc, argv);
   const int iters = argc > 1 ? atoi(argv[1]) : 2000;
   long ok = 0, bad = 0;
   for (int a = 2; a < argc; ++a) {
