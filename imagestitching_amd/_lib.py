@@ -75,6 +75,7 @@ SYMBOLS = [
     ("ist_op_box", C.c_int, [C.POINTER(Op), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int32)]),
     ("ist_ctx_create", C.c_void_p, [C.c_int]),
     ("ist_ctx_destroy", None, [C.c_void_p]),
+    ("ist_ctx_set_png_level", C.c_int, [C.c_void_p, C.c_int]),
     ("ist_job_create", C.c_void_p, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(Op), C.c_int,
                                     C.POINTER(ImageDesc), C.c_int, C.c_int, C.POINTER(Region)]),
     ("ist_job_info_get", C.c_int, [C.c_void_p, C.POINTER(JobInfo)]),

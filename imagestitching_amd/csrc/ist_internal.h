@@ -104,6 +104,12 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
 // resolve one op (exposed for tests): returns 0 ok, 1 nothing drawn, <0 error
 int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, int img_h, DevOp* out, bool edge_aa = false);
 
+// PNG export, compressing form (ist_png_deflate.hip); ist_png_encode_device picks it when the context's level is > 0
+int64_t png_deflate_bound(int64_t w, int64_t h);
+int png_encode_device_deflate(const void* canvas, size_t pitch, int64_t w, int64_t h, void* out, int64_t out_cap,
+                              int64_t* out_len, void* stream);
+int ctx_png_level(const ist_ctx* ctx);
+
 }  // namespace ist
 
 #endif  // IST_INTERNAL_H_

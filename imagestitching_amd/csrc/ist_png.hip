@@ -17,18 +17,19 @@
 //     partials (linear algebra over GF(2) / mod 65521, O(rows)) and patches the ~60 header/trailer bytes.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
 
+#include "ist_crc.h"
 #include "ist_internal.h"
 
 namespace ist {
 
 namespace {
 
-constexpr uint32_t kPoly = 0xEDB88320u;          // CRC-32 (PNG / zlib), reflected
 constexpr int kChunks = 4;                       // 16-byte chunks per lane per workgroup (16 KiB of a row per workgroup)
 constexpr int64_t kBlockData = 64512;            // pixel bytes per stored block: 63 KiB, a multiple of 1 KiB (wave-row)
 // IDAT chunk data limit (PNG allows 2^31-1); IST_PNG_IDAT_LIMIT lowers it so that tests can exercise multi-chunk files
@@ -40,31 +41,6 @@ static int64_t idat_limit() {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
-
-struct CrcTables { uint32_t t[4][256]; };
-
-// byte-at-a-time table and the three slices on top of it
-void make_tables(CrcTables* T) {
-  for (uint32_t i = 0; i < 256; ++i) {
-    uint32_t c = i;
-    for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ kPoly : c >> 1;
-    T->t[0][i] = c;
-  }
-  for (uint32_t i = 0; i < 256; ++i)
-    for (int s = 1; s < 4; ++s) T->t[s][i] = (T->t[s - 1][i] >> 8) ^ T->t[0][T->t[s - 1][i] & 0xFF];
-}
-
-inline uint32_t crc_byte(const CrcTables& T, uint32_t reg, uint8_t b) { return T.t[0][(reg ^ b) & 0xFF] ^ (reg >> 8); }
-
-// product of two polynomials over GF(2) modulo the CRC polynomial, reflected bit order (x^0 = 0x80000000)
-__host__ __device__ inline uint32_t gf_mul(uint32_t a, uint32_t b) {
-  uint32_t p = 0;
-  for (int i = 0; i < 32; ++i) {
-    if (a & (0x80000000u >> i)) p ^= b;
-    b = (b & 1u) ? (b >> 1) ^ kPoly : b >> 1;
-  }
-  return p;
-}
 
 struct PngArgs {
   const uint8_t* canvas; size_t pitch;
@@ -226,7 +202,8 @@ extern "C" {
 int64_t ist_png_bound(int64_t w, int64_t h) {
   if (w < 1 || h < 1) return 0;
   const int64_t row = 4 * w, nb = (row + kBlockData - 1) / kBlockData;
-  return 64 + h * (row + 81 + 80 * (nb - 1) + 16) + (h * (row + 200) / idat_limit() + 2) * 12 + 32;
+  const int64_t stored = 64 + h * (row + 81 + 80 * (nb - 1) + 16) + (h * (row + 200) / idat_limit() + 2) * 12 + 32;
+  return std::max(stored, png_deflate_bound(w, h));        // either encoder fits
 }
 
 int ist_png_encode_device(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* out, int64_t out_cap,
@@ -236,6 +213,7 @@ int ist_png_encode_device(ist_ctx* ctx, const void* canvas, size_t pitch, int64_
     return fail(IST_E_INVALID, "ist_png_encode_device: bad argument");
   if (w > (1ll << 29) || h > 2147483647ll) return fail(IST_E_OUTPUT_SIZE, "image too large for PNG");
   if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) return fail(IST_E_INVALID, "PNG output buffer must be 16-byte aligned");
+  if (ctx_png_level(ctx) > 0) return png_encode_device_deflate(canvas, pitch, w, h, out, out_cap, out_len, stream_);
   Layout L;
   make_layout(w, h, &L);
   if (L.total > out_cap) return fail(IST_E_INVALID, "PNG output buffer too small (see ist_png_bound)");
@@ -245,7 +223,7 @@ int ist_png_encode_device(ist_ctx* ctx, const void* canvas, size_t pitch, int64_
 
   static CrcTables T;
   static std::once_flag tables_once;
-  std::call_once(tables_once, []() { make_tables(&T); });
+  std::call_once(tables_once, []() { make_crc_tables(&T); });
   // x^(32 i): the register after 4 i zero bytes, starting from the polynomial "1"
   const int64_t n_pow = kBlockData / 4 + 1;
   std::vector<uint32_t> xpow(static_cast<size_t>(n_pow));

@@ -1,0 +1,504 @@
+// ist_png_deflate.hip — the COMPRESSING PNG export: Paeth filter + run-length matches + dynamic Huffman, on the GPU.
+//
+// Reference anchor: the export step of onStitch — wx.canvasToTempFilePath({fileType:'png', quality:1})
+// (utils/canvas.js:205-242, pages/index/index.js:1577-1579).  The reference's encoder is the WeChat client; a PNG that
+// decodes to the same pixels is the same result, so the bit stream is designed for the hardware:
+//
+//   * the filtered stream (per row: filter byte 4 = Paeth, then the Paeth residuals of the RGBA bytes) is cut into
+//     CHUNKS of at most 16 KiB — whole rows when a row fits, otherwise pieces of one row.  One 256-thread workgroup
+//     compresses one chunk into its own deflate block, entirely in LDS, independently of every other chunk.
+//   * tokens: thread t owns bytes [64 t, 64 t + 64) of the chunk.  A run of equal bytes becomes one literal + matches
+//     of distance 1 (what zlib calls Z_RLE, its recommended strategy for PNG); flat areas — gaps, margins, screenshots
+//     — filter to zeros and collapse to a few bits per 64 bytes.  Runs do not cross a thread's span, so no thread
+//     needs its neighbour's state.
+//   * code: one dynamic Huffman code per chunk over the 286 literal/length symbols, built from the chunk's histogram
+//     (bitonic sort + two-queue merge + the zlib length-limit fix-up); the code-length alphabet uses a fixed 4-bit code
+//     so no third code has to be built.  Every thread re-walks its span twice more: once to count its bits (block-wide
+//     exclusive scan gives its bit offset), once to emit them (LDS atomicOr).
+//   * a chunk whose Huffman form is not smaller than its bytes is written as a stored block (random data stays 1:1).
+//   * every chunk ends byte-aligned (empty stored block = zlib's sync flush) and is padded with further empty stored
+//     blocks (5 bytes each, coprime with 16) to a multiple of 16 bytes, so chunks concatenate with 16-byte copies.
+//   * each workgroup also returns the Adler-32 partial sums of its filtered bytes and the raw CRC-32 of its output
+//     bytes; the host combines them (O(chunks)), lays the chunks out behind one another (several IDAT chunks if the
+//     stream exceeds the IDAT limit), a second kernel copies them into place, and ~100 header/trailer bytes are patched.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "ist_crc.h"
+#include "ist_internal.h"
+
+namespace ist {
+
+namespace {
+
+constexpr int CH = 16384;              // most filtered-stream bytes in one chunk
+constexpr int SPAN = 64;               // bytes per thread
+constexpr int SLOT = CH + 128;         // bytes per chunk in the scratch area (stored form + framing + alignment pads)
+constexpr int NSYM = 286;              // literal/length symbols
+constexpr int HDR_BITS = 3 + 5 + 5 + 4 + 19 * 3 + (NSYM + 1) * 4;      // block header with every code length sent in 4 bits
+constexpr int PADDED = CH + CH / 16;   // LDS bytes of the filtered chunk: 4 pad bytes after every 64 (bank spread)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+
+struct DeflArgs {
+  const uint8_t* canvas; size_t pitch; int64_t w, h;
+  uint8_t* slots;                // n_chunks * SLOT
+  uint32_t* len16;               // per chunk: bytes written / 16
+  uint32_t* crc;                 // per chunk: raw CRC (register from 0) of the bytes written
+  uint32_t* ad_a; uint32_t* ad_b; uint32_t* ad_n;    // per chunk: sum of bytes, index-weighted sum mod 65521, byte count
+  const uint32_t* tables;        // 4 x 256 CRC slicing tables
+  const uint32_t* xpow16;        // x^(128 i) mod P: shift of a CRC register over 16 i zero bytes
+  int32_t rows_per_chunk;        // > 0: a chunk is this many whole rows; 0: a chunk is a piece of one row
+  int32_t pieces_per_row, piece_px;
+};
+
+__device__ __forceinline__ int padpos(int p) { return p + ((p >> 6) << 2); }
+
+__device__ __forceinline__ uint32_t paeth4(uint32_t cur, uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x = (cur >> (8 * k)) & 255, l = (a >> (8 * k)) & 255, u = (b >> (8 * k)) & 255, ul = (c >> (8 * k)) & 255;
+    const int pa = abs(u - ul), pb = abs(l - ul), pc = abs(l + u - 2 * ul);
+    const int pred = (pa <= pb && pa <= pc) ? l : (pb <= pc ? u : ul);
+    out |= static_cast<uint32_t>((x - pred) & 255) << (8 * k);
+  }
+  return out;
+}
+
+// deflate length symbol for a match of l bytes (3 <= l <= 66): symbol, extra-bit count, extra-bit value
+__device__ __forceinline__ void len_code(int l, int* sym, int* eb, int* ev) {
+  const int m = l - 3;
+  if (m < 8) { *sym = 257 + m; *eb = 0; *ev = 0; return; }
+  const int e = (31 - __builtin_clz(m)) - 2;
+  *sym = 257 + 4 * (e + 1) + ((m >> e) & 3); *eb = e; *ev = m & ((1 << e) - 1);
+}
+
+struct BitWriter {
+  uint32_t* w; unsigned long long acc; int n; int wp;
+  __device__ void init(uint32_t* words, int bitpos) { w = words; wp = bitpos >> 5; n = bitpos & 31; acc = 0; }
+  __device__ void put(uint32_t v, int bits) {
+    acc |= static_cast<unsigned long long>(v) << n; n += bits;
+    if (n >= 32) { atomicOr(&w[wp++], static_cast<uint32_t>(acc)); acc >>= 32; n -= 32; }
+  }
+  __device__ void flush() { if (n > 0 && acc) atomicOr(&w[wp], static_cast<uint32_t>(acc)); }
+};
+
+__device__ __forceinline__ void or_bits(uint32_t* w, int bitpos, uint32_t v, int bits) {
+  const int wp = bitpos >> 5, sh = bitpos & 31;
+  if (v) {
+    atomicOr(&w[wp], v << sh);
+    if (sh + bits > 32) atomicOr(&w[wp + 1], v >> (32 - sh));
+  }
+}
+
+__device__ __forceinline__ uint32_t rev_bits(uint32_t code, int len) { return __brev(code) >> (32 - len); }
+
+// One pass of a thread over its span.  PASS 0: histogram; 1: count bits; 2: emit.
+template <int PASS>
+__device__ __forceinline__ int walk_span(const uint8_t* f, int n, uint32_t* hist, const uint32_t* clen, const uint32_t* code, BitWriter* bw) {
+  int bits = 0, i = 0;
+  while (i < n) {
+    const uint32_t v = f[i];
+    int run = 1;
+    while (i + run < n && f[i + run] == v) ++run;
+    int lits = 1, rem = run - 1;
+    int msym = 0, meb = 0, mev = 0, mlen = 0;
+    if (rem >= 3) { mlen = rem; len_code(mlen, &msym, &meb, &mev); rem = 0; }     // a span is 64 bytes: one match covers the run
+    lits += rem;
+    if (PASS == 0) { atomicAdd(&hist[v], static_cast<uint32_t>(lits)); if (mlen) atomicAdd(&hist[msym], 1u); }
+    else if (PASS == 1) { bits += lits * static_cast<int>(clen[v]); if (mlen) bits += static_cast<int>(clen[msym]) + meb + 1; }
+    else {
+      // the literal that starts the run, then the match, then the 1-2 left-over literals
+      bw->put(code[v], static_cast<int>(clen[v]));
+      if (mlen) { bw->put(code[msym], static_cast<int>(clen[msym])); if (meb) bw->put(static_cast<uint32_t>(mev), meb); bw->put(0u, 1); }
+      for (int k = 1; k < lits; ++k) bw->put(code[v], static_cast<int>(clen[v]));
+    }
+    i += run;
+  }
+  return bits;
+}
+
+__global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) {
+  __shared__ __attribute__((aligned(16))) uint8_t filt[PADDED];
+  __shared__ __attribute__((aligned(16))) uint32_t outw[SLOT / 4];
+  __shared__ uint32_t T[4][256];
+  __shared__ uint32_t hist[288], clen[288], code[288];
+  __shared__ uint32_t keys[512];                 // sort keys; later: Huffman node weights / depths
+  __shared__ uint16_t parent[2 * NSYM];
+  __shared__ uint32_t wsum[8];
+  __shared__ int s_out_len;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t chunk = blockIdx.x;
+
+  // ---- which pixels: rows [y0, y0 + nrows) x columns [x0, x0 + npr); the filter byte belongs to the piece with x0 == 0
+  int64_t y0; int nrows, x0, npr;
+  if (P.rows_per_chunk > 0) {
+    y0 = chunk * P.rows_per_chunk; nrows = static_cast<int>(min(static_cast<int64_t>(P.rows_per_chunk), P.h - y0)); x0 = 0; npr = static_cast<int>(P.w);
+  } else {
+    y0 = chunk / P.pieces_per_row; nrows = 1;
+    const int piece = static_cast<int>(chunk - y0 * P.pieces_per_row);
+    x0 = piece * P.piece_px; npr = static_cast<int>(min(static_cast<int64_t>(P.piece_px), P.w - x0));
+  }
+  const int hasf = x0 == 0 ? 1 : 0;
+  const int rowlen = hasf + 4 * npr;
+  const int len = rowlen * nrows;                // <= CH by construction
+
+  for (int i = tid; i < 1024; i += 256) T[i >> 8][i & 255] = P.tables[i];
+  for (int i = tid; i < SLOT / 4; i += 256) outw[i] = 0;
+  for (int i = tid; i < 288; i += 256) { hist[i] = 0; clen[i] = 0; code[i] = 0; }
+  // ---- A. load + Paeth filter into LDS
+  const int npix = npr * nrows;
+  for (int q = tid; q < npix; q += 256) {
+    const int r = q / npr, xx = q - r * npr;
+    const int64_t y = y0 + r; const int x = x0 + xx;
+    const uint8_t* row = P.canvas + static_cast<size_t>(y) * P.pitch;
+    const uint32_t cur = *reinterpret_cast<const uint32_t*>(row + 4 * static_cast<size_t>(x));
+    const uint32_t a = x > 0 ? *reinterpret_cast<const uint32_t*>(row + 4 * static_cast<size_t>(x - 1)) : 0u;
+    uint32_t b = 0, c = 0;
+    if (y > 0) {
+      b = *reinterpret_cast<const uint32_t*>(row - P.pitch + 4 * static_cast<size_t>(x));
+      c = x > 0 ? *reinterpret_cast<const uint32_t*>(row - P.pitch + 4 * static_cast<size_t>(x - 1)) : 0u;
+    }
+    const uint32_t fv = paeth4(cur, a, b, c);
+    const int pos = r * rowlen + hasf + 4 * xx;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) filt[padpos(pos + k)] = static_cast<uint8_t>(fv >> (8 * k));
+    if (hasf && xx == 0) filt[padpos(r * rowlen)] = 4;          // filter type of the row
+  }
+  __syncthreads();
+
+  // ---- B. histogram (+ the end-of-block symbol), Adler partials
+  const int base = tid * SPAN;
+  const int n = max(0, min(SPAN, len - base));
+  const uint8_t* my = filt + tid * (SPAN + 4);
+  walk_span<0>(my, n, hist, nullptr, nullptr, nullptr);
+  if (tid == 0) atomicAdd(&hist[256], 1u);
+  uint32_t a1 = 0, a2 = 0;
+  for (int i = 0; i < n; ++i) { a1 += my[i]; a2 += static_cast<uint32_t>(len - (base + i)) * my[i]; }
+  a2 %= 65521u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); }
+  if (lane == 0) { wsum[wave] = a1; wsum[4 + wave] = a2; }
+  __syncthreads();
+  if (tid == 0) {
+    P.ad_a[chunk] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    P.ad_b[chunk] = (wsum[4] + wsum[5] + wsum[6] + wsum[7]) % 65521u;
+    P.ad_n[chunk] = static_cast<uint32_t>(len);
+  }
+
+  // ---- C. code lengths: sort the used symbols by frequency (bitonic, 512 keys), Huffman on one thread
+  for (int i = tid; i < 512; i += 256) keys[i] = (i < NSYM && hist[i]) ? ((hist[i] << 9) | static_cast<uint32_t>(i)) : 0xFFFFFFFFu;
+  __syncthreads();
+  for (int k = 2; k <= 512; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < 512; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint32_t x = keys[i], y = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) {
+    int ns = 0;
+    while (ns < NSYM && keys[ns] != 0xFFFFFFFFu) ++ns;        // >= 2: the end-of-block symbol and at least one literal
+    // leaves 0..ns-1 (ascending weight) keep their symbol in keys[] low bits; weights / depths live in outw[] scratch
+    // (outw is zeroed again before the bit stream is written)
+    uint32_t* wt = outw;                    // 2*ns - 1 node weights, later depths
+    for (int i = 0; i < ns; ++i) wt[i] = keys[i] >> 9;
+    int li = 0, ii = ns, nn = ns;           // next unused leaf, next unused internal node, nodes so far
+    for (int k = 0; k < ns - 1; ++k) {
+      int pick[2];
+      for (int t = 0; t < 2; ++t) {
+        if (li < ns && (ii >= nn || wt[li] <= wt[ii])) pick[t] = li++; else pick[t] = ii++;
+      }
+      wt[nn] = wt[pick[0]] + wt[pick[1]];
+      parent[pick[0]] = static_cast<uint16_t>(nn); parent[pick[1]] = static_cast<uint16_t>(nn);
+      ++nn;
+    }
+    wt[nn - 1] = 0;                                            // root depth
+    for (int v = nn - 2; v >= 0; --v) wt[v] = wt[parent[v]] + 1;
+    // length limit 15, the zlib way: count codes per length, push the overflow down, re-assign by frequency order
+    int bl[17];
+    for (int b = 0; b <= 16; ++b) bl[b] = 0;
+    int overflow = 0;
+    for (int i = 0; i < ns; ++i) { int d = static_cast<int>(wt[i]); if (d > 15) { d = 15; ++overflow; } ++bl[d]; }
+    while (overflow > 0) {
+      int bits = 14;
+      while (bl[bits] == 0) --bits;
+      --bl[bits]; bl[bits + 1] += 2; --bl[15];
+      overflow -= 2;
+    }
+    int idx = 0;                                               // least frequent symbols get the longest codes
+    for (int bits = 15; bits >= 1; --bits)
+      for (int c = 0; c < bl[bits]; ++c) clen[keys[idx++] & 511u] = static_cast<uint32_t>(bits);
+    // canonical codes in symbol order, stored bit-reversed (deflate packs Huffman codes most significant bit first)
+    uint32_t next[17]; uint32_t cd = 0;
+    bl[0] = 0;
+    for (int bits = 1; bits <= 15; ++bits) { cd = (cd + static_cast<uint32_t>(bl[bits - 1])) << 1; next[bits] = cd; }
+    for (int s = 0; s < NSYM; ++s) { const int l = static_cast<int>(clen[s]); if (l) code[s] = rev_bits(next[l]++, l); }
+  }
+  __syncthreads();
+
+  // ---- D. bits per thread, exclusive scan, choice between the Huffman and the stored form
+  const int mybits = walk_span<1>(my, n, nullptr, clen, nullptr, nullptr);
+  int incl = mybits;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+  __syncthreads();                                   // outw scratch (weights) no longer needed by thread 0
+  if (lane == 63) wsum[wave] = static_cast<uint32_t>(incl);
+  __syncthreads();
+  int wave_base = 0;
+  for (int k = 0; k < wave; ++k) wave_base += static_cast<int>(wsum[k]);
+  const int total_tok_bits = static_cast<int>(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+  const int lead = chunk == 0 ? 2 : 0;               // the zlib header travels with the first chunk
+  const int my_start = lead * 8 + HDR_BITS + wave_base + incl - mybits;
+  const int end_bit = lead * 8 + HDR_BITS + total_tok_bits + static_cast<int>(clen[256]);
+  const int huff_bytes = (end_bit + 3 + 7) / 8 + 4;  // + the empty stored block that re-aligns to a byte
+  const bool stored = huff_bytes >= lead + 5 + len;
+  for (int i = tid; i < SLOT / 4; i += 256) outw[i] = 0;
+  __syncthreads();
+  uint8_t* outb = reinterpret_cast<uint8_t*>(outw);
+  int body_end;                                       // bytes before the alignment pads
+  if (!stored) {
+    // header: BFINAL 0, BTYPE 2, HLIT 29, HDIST 0, HCLEN 15, the 19 code-length-code lengths, 286 + 1 code lengths.
+    // Code-length alphabet: symbols 0..15 all 4 bits long (a complete code: canonical code of symbol s = s), 16-18 unused.
+    const int hb = lead * 8;
+    if (tid == 0) {
+      if (lead) { outb[0] = 0x78; outb[1] = 0x01; }
+      or_bits(outw, hb, 4u | (29u << 3) | (0u << 8) | (15u << 13), 17);
+    }
+    if (tid < 19) or_bits(outw, hb + 17 + 3 * tid, tid < 3 ? 0u : 4u, 3);       // order 16,17,18,0,8,7,...: first three are unused
+    for (int s = tid; s < NSYM + 1; s += 256) {
+      const uint32_t l = s < NSYM ? clen[s] : 1u;                                // the one distance code: 1 bit
+      or_bits(outw, hb + 17 + 57 + 4 * s, rev_bits(l, 4), 4);
+    }
+    BitWriter bw; bw.init(outw, my_start);
+    walk_span<2>(my, n, nullptr, clen, code, &bw);
+    bw.flush();
+    if (tid == 0) or_bits(outw, end_bit - static_cast<int>(clen[256]), code[256], static_cast<int>(clen[256]));
+    body_end = (end_bit + 3 + 7) / 8;                 // 3 zero bits: BFINAL 0, BTYPE 00; then to the byte boundary
+    __syncthreads();
+    if (tid == 0) { outb[body_end + 2] = 0xFF; outb[body_end + 3] = 0xFF; }      // LEN 0000, NLEN FFFF
+    body_end += 4;
+  } else {
+    if (tid == 0) {
+      if (lead) { outb[0] = 0x78; outb[1] = 0x01; }
+      uint8_t* q = outb + lead;
+      q[0] = 0; q[1] = len & 0xFF; q[2] = (len >> 8) & 0xFF; q[3] = (~len) & 0xFF; q[4] = ((~len) >> 8) & 0xFF;
+    }
+    for (int i = 0; i < n; ++i) outb[lead + 5 + base + i] = my[i];
+    body_end = lead + 5 + len;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int total = body_end;
+    while (total & 15) { outb[total + 3] = 0xFF; outb[total + 4] = 0xFF; total += 5; }   // empty stored blocks: 00 00 00 FF FF
+    s_out_len = total;
+    P.len16[chunk] = static_cast<uint32_t>(total >> 4);
+  }
+  __syncthreads();
+
+  // ---- E. write the chunk to its slot; raw CRC of its bytes (each 16-byte unit shifted to the end of the chunk)
+  const int out_len = s_out_len;
+  uint8_t* slot = P.slots + static_cast<size_t>(chunk) * SLOT;
+  uint32_t crc = 0;
+  for (int u = tid; u < (out_len >> 4); u += 256) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(outw + 4 * u);
+    *reinterpret_cast<u32x4*>(slot + 16 * static_cast<size_t>(u)) = v;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t c = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      c ^= w[d];
+      c = T[3][c & 0xFF] ^ T[2][(c >> 8) & 0xFF] ^ T[1][(c >> 16) & 0xFF] ^ T[0][c >> 24];
+    }
+    crc ^= gf_mul(P.xpow16[(out_len >> 4) - 1 - u], c);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) crc ^= __shfl_xor(crc, off);
+  __syncthreads();
+  if (lane == 0) wsum[wave] = crc;
+  __syncthreads();
+  if (tid == 0) P.crc[chunk] = wsum[0] ^ wsum[1] ^ wsum[2] ^ wsum[3];
+}
+
+struct GatherArgs { const uint8_t* slots; uint8_t* out; const int64_t* dst; const uint32_t* len16; };
+
+// chunk j: len16[j] 16-byte units from its slot to file offset dst[j] (4-byte aligned)
+__global__ __launch_bounds__(256) void ist_png_gather_kernel(const GatherArgs G) {
+  const int64_t j = blockIdx.x;
+  const uint8_t* s = G.slots + static_cast<size_t>(j) * SLOT;
+  uint8_t* d = G.out + G.dst[j];
+  const int units = static_cast<int>(G.len16[j]);
+  for (int u = threadIdx.x; u < units; u += 256)
+    *reinterpret_cast<u32x4_a4*>(d + 16 * static_cast<size_t>(u)) = *reinterpret_cast<const u32x4*>(s + 16 * static_cast<size_t>(u));
+}
+
+void put32(uint8_t* p, uint32_t v) { p[0] = v >> 24; p[1] = (v >> 16) & 0xFF; p[2] = (v >> 8) & 0xFF; p[3] = v & 0xFF; }
+
+struct ChunkGrid { int64_t n_chunks; int rows_per_chunk, pieces_per_row, piece_px; };
+
+ChunkGrid make_grid(int64_t w, int64_t h) {
+  ChunkGrid g{0, 0, 0, 0};
+  const int64_t R = 4 * w + 1;
+  if (R <= CH) { g.rows_per_chunk = static_cast<int>(CH / R); g.n_chunks = (h + g.rows_per_chunk - 1) / g.rows_per_chunk; }
+  else { g.piece_px = (CH - 1) / 4; g.pieces_per_row = static_cast<int>((w + g.piece_px - 1) / g.piece_px); g.n_chunks = h * g.pieces_per_row; }
+  return g;
+}
+
+int64_t idat_limit() {
+  const char* e = std::getenv("IST_PNG_IDAT_LIMIT");
+  const int64_t v = e ? std::atoll(e) : 0;
+  return v >= 4096 ? (v & ~15ll) : (1ll << 30);
+}
+
+constexpr int kDataStart = 64;     // signature 8 + IHDR 25 + tEXt 23 + IDAT length/type 8: the stream starts 16-byte aligned
+
+}  // namespace
+
+// upper bound of the compressed form: every chunk stored
+int64_t png_deflate_bound(int64_t w, int64_t h) {
+  const ChunkGrid g = make_grid(w, h);
+  const int64_t data = g.n_chunks * SLOT + 16;
+  return kDataStart + data + (data / idat_limit() + 2) * 12 + 64;
+}
+
+int png_encode_device_deflate(const void* canvas, size_t pitch, int64_t w, int64_t h, void* out, int64_t out_cap,
+                              int64_t* out_len, void* stream_) {
+  const ChunkGrid g = make_grid(w, h);
+  if (g.n_chunks > 2147483647ll) return fail(IST_E_OUTPUT_SIZE, "image too large for one PNG launch");
+  if (png_deflate_bound(w, h) > out_cap) return fail(IST_E_INVALID, "PNG output buffer too small (see ist_png_bound)");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  static CrcTables T;
+  static std::vector<uint32_t> xpow;
+  static std::once_flag once;
+  std::call_once(once, []() {
+    make_crc_tables(&T);
+    xpow.resize(SLOT / 16 + 2);
+    uint32_t reg = 0x80000000u;                      // the polynomial "1"
+    for (size_t i = 0; i < xpow.size(); ++i) { xpow[i] = reg; for (int z = 0; z < 16; ++z) reg = crc_byte(T, reg, 0); }
+  });
+  const size_t n = static_cast<size_t>(g.n_chunks);
+  auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  const size_t o_T = 0, o_pow = o_T + up(sizeof T), o_len = o_pow + up(4 * xpow.size()), o_crc = o_len + up(4 * n), o_a = o_crc + up(4 * n),
+               o_b = o_a + up(4 * n), o_n = o_b + up(4 * n), o_dst = o_n + up(4 * n), o_slots = o_dst + up(8 * n), total_scratch = o_slots + n * SLOT;
+  uint8_t* scratch = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&scratch), total_scratch) != hipSuccess) return fail(IST_E_NOMEM, "PNG scratch allocation failed");
+  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{scratch};
+#define PNG_HIP(e) do { const hipError_t e_ = (e); if (e_ != hipSuccess) return fail(IST_E_HIP, std::string(#e) + ": " + hipGetErrorString(e_)); } while (0)
+  PNG_HIP(hipMemcpyAsync(scratch + o_T, &T, sizeof T, hipMemcpyHostToDevice, stream));
+  PNG_HIP(hipMemcpyAsync(scratch + o_pow, xpow.data(), 4 * xpow.size(), hipMemcpyHostToDevice, stream));
+  DeflArgs A;
+  A.canvas = static_cast<const uint8_t*>(canvas); A.pitch = pitch; A.w = w; A.h = h;
+  A.slots = scratch + o_slots;
+  A.len16 = reinterpret_cast<uint32_t*>(scratch + o_len); A.crc = reinterpret_cast<uint32_t*>(scratch + o_crc);
+  A.ad_a = reinterpret_cast<uint32_t*>(scratch + o_a); A.ad_b = reinterpret_cast<uint32_t*>(scratch + o_b); A.ad_n = reinterpret_cast<uint32_t*>(scratch + o_n);
+  A.tables = reinterpret_cast<const uint32_t*>(scratch + o_T); A.xpow16 = reinterpret_cast<const uint32_t*>(scratch + o_pow);
+  A.rows_per_chunk = g.rows_per_chunk; A.pieces_per_row = g.pieces_per_row; A.piece_px = g.piece_px;
+  hipLaunchKernelGGL(ist_png_deflate_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, stream, A);
+  PNG_HIP(hipGetLastError());
+  std::vector<uint32_t> len16(n), crc(n), ada(n), adb(n), adn(n);
+  PNG_HIP(hipMemcpyAsync(len16.data(), scratch + o_len, 4 * n, hipMemcpyDeviceToHost, stream));
+  PNG_HIP(hipMemcpyAsync(crc.data(), scratch + o_crc, 4 * n, hipMemcpyDeviceToHost, stream));
+  PNG_HIP(hipMemcpyAsync(ada.data(), scratch + o_a, 4 * n, hipMemcpyDeviceToHost, stream));
+  PNG_HIP(hipMemcpyAsync(adb.data(), scratch + o_b, 4 * n, hipMemcpyDeviceToHost, stream));
+  PNG_HIP(hipMemcpyAsync(adn.data(), scratch + o_n, 4 * n, hipMemcpyDeviceToHost, stream));
+  PNG_HIP(hipStreamSynchronize(stream));
+
+  // ---- host: Adler-32 of the filtered stream, the layout of the chunks in the file, the CRC of every IDAT
+  const uint64_t M = 65521;
+  uint64_t a = 1, b = 0;
+  for (size_t j = 0; j < n; ++j) {
+    b = (b + (adn[j] % M) * a + adb[j]) % M;
+    a = (a + ada[j]) % M;
+  }
+  const uint32_t adler = static_cast<uint32_t>((b << 16) | a);
+  struct Patch { int64_t at; uint8_t b[64]; int n; };
+  std::vector<Patch> patches;
+  std::vector<int64_t> dst(n);
+  const int64_t limit = idat_limit();
+  static const uint8_t trailer_block[5] = {0x01, 0x00, 0x00, 0xFF, 0xFF};          // final, empty stored block
+  uint32_t reg = 0xFFFFFFFFu;
+  auto feed = [&](const uint8_t* p, int k) { for (int i = 0; i < k; ++i) reg = crc_byte(T, reg, p[i]); };
+  {
+    Patch pt; std::memset(&pt, 0, sizeof pt);
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::memcpy(pt.b, sig, 8);
+    put32(pt.b + 8, 13); std::memcpy(pt.b + 12, "IHDR", 4);
+    put32(pt.b + 16, static_cast<uint32_t>(w)); put32(pt.b + 20, static_cast<uint32_t>(h));
+    pt.b[24] = 8; pt.b[25] = 6; pt.b[26] = 0; pt.b[27] = 0; pt.b[28] = 0;
+    uint32_t c = 0xFFFFFFFFu;
+    for (int i = 12; i < 29; ++i) c = crc_byte(T, c, pt.b[i]);
+    put32(pt.b + 29, c ^ 0xFFFFFFFFu);
+    // an 11-byte tEXt chunk: its only job is to start the IDAT data at file offset 64
+    put32(pt.b + 33, 11); std::memcpy(pt.b + 37, "tEXtSoftware\0is", 15);
+    c = 0xFFFFFFFFu;
+    for (int i = 37; i < 52; ++i) c = crc_byte(T, c, pt.b[i]);
+    put32(pt.b + 52, c ^ 0xFFFFFFFFu);
+    pt.at = 0; pt.n = 56;
+    patches.push_back(pt);
+  }
+  int64_t pos = 56, idat_len_at = 0, idat_data = 0;
+  auto open_idat = [&]() {
+    Patch pt; std::memset(&pt, 0, sizeof pt);
+    pt.at = pos; idat_len_at = pos;
+    std::memcpy(pt.b + 4, "IDAT", 4);
+    pt.n = 8; patches.push_back(pt);
+    reg = 0xFFFFFFFFu; feed(pt.b + 4, 4);
+    pos += 8; idat_data = 0;
+  };
+  auto close_idat = [&]() {
+    Patch pt; std::memset(&pt, 0, sizeof pt);
+    pt.at = pos; put32(pt.b, reg ^ 0xFFFFFFFFu); pt.n = 4; patches.push_back(pt);
+    Patch lp; std::memset(&lp, 0, sizeof lp);
+    lp.at = idat_len_at; put32(lp.b, static_cast<uint32_t>(idat_data)); lp.n = 4; patches.push_back(lp);
+    pos += 4;
+  };
+  open_idat();
+  for (size_t j = 0; j < n; ++j) {
+    const int64_t bytes = static_cast<int64_t>(len16[j]) * 16;
+    if (bytes <= 0 || bytes > SLOT) return fail(IST_E_HIP, "PNG deflate kernel returned an impossible chunk length");
+    if (idat_data > 0 && idat_data + bytes + 9 > limit) { close_idat(); open_idat(); }
+    dst[j] = pos;
+    reg = gf_mul(xpow[static_cast<size_t>(len16[j])], reg) ^ crc[j];
+    pos += bytes; idat_data += bytes;
+  }
+  {
+    Patch pt; std::memset(&pt, 0, sizeof pt);
+    pt.at = pos;
+    std::memcpy(pt.b, trailer_block, 5); put32(pt.b + 5, adler);
+    feed(pt.b, 9);
+    pt.n = 9; patches.push_back(pt);
+    pos += 9; idat_data += 9;
+    close_idat();
+    Patch ie; std::memset(&ie, 0, sizeof ie);
+    ie.at = pos; put32(ie.b, 0); std::memcpy(ie.b + 4, "IEND", 4);
+    uint32_t c = 0xFFFFFFFFu;
+    for (int i = 4; i < 8; ++i) c = crc_byte(T, c, ie.b[i]);
+    put32(ie.b + 8, c ^ 0xFFFFFFFFu);
+    ie.n = 12; patches.push_back(ie);
+    pos += 12;
+  }
+  if (pos > out_cap) return fail(IST_E_INVALID, "PNG output buffer too small (see ist_png_bound)");
+  PNG_HIP(hipMemcpyAsync(scratch + o_dst, dst.data(), 8 * n, hipMemcpyHostToDevice, stream));
+  GatherArgs G{scratch + o_slots, static_cast<uint8_t*>(out), reinterpret_cast<const int64_t*>(scratch + o_dst), reinterpret_cast<const uint32_t*>(scratch + o_len)};
+  hipLaunchKernelGGL(ist_png_gather_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, stream, G);
+  PNG_HIP(hipGetLastError());
+  for (const Patch& pt : patches)
+    PNG_HIP(hipMemcpyAsync(static_cast<uint8_t*>(out) + pt.at, pt.b, static_cast<size_t>(pt.n), hipMemcpyHostToDevice, stream));
+  PNG_HIP(hipStreamSynchronize(stream));
+#undef PNG_HIP
+  *out_len = pos;
+  return IST_OK;
+}
+
+}  // namespace ist

@@ -30,7 +30,10 @@ struct ist_ctx {
   void* scratch_src = nullptr; size_t scratch_src_bytes = 0;
   void* scratch_dst = nullptr; size_t scratch_dst_bytes = 0;
   std::mutex mu;                         // one host-path stitch in flight per context (index.js:772 isStitching)
+  int png_level = 0;                     // 0: stored deflate blocks; 1: Paeth + run-length + Huffman (ist_ctx_set_png_level)
 };
+
+namespace ist { int ctx_png_level(const ist_ctx* ctx) { return ctx ? ctx->png_level : 0; } }
 
 struct ist_job {
   ist_ctx* ctx = nullptr;
@@ -108,6 +111,13 @@ ist_ctx* ist_ctx_create(int device) {
     return nullptr;
   }
   return c.release();
+}
+
+int ist_ctx_set_png_level(ist_ctx* ctx, int level) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (level < 0 || level > 1) return fail(IST_E_INVALID, "PNG level must be 0 (stored) or 1 (compressed)");
+  ctx->png_level = level;
+  return IST_OK;
 }
 
 void ist_ctx_destroy(ist_ctx* ctx) {

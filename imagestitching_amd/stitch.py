@@ -34,7 +34,10 @@ DEFAULT_OPTS = {
     "maxPixels": None,      # deviceMaxCanvasPixels override
     "superSample": None,    # None: 1 when platform is None, reference rule (index.js:1363) otherwise
     "edgeAA": False,        # anti-alias fractional rectangle edges by area coverage (IST_FILTER_EDGE_AA)
+    "pngLevel": None,       # PNG export form of the *_png / stitch_files calls: 0 stored, 1 compressed on the GPU; None = DEFAULT_PNG_LEVEL
 }
+
+DEFAULT_PNG_LEVEL = 0
 
 
 def _limits(opts):
@@ -136,6 +139,14 @@ def _ctx(device=0):
         if not c:
             raise L.StitchError(-5, L.last_error())
         _ctx_cache[device] = c
+    return c
+
+
+def _ctx_png(device, level):
+    """The context with its PNG export form set (ist_ctx_set_png_level): a per-context setting, so concurrent callers
+    that want different forms on one device should serialise."""
+    c = _ctx(device)
+    L.check(L.lib.ist_ctx_set_png_level(c, int(DEFAULT_PNG_LEVEL if level is None else level)))
     return c
 
 
@@ -269,7 +280,7 @@ def stitch_files(paths, direction, opts=None, out_path=None, device=0):
     cplan = L.Plan()
     lim = _limits(o)
     out, ln = C.POINTER(C.c_uint8)(), C.c_int64(0)
-    rc = L.check(L.lib.ist_stitch_files_png(_ctx(device), files, lens, n, _DIRECTIONS[direction], _MODES[o["mode"]], float(o["gap"] or 0),
+    rc = L.check(L.lib.ist_stitch_files_png(_ctx_png(device, o["pngLevel"]), files, lens, n, _DIRECTIONS[direction], _MODES[o["mode"]], float(o["gap"] or 0),
                                             C.byref(lim), _filter_of(o), C.byref(cplan), C.byref(out), C.byref(ln)))
     if rc == L.IST_NOTHING_TO_DO:
         return None
@@ -282,15 +293,16 @@ def stitch_files(paths, direction, opts=None, out_path=None, device=0):
     return res
 
 
-def encode_png(pixels, device=0):
-    """Lossless PNG (colour type 6) of an HxWx4 uint8 array, encoded on the GPU (export step, utils/canvas.js:205-242)."""
+def encode_png(pixels, device=0, level=None):
+    """Lossless PNG (colour type 6) of an HxWx4 uint8 array, encoded on the GPU (export step, utils/canvas.js:205-242).
+    level 0: stored deflate blocks; 1: Paeth + run-length + Huffman (ist_ctx_set_png_level)."""
     a = np.asarray(pixels)
     if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 4:
         raise TypeError("expected an HxWx4 uint8 RGBA array")
     if a.strides[2] != 1 or a.strides[1] != 4:
         a = np.ascontiguousarray(a)
     out, n = C.POINTER(C.c_uint8)(), C.c_int64(0)
-    L.check(L.lib.ist_png_encode_rgba8(_ctx(device), a.ctypes.data, a.strides[0], a.shape[1], a.shape[0], C.byref(out), C.byref(n)))
+    L.check(L.lib.ist_png_encode_rgba8(_ctx_png(device, level), a.ctypes.data, a.strides[0], a.shape[1], a.shape[0], C.byref(out), C.byref(n)))
     return _take_png(out, n)
 
 
@@ -314,7 +326,7 @@ def stitch_png(images, direction, opts=None, device=0):
     cplan = L.Plan()
     lim = _limits(o)
     out, ln = C.POINTER(C.c_uint8)(), C.c_int64(0)
-    rc = L.check(L.lib.ist_stitch_png(_ctx(device), descs, ptrs, pitches, n, _DIRECTIONS[direction], _MODES[o["mode"]],
+    rc = L.check(L.lib.ist_stitch_png(_ctx_png(device, o["pngLevel"]), descs, ptrs, pitches, n, _DIRECTIONS[direction], _MODES[o["mode"]],
                                       float(o["gap"] or 0), C.byref(lim), _filter_of(o), C.byref(cplan), C.byref(out), C.byref(ln)))
     if rc == L.IST_NOTHING_TO_DO:
         return None
@@ -323,7 +335,7 @@ def stitch_png(images, direction, opts=None, device=0):
     return {"width": w, "height": h, "png": _take_png(out, ln)}
 
 
-def encode_png_device(canvas, out=None, stream=None, device=None):
+def encode_png_device(canvas, out=None, stream=None, device=None, level=None):
     """PNG of a canvas that is resident in HBM (HxWx4 uint8 CUDA tensor) into a CUDA uint8 tensor; returns (tensor, length)."""
     import torch
     h, w = int(canvas.shape[0]), int(canvas.shape[1])
@@ -335,7 +347,7 @@ def encode_png_device(canvas, out=None, stream=None, device=None):
     st = stream if stream is not None else torch.cuda.current_stream(canvas.device)
     n = C.c_int64(0)
     dev = canvas.device.index if device is None else device
-    L.check(L.lib.ist_png_encode_device(_ctx(dev or 0), C.c_void_p(canvas.data_ptr()), canvas.stride(0), w, h,
+    L.check(L.lib.ist_png_encode_device(_ctx_png(dev or 0, level), C.c_void_p(canvas.data_ptr()), canvas.stride(0), w, h,
                                         C.c_void_p(aligned), out.numel() - (aligned - base), C.byref(n), C.c_void_p(st.cuda_stream)))
     off = aligned - base
     return out[off:off + n.value], n.value

@@ -111,3 +111,114 @@ def test_stitch_files_png_in_png_out(tmp_path):
         (tmp_path / "bad.png").write_bytes(b"not a png at all, definitely not, no no no no no no no no no no no")
         ist.stitch_files([paths[0], str(tmp_path / "bad.png")], "vertical")
     assert "图片1解码异常" in str(e.value)
+
+
+# ---- the compressing form (ist_ctx_set_png_level 1): Paeth + run-length matches + a dynamic Huffman code per 16 KiB ----
+def _walk(png):
+    """chunk walk: every CRC, the Adler (zlib.decompress), the filter bytes; returns (ihdr, raw stream, IDAT count)"""
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr, n_idat, seen_end = 8, b"", None, 0, False
+    while pos < len(png):
+        ln, typ = struct.unpack(">I4s", png[pos:pos + 8])
+        data = png[pos + 8:pos + 8 + ln]
+        crc, = struct.unpack(">I", png[pos + 8 + ln:pos + 12 + ln])
+        assert zlib.crc32(typ + data) == crc, "bad CRC in %r chunk" % typ
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", data)
+        elif typ == b"IDAT":
+            idat += data
+            n_idat += 1
+        elif typ == b"IEND":
+            assert ln == 0 and pos + 12 == len(png)
+            seen_end = True
+        pos += 12 + ln
+    assert seen_end
+    return ihdr, zlib.decompress(idat), n_idat
+
+
+def _check_compressed(a, max_ratio=None):
+    from PIL import Image
+    png = ist.encode_png(a, level=1)
+    h, w = a.shape[:2]
+    ihdr, raw, n_idat = _walk(png)
+    assert ihdr == (w, h, 8, 6, 0, 0, 0)
+    assert len(raw) == h * (4 * w + 1)
+    assert (np.frombuffer(raw, np.uint8).reshape(h, 4 * w + 1)[:, 0] == 4).all()      # Paeth on every row
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(png)).convert("RGBA")), a)
+    assert np.array_equal(ist.decode_png(png), a)
+    if max_ratio is not None:
+        assert len(png) <= max_ratio * a.nbytes + 400, (len(png), a.nbytes)
+    return png, n_idat
+
+
+def _photo_like(seed, h, w):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([128 + 90 * np.sin(xx / 37.0 + yy / 91.0), 128 + 80 * np.cos(xx / 53.0 - yy / 29.0), 100 + 0.03 * xx + 0.05 * yy, np.full((h, w), 255.0)], -1)
+    base[..., :3] += rng.normal(0, 2.0, (h, w, 3))
+    return base.clip(0, 255).astype(np.uint8)
+
+
+def _screenshot_like(seed, h, w):
+    rng = np.random.default_rng(seed)
+    a = np.full((h, w, 4), 255, np.uint8)
+    for _ in range(max(1, h // 12)):                      # "text lines": short dark dashes on white
+        y = int(rng.integers(0, h)); x = int(rng.integers(0, max(1, w - 40)))
+        a[y:y + 2, x:x + int(rng.integers(5, 40)), :3] = rng.integers(0, 80, 3, dtype=np.uint8)
+    a[h // 3:h // 3 + max(1, h // 10), :, :3] = (40, 120, 200)      # a flat coloured banner
+    return a
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 5), (4, 4), (64, 33), (257, 19), (1000, 300), (4032, 50), (4095, 3), (4096, 3), (5000, 5), (36288, 2)])
+def test_compressed_png_roundtrip_random(w, h):
+    """random bytes: every chunk falls back to a stored block; whole rows per chunk, several rows per chunk, and
+    pieces of one row (rows longer than 16 KiB) all round-trip"""
+    png, _ = _check_compressed(U.rand_image(500 + w, h, w, opaque=False))
+    assert len(png) <= 1.02 * 4 * w * h + 400
+
+
+@pytest.mark.parametrize("w,h", [(7, 9), (640, 480), (4032, 64), (5000, 40), (300, 2000)])
+def test_compressed_png_photo_like(w, h):
+    a = _photo_like(w + h, h, w)
+    png, _ = _check_compressed(a, max_ratio=0.62)
+    raw = np.frombuffer(_walk(png)[1], np.uint8)
+    yard = len(zlib.compress(raw.tobytes(), 6))
+    print("photo-like %dx%d: raw %d, ours %d (%.3f), zlib-6 on the same Paeth stream %d (%.3f)" % (w, h, a.nbytes, len(png), len(png) / a.nbytes, yard, yard / a.nbytes))
+    assert len(png) <= 1.25 * yard + 400
+
+
+@pytest.mark.parametrize("w,h", [(750, 1334), (4032, 200)])
+def test_compressed_png_flat_content(w, h):
+    a = _screenshot_like(w, h, w)
+    png, _ = _check_compressed(a, max_ratio=0.04)
+    print("screenshot-like %dx%d: raw %d, ours %d (%.4f)" % (w, h, a.nbytes, len(png), len(png) / a.nbytes))
+
+
+def test_compressed_png_translucent_and_extremes():
+    a = _photo_like(3, 120, 333)
+    a[..., 3] = (np.arange(333) % 256).astype(np.uint8)[None, :]
+    _check_compressed(a)
+    _check_compressed(np.zeros((50, 70, 4), np.uint8), max_ratio=0.02)
+    _check_compressed(np.full((50, 70, 4), 255, np.uint8), max_ratio=0.02)
+    sk = np.zeros((64, 256, 4), np.uint8)                      # a skewed histogram: long Huffman codes
+    sk[..., 0] = (np.arange(256) ** 2 // 256).astype(np.uint8)[None, :]
+    sk[::7, ::5, 1] = 200
+    _check_compressed(sk)
+
+
+def test_compressed_png_splits_idat(monkeypatch):
+    monkeypatch.setenv("IST_PNG_IDAT_LIMIT", "65536")
+    a = U.rand_image(77, 200, 300, opaque=False)
+    png, n_idat = _check_compressed(a)
+    assert n_idat >= 3
+    b = _photo_like(5, 300, 800)
+    png, n_idat = _check_compressed(b)
+    assert n_idat >= 2
+
+
+def test_stitch_png_with_compression_matches_stored_pixels():
+    imgs = [{"width": 320, "height": 240, "data": _photo_like(k, 240, 320)} for k in range(3)]
+    a = ist.stitch_png(imgs, "vertical", {"gap": 6, "pngLevel": 0})
+    b = ist.stitch_png(imgs, "vertical", {"gap": 6, "pngLevel": 1})
+    assert np.array_equal(ist.decode_png(a["png"]), ist.decode_png(b["png"]))
+    assert len(b["png"]) < 0.7 * len(a["png"])
