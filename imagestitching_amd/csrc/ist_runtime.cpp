@@ -30,7 +30,7 @@ struct ist_ctx {
   void* scratch_src = nullptr; size_t scratch_src_bytes = 0;
   void* scratch_dst = nullptr; size_t scratch_dst_bytes = 0;
   std::mutex mu;                         // one host-path stitch in flight per context (index.js:772 isStitching)
-  int png_level = 0;                     // 0: stored deflate blocks; 1: Paeth + run-length + Huffman (ist_ctx_set_png_level)
+  int png_level = 1;                     // 1: Paeth + run-length + Huffman; 0: stored deflate blocks (ist_ctx_set_png_level)
 };
 
 namespace ist { int ctx_png_level(const ist_ctx* ctx) { return ctx ? ctx->png_level : 0; } }

@@ -37,7 +37,7 @@ DEFAULT_OPTS = {
     "pngLevel": None,       # PNG export form of the *_png / stitch_files calls: 0 stored, 1 compressed on the GPU; None = DEFAULT_PNG_LEVEL
 }
 
-DEFAULT_PNG_LEVEL = 0
+DEFAULT_PNG_LEVEL = 1
 
 
 def _limits(opts):
@@ -299,8 +299,8 @@ def encode_png(pixels, device=0, level=None):
     a = np.asarray(pixels)
     if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 4:
         raise TypeError("expected an HxWx4 uint8 RGBA array")
-    if a.strides[2] != 1 or a.strides[1] != 4:
-        a = np.ascontiguousarray(a)
+    if a.strides[2] != 1 or a.strides[1] != 4 or a.strides[0] < 4 * a.shape[1]:
+        a = np.ascontiguousarray(a).copy()
     out, n = C.POINTER(C.c_uint8)(), C.c_int64(0)
     L.check(L.lib.ist_png_encode_rgba8(_ctx_png(device, level), a.ctypes.data, a.strides[0], a.shape[1], a.shape[0], C.byref(out), C.byref(n)))
     return _take_png(out, n)

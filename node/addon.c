@@ -542,6 +542,20 @@ static napi_value js_abi_version(napi_env env, napi_callback_info info) {
   (void)info; napi_value v; napi_create_int32(env, ist_abi_version(), &v); return v;
 }
 
+/* setPngLevel(level): 0 stored deflate blocks, 1 compressed on the GPU (ist_ctx_set_png_level) - applies to every PNG
+ * this process exports afterwards */
+static napi_value js_set_png_level(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  CHECK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  int32_t level = 0;
+  if (argc < 1 || napi_get_value_int32(env, argv[0], &level) != napi_ok) { napi_throw_type_error(env, NULL, "setPngLevel(level)"); return NULL; }
+  ist_ctx* ctx = get_ctx();
+  if (!ctx) { napi_throw(env, make_error(env, IST_E_NO_DEVICE, g_ctx_err)); return NULL; }
+  const int rc = ist_ctx_set_png_level(ctx, level);
+  if (rc < 0) return throw_ist(env, rc);
+  napi_value v; napi_get_undefined(env, &v); return v;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"plan", NULL, js_plan, NULL, NULL, NULL, napi_default, NULL},
@@ -550,6 +564,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"stitchFiles", NULL, js_stitch_files, NULL, NULL, NULL, napi_default, NULL},
       {"render", NULL, js_render, NULL, NULL, NULL, napi_default, NULL},
       {"encodePng", NULL, js_encode_png, NULL, NULL, NULL, napi_default, NULL},
+      {"setPngLevel", NULL, js_set_png_level, NULL, NULL, NULL, napi_default, NULL},
       {"decodePng", NULL, js_decode_png, NULL, NULL, NULL, napi_default, NULL},
       {"decodeImage", NULL, js_decode_image, NULL, NULL, NULL, napi_default, NULL},
       {"deviceCount", NULL, js_device_count, NULL, NULL, NULL, napi_default, NULL},

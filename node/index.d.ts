@@ -17,6 +17,7 @@ export interface StitchOptions {
   maxSide?: number; maxPixels?: number; superSample?: number;
   edgeAA?: boolean;                         // anti-alias fractional rectangle edges (ctx.scale(superSample), unrounded cursor)
   onProgress?: (percent: number) => void;   // stitchProgress checkpoints (index.js:1193-1611)
+  pngLevel?: 0 | 1;                         // PNG export form: 0 stored, 1 compressed on the GPU (process-wide once set)
 }
 export interface PlanRect { image: number; orientation: number; dx: number; dy: number; dw: number; dh: number; }
 export interface StitchPlan {
@@ -29,7 +30,8 @@ export function stitchSync(images: StitchImage[], direction: Direction, opts?: S
 export function plan(images: StitchImage[], direction: Direction, opts?: StitchOptions): StitchPlan | null;
 export interface StitchPngResult { width: number; height: number; png: Buffer; plan: StitchPlan; }
 export function stitchPng(images: StitchImage[], direction: Direction, opts?: StitchOptions): Promise<StitchPngResult | null>;
-export function encodePng(data: Uint8Array, width: number, height: number): Buffer;
+export function encodePng(data: Uint8Array, width: number, height: number, opts?: { pngLevel?: 0 | 1 }): Buffer;
+export function setPngLevel(level: 0 | 1): void;
 export function decodePng(file: Uint8Array): { width: number; height: number; data: Buffer };
 export function stitchFiles(paths: string[], direction: Direction, opts?: StitchOptions, outPath?: string): Promise<StitchPngResult | null>;
 export function decodeImage(file: Uint8Array): { width: number; height: number; orientation: number; opaque: boolean; data: Buffer };

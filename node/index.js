@@ -25,7 +25,7 @@ const DIRECTION = { vertical: 0, horizontal: 1 };
 const MODE = { min: 0, max: 1, original: 2 };
 const FILTER = { nearest: 0, bilinear: 1 };
 const PLATFORM = { other: 0, devtools: 0, windows: 0, mac: 0, ios: 1, android: 2 };
-const KNOWN = ['mode', 'gap', 'filter', 'platform', 'maxSide', 'maxPixels', 'superSample', 'onProgress', 'edgeAA'];
+const KNOWN = ['mode', 'gap', 'filter', 'platform', 'maxSide', 'maxPixels', 'superSample', 'onProgress', 'edgeAA', 'pngLevel'];
 const FILTER_EDGE_AA = 0x100;    // IST_FILTER_EDGE_AA: anti-alias fractional rectangle edges by area coverage
 
 function limitsOf(opts) {
@@ -76,8 +76,12 @@ function stitchPng(images, direction, opts) {
   let a;
   try { a = args(images, direction, opts); } catch (e) { return Promise.reject(e); }
   if (!a[0].length) return Promise.resolve(null);
-  return withProgress(opts, () => native.stitch(...a, true));
+  return withProgress(opts, () => { pngLevel(opts); return native.stitch(...a, true); });
 }
+/** opts.pngLevel: 0 = stored deflate blocks (file = raw size, fastest), 1 = Paeth + run-length + Huffman on the GPU
+ *  (photographs about half, screenshots a few per cent). A process-wide setting of the native context. */
+function pngLevel(opts) { if (opts && opts.pngLevel !== undefined && opts.pngLevel !== null) native.setPngLevel(opts.pngLevel | 0); }
+function setPngLevel(level) { native.setPngLevel(level | 0); }
 /** PNG file bytes -> {width, height, data} (RGBA8, straight alpha). Host decode: the Image.src step for 'png' inputs
  *  (utils/canvas.js:27-121; SUPPORTED_IMAGE_TYPES, index.js:4). JPEG / WebP / HEIC are not built: err.code '-7'. */
 function decodePng(file) { return native.decodePng(file); }
@@ -93,15 +97,15 @@ async function stitchFiles(paths, direction, opts, outPath) {
   if (!paths || !paths.length) return null;
   const files = paths.map((p) => fs.readFileSync(p));
   // one native call: Huffman / inflate on host threads, reconstruction + stitch + PNG on the GPU, buffers stay in HBM
-  const res = await withProgress(opts, () => native.stitchFiles(files, a[1], a[2], a[3], a[4], a[5]));
+  const res = await withProgress(opts, () => { pngLevel(opts); return native.stitchFiles(files, a[1], a[2], a[3], a[4], a[5]); });
   if (res && outPath) fs.writeFileSync(outPath, res.png);
   return res;
 }
 /** Lossless PNG of RGBA8 pixels, encoded on the GPU. */
-function encodePng(data, width, height) { return native.encodePng(data, width, height); }
+function encodePng(data, width, height, opts) { pngLevel(opts); return native.encodePng(data, width, height); }
 function plan(images, direction, opts) {
   const a = args(images, direction, opts);
   return native.plan(a[0], a[1], a[2], a[3], a[4]);
 }
 
-module.exports = { stitch, stitchSync, stitchPng, stitchFiles, encodePng, decodePng, decodeImage, plan, native, DIRECTION, MODE, FILTER, PLATFORM };
+module.exports = { stitch, stitchSync, stitchPng, stitchFiles, encodePng, setPngLevel, decodePng, decodeImage, plan, native, DIRECTION, MODE, FILTER, PLATFORM };

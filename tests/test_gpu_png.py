@@ -40,7 +40,7 @@ def _decode_by_hand(png):
 
 def _check(a):
     from PIL import Image
-    png = ist.encode_png(a)
+    png = ist.encode_png(a, level=0)
     by_hand, _ = _decode_by_hand(png)
     assert np.array_equal(by_hand, a)
     pil = np.asarray(Image.open(io.BytesIO(png)).convert("RGBA"))
@@ -66,7 +66,7 @@ def test_png_more_rows_than_65535():
 def test_png_multiple_idat_chunks(monkeypatch):
     monkeypatch.setenv("IST_PNG_IDAT_LIMIT", "65536")
     a = U.rand_image(413, 300, 257)
-    png = ist.encode_png(a)
+    png = ist.encode_png(a, level=0)
     got, n_idat = _decode_by_hand(png)
     assert n_idat > 3 and np.array_equal(got, a)
 
@@ -86,12 +86,31 @@ def test_png_device_resident_full_size():
     """BASELINE configs[1] canvas (4032x27216, 439 MB) encoded without leaving HBM; decoded by zlib on the host."""
     import torch
     canvas = torch.randint(0, 256, (27216, 4032, 4), dtype=torch.uint8, device="cuda")
-    out, n = ist.encode_png_device(canvas)
+    out, n = ist.encode_png_device(canvas, level=0)
     torch.cuda.synchronize()
     png = out.cpu().numpy().tobytes()
     assert len(png) == n and n < ist._lib.lib.ist_png_bound(4032, 27216)
     got, n_idat = _decode_by_hand(png)
     assert n_idat == 1 and np.array_equal(got, canvas.cpu().numpy())
+
+
+def test_compressed_png_device_resident_full_size():
+    """the same canvas size with photo-like content, compressed form: 439 MB -> about 0.43 of it, decoded by zlib + PIL-free un-filter (own decoder)"""
+    import torch
+    H, W = 27216, 4032
+    yy = torch.arange(H, device="cuda", dtype=torch.float32)[:, None]
+    xx = torch.arange(W, device="cuda", dtype=torch.float32)[None, :]
+    c = torch.stack([128 + 90 * torch.sin(xx / 37 + yy / 91), 128 + 80 * torch.cos(xx / 53 - yy / 29), 100 + 0.03 * xx + 0.002 * yy, torch.full((H, W), 255.0, device="cuda")], -1)
+    c[..., :3] += torch.randn((H, W, 3), device="cuda") * 2.0
+    canvas = c.clamp(0, 255).to(torch.uint8).contiguous()
+    del c
+    out, n = ist.encode_png_device(canvas, level=1)
+    torch.cuda.synchronize()
+    png = out.cpu().numpy().tobytes()
+    assert len(png) == n and n < 0.5 * canvas.numel()
+    ihdr, raw, n_idat = _walk(png)
+    assert ihdr == (W, H, 8, 6, 0, 0, 0) and len(raw) == H * (4 * W + 1) and n_idat == 1
+    assert np.array_equal(ist.decode_png(png), canvas.cpu().numpy())
 
 
 def test_stitch_files_png_in_png_out(tmp_path):
@@ -222,3 +241,37 @@ def test_stitch_png_with_compression_matches_stored_pixels():
     b = ist.stitch_png(imgs, "vertical", {"gap": 6, "pngLevel": 1})
     assert np.array_equal(ist.decode_png(a["png"]), ist.decode_png(b["png"]))
     assert len(b["png"]) < 0.7 * len(a["png"])
+
+
+def test_compressed_png_code_longer_than_15_bits_is_limited():
+    """Fibonacci symbol counts make the unrestricted Huffman code ~19 bits deep: the length limiter must produce a
+    valid, complete 15-bit code (zlib refuses both over-subscribed and incomplete literal/length codes)."""
+    fib = [1, 1]
+    while len(fib) < 19:
+        fib.append(fib[-1] + fib[-2])
+    vals = np.arange(19) * 7 + 20                                   # 19 distinct residual values
+    res = np.repeat(vals, fib).astype(np.uint8)
+    rng = np.random.default_rng(11)
+    rng.shuffle(res)
+    res = np.concatenate([res, np.full((-len(res)) % 4, 20, np.uint8)])
+    a = np.ascontiguousarray(np.cumsum(res.reshape(-1, 4).astype(np.int64), axis=0).astype(np.uint8)[None, :, :]).copy()      # h = 1: Paeth = Sub
+    png, _ = _check_compressed(a)
+    assert len(png) < 0.5 * a.nbytes
+
+
+def test_compressed_png_many_random_shapes_and_contents():
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        h, w = int(rng.integers(1, 200)), int(rng.integers(1, 400))
+        kind = case % 5
+        if kind == 0:
+            a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        elif kind == 1:
+            a = rng.choice(np.array([0, 1, 2, 255], np.uint8), (h, w, 4))
+        elif kind == 2:
+            a = np.repeat(rng.integers(0, 256, (h, (w + 15) // 16, 4), dtype=np.uint8), 16, axis=1)[:, :w]      # runs
+        elif kind == 3:
+            a = _photo_like(case, h, w)
+        else:
+            a = _screenshot_like(case, h, w)
+        _check_compressed(np.ascontiguousarray(a))
