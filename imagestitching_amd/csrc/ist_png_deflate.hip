@@ -99,40 +99,56 @@ __device__ __forceinline__ void or_bits(uint32_t* w, int bitpos, uint32_t v, int
 
 __device__ __forceinline__ uint32_t rev_bits(uint32_t code, int len) { return __brev(code) >> (32 - len); }
 
-// One pass of a thread over its span.  PASS 0: histogram; 1: count bits; 2: emit.
+// One pass of a thread over its span.  PASS 0: histogram; 1: count bits; 2: emit.  The span is read as 16 dwords (the
+// padded layout keeps every span 4-byte aligned) and walked as a stream: a run is flushed when the byte changes.
+template <int PASS>
+__device__ __forceinline__ void flush_run(uint32_t v, int run, int* bits, uint32_t* hist, const uint32_t* clen, const uint32_t* code, BitWriter* bw) {
+  int lits = 1, rem = run - 1;
+  int msym = 0, meb = 0, mev = 0, mlen = 0;
+  if (rem >= 3) { mlen = rem; len_code(mlen, &msym, &meb, &mev); rem = 0; }     // a span is 64 bytes: one match covers the run
+  lits += rem;
+  if (PASS == 0) { atomicAdd(&hist[v], static_cast<uint32_t>(lits)); if (mlen) atomicAdd(&hist[msym], 1u); }
+  else if (PASS == 1) { *bits += lits * static_cast<int>(clen[v]); if (mlen) *bits += static_cast<int>(clen[msym]) + meb + 1; }
+  else {
+    // the literal that starts the run, then the match (distance 1: one zero bit), then the 1-2 left-over literals
+    const uint32_t cv = code[v]; const int lv = static_cast<int>(clen[v]);
+    bw->put(cv, lv);
+    if (mlen) { bw->put(code[msym], static_cast<int>(clen[msym])); if (meb) bw->put(static_cast<uint32_t>(mev), meb); bw->put(0u, 1); }
+    for (int k = 1; k < lits; ++k) bw->put(cv, lv);
+  }
+}
+
 template <int PASS>
 __device__ __forceinline__ int walk_span(const uint8_t* f, int n, uint32_t* hist, const uint32_t* clen, const uint32_t* code, BitWriter* bw) {
-  int bits = 0, i = 0;
-  while (i < n) {
-    const uint32_t v = f[i];
-    int run = 1;
-    while (i + run < n && f[i + run] == v) ++run;
-    int lits = 1, rem = run - 1;
-    int msym = 0, meb = 0, mev = 0, mlen = 0;
-    if (rem >= 3) { mlen = rem; len_code(mlen, &msym, &meb, &mev); rem = 0; }     // a span is 64 bytes: one match covers the run
-    lits += rem;
-    if (PASS == 0) { atomicAdd(&hist[v], static_cast<uint32_t>(lits)); if (mlen) atomicAdd(&hist[msym], 1u); }
-    else if (PASS == 1) { bits += lits * static_cast<int>(clen[v]); if (mlen) bits += static_cast<int>(clen[msym]) + meb + 1; }
-    else {
-      // the literal that starts the run, then the match, then the 1-2 left-over literals
-      bw->put(code[v], static_cast<int>(clen[v]));
-      if (mlen) { bw->put(code[msym], static_cast<int>(clen[msym])); if (meb) bw->put(static_cast<uint32_t>(mev), meb); bw->put(0u, 1); }
-      for (int k = 1; k < lits; ++k) bw->put(code[v], static_cast<int>(clen[v]));
+  int bits = 0, run = 0;
+  uint32_t v = 0;
+  const uint32_t* fw = reinterpret_cast<const uint32_t*>(f);
+  for (int d = 0; 4 * d < n; ++d) {
+    const uint32_t w = fw[d];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (4 * d + k < n) {
+        const uint32_t b = (w >> (8 * k)) & 255u;
+        if (run > 0 && b == v) ++run;
+        else { if (run > 0) flush_run<PASS>(v, run, &bits, hist, clen, code, bw); v = b; run = 1; }
+      }
     }
-    i += run;
   }
+  if (run > 0) flush_run<PASS>(v, run, &bits, hist, clen, code, bw);
   return bits;
 }
 
 __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) {
   __shared__ __attribute__((aligned(16))) uint8_t filt[PADDED];
   __shared__ __attribute__((aligned(16))) uint32_t outw[SLOT / 4];
-  __shared__ uint32_t T[4][256];
-  __shared__ uint32_t hist[288], clen[288], code[288];
-  __shared__ uint32_t keys[512];                 // sort keys; later: Huffman node weights / depths
-  __shared__ uint16_t parent[2 * NSYM];
+  // one LDS area, two lives: histogram / code lengths / codes / sort keys while the block is built, then the CRC tables
+  __shared__ __attribute__((aligned(16))) uint32_t area[3 * 288 + 512];
+  uint32_t* const hist = area; uint32_t* const clen = area + 288; uint32_t* const code = area + 576; uint32_t* const keys = area + 864;
+  uint32_t (*const T)[256] = reinterpret_cast<uint32_t (*)[256]>(area);
+  uint16_t* const parent = reinterpret_cast<uint16_t*>(outw + 640);      // Huffman scratch (with the node weights in outw[0..571])
   __shared__ uint32_t wsum[8];
-  __shared__ int s_out_len;
+  __shared__ int s_out_len, s_skip, s_ns, s_ovf;
+  __shared__ int bl[17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t chunk = blockIdx.x;
 
@@ -149,7 +165,6 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
   const int rowlen = hasf + 4 * npr;
   const int len = rowlen * nrows;                // <= CH by construction
 
-  for (int i = tid; i < 1024; i += 256) T[i >> 8][i & 255] = P.tables[i];
   for (int i = tid; i < SLOT / 4; i += 256) outw[i] = 0;
   for (int i = tid; i < 288; i += 256) { hist[i] = 0; clen[i] = 0; code[i] = 0; }
   // ---- A. load + Paeth filter into LDS
@@ -192,64 +207,115 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
     P.ad_n[chunk] = static_cast<uint32_t>(len);
   }
 
-  // ---- C. code lengths: sort the used symbols by frequency (bitonic, 512 keys), Huffman on one thread
-  for (int i = tid; i < 512; i += 256) keys[i] = (i < NSYM && hist[i]) ? ((hist[i] << 9) | static_cast<uint32_t>(i)) : 0xFFFFFFFFu;
-  __syncthreads();
-  for (int k = 2; k <= 512; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < 512; i += 256) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const uint32_t x = keys[i], y = keys[ixj];
-          const bool up = (i & k) == 0;
-          if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
-        }
-      }
-      __syncthreads();
-    }
-  if (tid == 0) {
-    int ns = 0;
-    while (ns < NSYM && keys[ns] != 0xFFFFFFFFu) ++ns;        // >= 2: the end-of-block symbol and at least one literal
-    // leaves 0..ns-1 (ascending weight) keep their symbol in keys[] low bits; weights / depths live in outw[] scratch
-    // (outw is zeroed again before the bit stream is written)
-    uint32_t* wt = outw;                    // 2*ns - 1 node weights, later depths
-    for (int i = 0; i < ns; ++i) wt[i] = keys[i] >> 9;
-    int li = 0, ii = ns, nn = ns;           // next unused leaf, next unused internal node, nodes so far
-    for (int k = 0; k < ns - 1; ++k) {
-      int pick[2];
-      for (int t = 0; t < 2; ++t) {
-        if (li < ns && (ii >= nn || wt[li] <= wt[ii])) pick[t] = li++; else pick[t] = ii++;
-      }
-      wt[nn] = wt[pick[0]] + wt[pick[1]];
-      parent[pick[0]] = static_cast<uint16_t>(nn); parent[pick[1]] = static_cast<uint16_t>(nn);
-      ++nn;
-    }
-    wt[nn - 1] = 0;                                            // root depth
-    for (int v = nn - 2; v >= 0; --v) wt[v] = wt[parent[v]] + 1;
-    // length limit 15, the zlib way: count codes per length, push the overflow down, re-assign by frequency order
-    int bl[17];
-    for (int b = 0; b <= 16; ++b) bl[b] = 0;
-    int overflow = 0;
-    for (int i = 0; i < ns; ++i) { int d = static_cast<int>(wt[i]); if (d > 15) { d = 15; ++overflow; } ++bl[d]; }
-    while (overflow > 0) {
-      int bits = 14;
-      while (bl[bits] == 0) --bits;
-      --bl[bits]; bl[bits + 1] += 2; --bl[15];
-      overflow -= 2;
-    }
-    int idx = 0;                                               // least frequent symbols get the longest codes
-    for (int bits = 15; bits >= 1; --bits)
-      for (int c = 0; c < bl[bits]; ++c) clen[keys[idx++] & 511u] = static_cast<uint32_t>(bits);
-    // canonical codes in symbol order, stored bit-reversed (deflate packs Huffman codes most significant bit first)
-    uint32_t next[17]; uint32_t cd = 0;
-    bl[0] = 0;
-    for (int bits = 1; bits <= 15; ++bits) { cd = (cd + static_cast<uint32_t>(bl[bits - 1])) << 1; next[bits] = cd; }
-    for (int s = 0; s < NSYM; ++s) { const int l = static_cast<int>(clen[s]); if (l) code[s] = rev_bits(next[l]++, l); }
+  // ---- C. code lengths.  First a lower bound: no prefix code beats the entropy of the token symbols, so a chunk whose
+  // entropy already exceeds its stored size (random data) skips the code construction altogether.
+  const int lead = chunk == 0 ? 2 : 0;               // the zlib header travels with the first chunk
+  __syncthreads();                                   // thread 0 has read the Adler partials out of wsum[]
+  {
+    float hsum = 0.0f;
+    uint32_t tot = 0;
+    for (int i = tid; i < NSYM; i += 256) tot += hist[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    if (lane == 0) wsum[wave] = tot;
+    __syncthreads();
+    const float total = static_cast<float>(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    for (int i = tid; i < NSYM; i += 256) { const float f = static_cast<float>(hist[i]); if (f > 0.0f) hsum += f * __log2f(total / f); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) hsum += __shfl_xor(hsum, off);
+    __syncthreads();
+    if (lane == 0) wsum[wave] = __float_as_uint(hsum);
+    __syncthreads();
+    const float H = __uint_as_float(wsum[0]) + __uint_as_float(wsum[1]) + __uint_as_float(wsum[2]) + __uint_as_float(wsum[3]);
+    s_skip = (0.999f * H + static_cast<float>(HDR_BITS)) >= 8.0f * static_cast<float>(5 + len) ? 1 : 0;      // every thread writes the same value
   }
   __syncthreads();
+  const bool skip = s_skip != 0;
+  if (!skip) {
+    // sort the used symbols by frequency (bitonic, 512 keys)
+    if (tid == 0) { s_ns = 0; s_ovf = 0; }
+    for (int i = tid; i < 17; i += 256) bl[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < 512; i += 256) keys[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int i = tid; i < NSYM; i += 256)
+      if (hist[i]) keys[atomicAdd(&s_ns, 1)] = (hist[i] << 9) | static_cast<uint32_t>(i);      // compacted, any order
+    __syncthreads();
+    int m = 2;
+    while (m < s_ns) m <<= 1;                 // bitonic sort of the next power of two (the tail is 0xFFFFFFFF)
+    for (int k = 2; k <= m; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < m; i += 256) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const uint32_t x = keys[i], y = keys[ixj];
+            const bool up = (i & k) == 0;
+            if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
+          }
+        }
+        __syncthreads();
+      }
+    const int ns = s_ns;                      // >= 2: the end-of-block symbol and at least one literal
+    // Huffman tree, two-queue merge over the sorted leaves: the one serial step (ns - 1 merges on one thread).
+    // Node weights live in outw[] (zeroed again before the bit stream is written).
+    uint32_t* wt = outw;
+    for (int i = tid; i < ns; i += 256) wt[i] = keys[i] >> 9;
+    __syncthreads();
+    if (tid == 0) {
+      int li = 0, ii = ns, nn = ns;           // next unused leaf, next unused internal node, nodes so far
+      for (int k = 0; k < ns - 1; ++k) {
+        int pick[2];
+        for (int t = 0; t < 2; ++t) {
+          if (li < ns && (ii >= nn || wt[li] <= wt[ii])) pick[t] = li++; else pick[t] = ii++;
+        }
+        wt[nn] = wt[pick[0]] + wt[pick[1]];
+        parent[pick[0]] = static_cast<uint16_t>(nn); parent[pick[1]] = static_cast<uint16_t>(nn);
+        ++nn;
+      }
+    }
+    __syncthreads();
+    // depth of every leaf (walk to the root), codes per length; more than 15 bits -> the zlib fix-up
+    const int root = 2 * ns - 2;
+    for (int i = tid; i < ns; i += 256) {
+      int d = 0, v = i;
+      while (v != root) { v = parent[v]; ++d; }
+      if (d > 15) { d = 15; atomicAdd(&s_ovf, 1); }
+      atomicAdd(&bl[d], 1);
+    }
+    __syncthreads();
+    if (tid == 0 && s_ovf > 0) {
+      int overflow = s_ovf;
+      while (overflow > 0) {
+        int bits = 14;
+        while (bl[bits] == 0) --bits;
+        --bl[bits]; bl[bits + 1] += 2; --bl[15];
+        overflow -= 2;
+      }
+    }
+    __syncthreads();
+    // lengths by frequency order (least frequent = longest), then canonical codes in symbol order, stored bit-reversed
+    // (deflate packs Huffman codes most significant bit first)
+    for (int i = tid; i < ns; i += 256) {
+      int c = 0, l = 1;
+      for (int bits = 15; bits >= 1; --bits) { c += bl[bits]; if (i < c) { l = bits; break; } }
+      clen[keys[i] & 511u] = static_cast<uint32_t>(l);
+    }
+    __syncthreads();
+    for (int s2 = tid; s2 < NSYM; s2 += 256) {
+      const int l = static_cast<int>(clen[s2]);
+      if (l) {
+        uint32_t cd = 0;
+        for (int bits = 1; bits <= l; ++bits) cd = (cd + static_cast<uint32_t>(bits > 1 ? bl[bits - 1] : 0)) << 1;      // first code of length l
+        int rank = 0;
+        for (int q = 0; q < s2; ++q) rank += (clen[q] == static_cast<uint32_t>(l)) ? 1 : 0;
+        code[s2] = rev_bits(cd + static_cast<uint32_t>(rank), l);
+      }
+    }
+    __syncthreads();
+  }
 
   // ---- D. bits per thread, exclusive scan, choice between the Huffman and the stored form
-  const int mybits = walk_span<1>(my, n, nullptr, clen, nullptr, nullptr);
+  const int mybits = skip ? 0 : walk_span<1>(my, n, nullptr, clen, nullptr, nullptr);
   int incl = mybits;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
@@ -259,11 +325,10 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
   int wave_base = 0;
   for (int k = 0; k < wave; ++k) wave_base += static_cast<int>(wsum[k]);
   const int total_tok_bits = static_cast<int>(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
-  const int lead = chunk == 0 ? 2 : 0;               // the zlib header travels with the first chunk
   const int my_start = lead * 8 + HDR_BITS + wave_base + incl - mybits;
   const int end_bit = lead * 8 + HDR_BITS + total_tok_bits + static_cast<int>(clen[256]);
   const int huff_bytes = (end_bit + 3 + 7) / 8 + 4;  // + the empty stored block that re-aligns to a byte
-  const bool stored = huff_bytes >= lead + 5 + len;
+  const bool stored = skip || huff_bytes >= lead + 5 + len;
   for (int i = tid; i < SLOT / 4; i += 256) outw[i] = 0;
   __syncthreads();
   uint8_t* outb = reinterpret_cast<uint8_t*>(outw);
@@ -308,6 +373,8 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
   __syncthreads();
 
   // ---- E. write the chunk to its slot; raw CRC of its bytes (each 16-byte unit shifted to the end of the chunk)
+  for (int i = tid; i < 1024; i += 256) area[i] = P.tables[i];          // the code tables are dead: the area now holds the CRC tables
+  __syncthreads();
   const int out_len = s_out_len;
   uint8_t* slot = P.slots + static_cast<size_t>(chunk) * SLOT;
   uint32_t crc = 0;
