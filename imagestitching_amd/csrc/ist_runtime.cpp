@@ -7,6 +7,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -423,6 +425,17 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   if (!files || !lens) return fail(IST_E_INVALID, "ist_stitch_files_png: NULL input");
   if (n_images > kMaxImages) return fail(IST_E_UNSUPPORTED, "more than 128 images in one launch");
   const int n = n_images;
+  // IST_TIMING=1: phase times of this call on stderr (diagnostics; the phases end with a stream sync only when it is on)
+  static const bool timing = std::getenv("IST_TIMING") != nullptr;
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto t_prev = now();
+  auto lap = [&](const char* what, hipStream_t st) {
+    if (!timing) return;
+    if (st) (void)hipStreamSynchronize(st);
+    const auto t = now();
+    std::fprintf(stderr, "[ist timing] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   // 1. host side of decoding, one thread per image
   struct Dec { int rc = 0; std::string err; bool jpeg = false; JpegImage J; int w = 0, h = 0, orient = 0; std::vector<uint8_t> px; };
   std::vector<Dec> dec(static_cast<size_t>(n));
@@ -448,6 +461,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
     if (dec[static_cast<size_t>(i)].rc != IST_OK)
       return fail(dec[static_cast<size_t>(i)].rc, "图片" + std::to_string(i) + "解码异常: " + dec[static_cast<size_t>(i)].err);   // index.js:1512-1514
 
+  lap("entropy decode (host threads)", nullptr);
   // 2. plan (orientation from the file, like getImageInfo -> index.js:734)
   std::vector<ist_image_desc> descs(static_cast<size_t>(n));
   for (int i = 0; i < n; ++i) {
@@ -490,6 +504,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   uint8_t* d = nullptr;
   IST_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
   struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
+  lap("plan + device arena", nullptr);
   std::vector<const void*> dsrc(static_cast<size_t>(n));
   std::vector<size_t> dpitch(static_cast<size_t>(n));
   for (int i = 0; i < n; ++i) {
@@ -514,6 +529,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
     rc = jpeg_launch_reconstruct(job, ctx->stream);
     if (rc) return rc;
   }
+  lap("H2D + JPEG reconstruct (GPU)", ctx->stream);
   // 4. the stitch: one fused launch from the decoded bitmaps (HBM) into the canvas (HBM)
   static const uint8_t transparent[4] = {0, 0, 0, 0};
   ist_job* job = ist_job_create(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, descs.data(), n, filter, nullptr);
@@ -521,14 +537,17 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   struct JobFree { ist_job* j; ~JobFree() { ist_job_destroy(j); } } jf{job};
   rc = ist_job_launch(job, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, ctx->stream);
   if (rc) return rc;
+  lap("compile + stitch launch", ctx->stream);
   // 5. PNG export on the device, then the only D2H of the call
   int64_t len = 0;
   rc = ist_png_encode_device(ctx, d + o_canvas, canvas_pitch, out_plan->canvas_w, out_plan->canvas_h, d + o_png, png_cap, &len, ctx->stream);
   if (rc) return rc;
+  lap("PNG encode (GPU)", ctx->stream);
   uint8_t* host = static_cast<uint8_t*>(std::malloc(static_cast<size_t>(len)));
   if (!host) return fail(IST_E_NOMEM, "out of memory for the PNG");
   if (hipMemcpyAsync(host, d + o_png, static_cast<size_t>(len), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess) { std::free(host); return fail(IST_E_HIP, "PNG readback failed"); }
+  lap("PNG D2H", nullptr);
   *out_png = host; *out_len = len;
   pg.keep = true;
   return IST_OK;
