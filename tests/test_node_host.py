@@ -155,6 +155,17 @@ def test_node_png_export(tmp_path):
                           "outDir": str(tmp_path)}, tmp_path)
     assert rc == 0, err
     assert np.array_equal(np.asarray(Image.open(meta["plan"]["file"]).convert("RGBA")), ref)
+    # opts.pngLevel: the same pixels, stored (0) or compressed on the GPU (1, the default)
+    flat = [np.full((48, 64, 4), 255, np.uint8) for _ in range(3)]
+    fimgs = _write_images(flat, tmp_path)
+    sizes = {}
+    for level in (0, 1):
+        o = tmp_path / ("lvl%d.png" % level)
+        rc, meta, err = _cli({"mode": "stitch", "png": True, "direction": "vertical", "opts": {"filter": "nearest", "pngLevel": level}, "images": fimgs, "out": str(o)}, tmp_path)
+        assert rc == 0, err
+        assert np.array_equal(np.asarray(Image.open(o).convert("RGBA")), np.concatenate(flat, 0))
+        sizes[level] = os.path.getsize(o)
+    assert sizes[0] > 3 * 48 * 64 * 4 and sizes[1] < 0.1 * sizes[0]
 
 
 @needs_node
