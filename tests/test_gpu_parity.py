@@ -338,3 +338,73 @@ def test_edge_antialiasing_known_answer():
         L.check(L.lib.ist_render_rgba8(_ctx(0), 2, 3, clear, ops, 2, descs, ptrs, pit, 1, filt | 0x100, None, out.ctypes.data, 8))
         assert out[:, 0, 0].tolist() == [64, 0, 191], out[:, 0, 0].tolist()      # floor(255*0.25+0.5), 0, floor(255*0.75+0.5)
         assert (out[..., 3] == 255).all()
+
+
+def test_random_op_lists_against_oracle():
+    """Differential test of the op-list surface (what the Canvas shim records): fills, draws under all eight
+    axis-aligned transforms at random scales, source rectangles that leave the bitmap, overlapping and translucent
+    draws, opaque or transparent canvases, all three coverage rules.  Nearest must be exact, bilinear within 1 LSB."""
+    import ctypes as C
+    from imagestitching_amd import _lib as L
+    from imagestitching_amd.stitch import _ctx
+    rng = np.random.default_rng(777)
+    worst = 0
+    for case in range(250):
+        cw, ch = int(rng.integers(8, 300)), int(rng.integers(8, 300))
+        n_img = int(rng.integers(1, 4))
+        px = [U.rand_image(900 + 7 * case + k, int(rng.integers(2, 120)), int(rng.integers(2, 120)), opaque=bool(rng.integers(0, 2))) for k in range(n_img)]
+        descs_o = [{"width": a.shape[1], "height": a.shape[0]} for a in px]
+        ops_o = []
+        if rng.integers(0, 2):
+            ops_o.append({"kind": "fill", "m": [1, 0, 0, 1, 0, 0], "rect": [0, 0, cw, ch], "rgba": tuple(int(v) for v in rng.integers(0, 256, 3)) + (255,)})
+        for _ in range(int(rng.integers(1, 6))):
+            k = int(rng.integers(0, n_img))
+            h, w = px[k].shape[:2]
+            sc = 1.0 if rng.integers(0, 3) == 0 else float(rng.uniform(0.3, 3.0))
+            t = int(rng.integers(0, 8))
+            sx, sy = (-sc if t & 1 else sc), (-sc if t & 2 else sc)
+            e, f = float(rng.integers(0, cw)), float(rng.integers(0, ch))
+            if rng.integers(0, 2):
+                e += float(rng.uniform(0, 1)); f += float(rng.uniform(0, 1))
+            m = [0, sx, sy, 0, e, f] if t & 4 else [sx, 0, 0, sy, e, f]
+            if rng.integers(0, 2):
+                s = [0, 0, w, h]
+            else:
+                s = [float(rng.uniform(-5, w / 2)), float(rng.uniform(-5, h / 2)), float(rng.uniform(1, w)), float(rng.uniform(1, h))]
+            d = [float(rng.uniform(-20, 20)), float(rng.uniform(-20, 20)), float(rng.uniform(4, 150)), float(rng.uniform(4, 150))]
+            if rng.integers(0, 3) == 0:
+                d = [round(v) for v in d]
+            ops_o.append({"kind": "draw", "image": k, "m": m, "s": s, "d": d})
+        clear = (0, 0, 0, 0) if rng.integers(0, 2) else tuple(int(v) for v in rng.integers(0, 256, 3)) + (255,)
+        filt = "nearest" if rng.integers(0, 2) else "bilinear"
+        aa = bool(rng.integers(0, 3) == 0)
+        ref = O.render_ops(cw, ch, ops_o, descs_o, px, filt, clear=clear, edge_aa=aa)
+        ops = (L.Op * len(ops_o))()
+        for i, o in enumerate(ops_o):
+            ops[i].m[:] = o["m"]
+            if o["kind"] == "fill":
+                ops[i].kind = 0; ops[i].image = -1; ops[i].d[:] = o["rect"]; ops[i].rgba[:] = o["rgba"]
+            else:
+                ops[i].kind = 1; ops[i].image = o["image"]; ops[i].s[:] = o["s"]; ops[i].d[:] = o["d"]
+        descs = (L.ImageDesc * n_img)(*[L.ImageDesc(a.shape[1], a.shape[0], 1, 0, 0, 0, 0) for a in px])
+        ptrs = (C.c_void_p * n_img)(*[a.ctypes.data for a in px])
+        pit = (C.c_size_t * n_img)(*[a.strides[0] for a in px])
+        out = np.zeros((ch, cw, 4), np.uint8)
+        f = {"nearest": 0, "bilinear": 1}[filt] | (0x100 if aa else 0)
+        L.check(L.lib.ist_render_rgba8(_ctx(0), cw, ch, (C.c_uint8 * 4)(*clear), ops, len(ops_o), descs, ptrs, pit, n_img, f, None, out.ctypes.data, out.strides[0]))
+        d = np.abs(out.astype(np.int16) - ref.astype(np.int16))
+        tol = 0 if filt == "nearest" and not aa else 1
+        solid = ref[..., 3] == 255                     # what the stitch path produces (the canvas is filled white first)
+        assert d[..., 3].max() <= tol, (case, filt, aa, ops_o)
+        if solid.any():
+            worst = max(worst, int(d[solid].max()))
+            assert d[solid].max() <= tol, (case, filt, aa, int(d[solid].max()), ops_o)
+        # a translucent pixel of a transparent canvas reads back un-premultiplied (c * 255 / a): one LSB of the
+        # premultiplied value becomes up to 255 / a LSBs of the colour
+        soft = ~solid & (ref[..., 3] > 0)
+        if soft.any() and tol:
+            lim = tol + np.ceil(255.0 / ref[..., 3][soft].astype(np.float64))
+            assert (d[..., :3][soft].max(axis=-1) <= lim).all(), (case, filt, aa, ops_o)
+        elif soft.any():
+            assert d[soft].max() == 0, (case, filt, aa, ops_o)
+    assert worst <= 1
