@@ -10,7 +10,7 @@ static void handler(int sig) {
   void* bt[64];
   int n = backtrace(bt, 64);
   const char* m = sig == SIGABRT ? "\n=== SIGABRT native backtrace ===\n" : "\n=== SIGSEGV native backtrace ===\n";
-  write(2, m, strlen(m));
+  if (write(2, m, strlen(m)) < 0) {}
   backtrace_symbols_fd(bt, n, 2);
   signal(sig, SIG_DFL);
   raise(sig);
