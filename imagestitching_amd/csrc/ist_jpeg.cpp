@@ -35,6 +35,9 @@ struct Huff {
   int32_t mincode[17];
   // 9-bit lookahead: (length << 8) | symbol, 0 = not resolved
   uint16_t look[512];
+  // AC tables only: when code + magnitude bits fit in the same 9 bits, the whole coefficient comes from one look-up:
+  // (value << 8) | (run << 4) | (code length + magnitude bits), 0 = take the general path
+  int16_t fast_ac[512];
   bool build() {                        // false: the code lengths over-subscribe the code space (a corrupt table)
     int code = 0, k = 0;
     for (int l = 1; l <= 16; ++l) {
@@ -56,6 +59,16 @@ struct Huff {
       }
       code <<= 1;
     }
+    for (int i = 0; i < 512; ++i) {
+      fast_ac[i] = 0;
+      const uint16_t e = look[i];
+      if (!e) continue;
+      const int len = e >> 8, rs = e & 0xFF, run = rs >> 4, mag = rs & 15;
+      if (mag == 0 || len + mag > 9) continue;
+      int k = ((i << len) & 511) >> (9 - mag);               // the magnitude bits that follow the code
+      if (k < (1 << (mag - 1))) k += -(1 << mag) + 1;        // EXTEND (T.81 F.2.2.1)
+      if (k >= -128 && k <= 127) fast_ac[i] = static_cast<int16_t>(k * 256 + run * 16 + len + mag);
+    }
     return true;
   }
 };
@@ -65,6 +78,17 @@ struct BitReader {
   uint64_t acc = 0; int n = 0;
   bool hit_marker = false;
   void fill() {
+    // fast path: the next six bytes hold no 0xFF (no stuffing, no marker): take them at once
+    if (n <= 16 && !hit_marker && end - p >= 8) {
+      uint64_t w = 0;
+      for (int i = 0; i < 8; ++i) w = (w << 8) | p[i];        // big-endian load (the compiler makes it a bswap)
+      const uint64_t v = ~w | 0xFFFFull;                      // only the upper six bytes are consumed
+      if (!((v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull)) {
+        acc |= (w >> 16) << (16 - n);
+        n += 48; p += 6;
+        return;
+      }
+    }
     while (n <= 56) {
       uint32_t b = 0;
       if (!hit_marker && p < end) {
@@ -219,7 +243,14 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
         JpegComp& C = J->comp[c];
         if (!have_q[C.tq]) return fail(IST_E_DECODE, "JPEG component uses an undefined quantisation table");
         std::memcpy(C.q, qt[C.tq], sizeof C.q);
-        if (C.coef.empty()) C.coef.assign(static_cast<size_t>(C.blocks_x) * C.blocks_y * 64, 0);
+        const size_t nblk = static_cast<size_t>(C.blocks_x) * C.blocks_y;
+        if (progressive) {
+          if (C.coef.empty() && !C.coef.alloc_zero(nblk * 64)) return fail(IST_E_NOMEM, "out of memory for the JPEG coefficients");
+        } else if (!C.sparse) {
+          C.sparse = true;
+          C.start.assign(nblk, 0); C.cnt.assign(nblk, 0);
+          C.ent.reserve(2 * static_cast<size_t>(n) + 1024);      // virtual only: a photo has ~1.3 entries per file byte, untouched pages cost nothing
+        }
       }
       BitReader br; br.p = d + dl; br.end = f + n;
       int pred[3] = {0, 0, 0}, eobrun = 0;
@@ -249,23 +280,42 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
             const int bh = interleaved ? C.h : 1, bv = interleaved ? C.v : 1;
             for (int by = 0; by < bv; ++by) for (int bx = 0; bx < bh; ++bx) {
               const int gx = x * bh + bx, gy = y * bv + by;
-              int16_t* blk = C.coef.data() + (static_cast<size_t>(gy) * C.blocks_x + gx) * 64;
-              if (!progressive) {
+              const size_t bi = static_cast<size_t>(gy) * C.blocks_x + gx;
+              int16_t* blk = progressive ? C.coef.data() + bi * 64 : nullptr;
+              if (!progressive) {                            // sequential: the block's non-zero coefficients as sparse entries
+                const size_t first = C.ent.size();
+                C.ent.resize(first + 64);                   // room for a whole block, trimmed below (no per-entry capacity check)
+                uint32_t* e = C.ent.data() + first;
                 int t = decode_symbol(br, dc[td[s]]);
                 if (t < 0 || t > 11) return fail(IST_E_DECODE, "corrupt JPEG entropy data (DC)");
                 const int diff = t ? extend(br.get(t), t) : 0;
                 pred[s] += diff;
-                blk[0] = static_cast<int16_t>(pred[s]);
+                if (pred[s]) *e++ = static_cast<uint32_t>(static_cast<uint16_t>(static_cast<int16_t>(pred[s])));
+                const Huff& hac = ac[ta[s]];
                 for (int k = 1; k < 64;) {
-                  const int rs = decode_symbol(br, ac[ta[s]]);
+                  const int fa = hac.fast_ac[br.peek(16) >> 7];
+                  if (fa) {                                  // run, value and both bit counts from one look-up
+                    k += (fa >> 4) & 15;
+                    if (k > 63) return fail(IST_E_DECODE, "corrupt JPEG entropy data (run)");
+                    br.skip(fa & 15);
+                    *e++ = (static_cast<uint32_t>(kZigzag[k]) << 16) | static_cast<uint16_t>(static_cast<int16_t>(fa >> 8));
+                    ++k;
+                    continue;
+                  }
+                  const int rs = decode_symbol(br, hac);
                   if (rs < 0) return fail(IST_E_DECODE, "corrupt JPEG entropy data (AC)");
                   const int r = rs >> 4, sz = rs & 15;
                   if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
                   k += r;
                   if (k > 63) return fail(IST_E_DECODE, "corrupt JPEG entropy data (run)");
-                  blk[kZigzag[k]] = static_cast<int16_t>(extend(br.get(sz), sz));
+                  const int v = extend(br.get(sz), sz);
+                  if (v) *e++ = (static_cast<uint32_t>(kZigzag[k]) << 16) | static_cast<uint16_t>(static_cast<int16_t>(v));
                   ++k;
                 }
+                const size_t used = static_cast<size_t>(e - (C.ent.data() + first));      // <= 64
+                C.ent.resize(first + used);
+                C.start[bi] = static_cast<uint32_t>(first);
+                C.cnt[bi] = static_cast<uint8_t>(used);
               } else if (dc_scan && Ah == 0) {               // DC first pass: the difference, scaled by 2^Al
                 const int t = decode_symbol(br, dc[td[s]]);
                 if (t < 0 || t > 11) return fail(IST_E_DECODE, "corrupt JPEG entropy data (DC)");
@@ -343,6 +393,15 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
   if (!have_sof) return fail(IST_E_DECODE, "JPEG without a frame header");
   if (!header_only && J->scans == 0) return fail(IST_E_DECODE, "JPEG without image data");
   return IST_OK;
+}
+
+std::vector<int16_t> jpeg_dense_coefficients(const JpegComp& c) {
+  const size_t nblk = static_cast<size_t>(c.blocks_x) * c.blocks_y;
+  std::vector<int16_t> d(nblk * 64, 0);
+  if (!c.sparse) { if (c.coef.size() == d.size()) std::memcpy(d.data(), c.coef.data(), d.size() * 2); return d; }
+  for (size_t b = 0; b < nblk; ++b)
+    for (uint32_t k = 0; k < c.cnt[b]; ++k) { const uint32_t e = c.ent[c.start[b] + k]; d[b * 64 + (e >> 16)] = static_cast<int16_t>(e & 0xFFFFu); }
+  return d;
 }
 
 }  // namespace ist

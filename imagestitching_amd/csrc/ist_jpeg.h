@@ -3,15 +3,46 @@
 #define IST_JPEG_H_
 
 #include <cstdint>
+#include <cstdlib>
+#include <utility>
 #include <vector>
 
 namespace ist {
+
+// Zero-initialised int16 plane from calloc: the kernel hands out zero pages on first touch, so there is no separate
+// 36 MB memset pass per 12 MP image (std::vector::assign writes every page before the decoder does).
+class CoefBuf {
+ public:
+  CoefBuf() = default;
+  ~CoefBuf() { std::free(p_); }
+  CoefBuf(const CoefBuf&) = delete;
+  CoefBuf& operator=(const CoefBuf&) = delete;
+  CoefBuf(CoefBuf&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+  CoefBuf& operator=(CoefBuf&& o) noexcept { if (this != &o) { std::free(p_); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
+  bool alloc_zero(size_t n) { std::free(p_); p_ = static_cast<int16_t*>(std::calloc(n ? n : 1, sizeof(int16_t))); n_ = p_ ? n : 0; return p_ != nullptr; }
+  bool empty() const { return n_ == 0; }
+  size_t size() const { return n_; }
+  int16_t* data() { return p_; }
+  const int16_t* data() const { return p_; }
+  const int16_t* begin() const { return p_; }
+  const int16_t* end() const { return p_ + n_; }
+ private:
+  int16_t* p_ = nullptr; size_t n_ = 0;
+};
 
 struct JpegComp {
   int id = 0, h = 1, v = 1, tq = 0;
   int blocks_x = 0, blocks_y = 0;      // padded to whole MCUs
   uint16_t q[64];                      // quantisation table, natural (row-major) order
-  std::vector<int16_t> coef;           // blocks_y * blocks_x blocks of 64 coefficients, natural order, NOT dequantised
+  CoefBuf coef;                        // DENSE form (progressive files): blocks_y * blocks_x blocks of 64 coefficients,
+                                       // natural order, NOT dequantised
+  // SPARSE form (sequential files: every block is coded exactly once): the non-zero coefficients only, in decoding
+  // order, entry = (natural-order index << 16) | uint16(value); block b (raster order) owns ent[start[b] .. +cnt[b]).
+  // A 12 MP photo is ~2.5 M entries (10 MB) instead of a 36 MB plane: less host memory to fault in, 4x less H2D;
+  // the GPU scatters the entries into a zeroed dense plane (jpeg_launch_scatter) in front of the IDCT.
+  bool sparse = false;
+  std::vector<uint32_t> ent, start;
+  std::vector<uint8_t> cnt;
 };
 
 struct JpegImage {
@@ -37,6 +68,10 @@ struct JpegDeviceJob {
   uint8_t* out; size_t out_pitch;
 };
 int jpeg_launch_reconstruct(const JpegDeviceJob& job, void* stream);
+// d_coef (zeroed by the caller) <- the sparse entries of n_blocks blocks.  Asynchronous on `stream`.
+int jpeg_launch_scatter(const uint32_t* d_ent, const uint32_t* d_start, const uint8_t* d_cnt, int16_t* d_coef, int n_blocks, void* stream);
+// host-side expansion of one component to the dense form (tests, tools)
+std::vector<int16_t> jpeg_dense_coefficients(const JpegComp& c);
 
 }  // namespace ist
 

@@ -83,6 +83,15 @@ __global__ __launch_bounds__(128) void ist_jpeg_idct_kernel(const IdctArgs A) {
   }
 }
 
+// sparse -> dense: one thread per block writes its non-zero coefficients into the (zeroed) plane
+__global__ __launch_bounds__(256) void ist_jpeg_scatter_kernel(const uint32_t* ent, const uint32_t* start, const uint8_t* cnt, int16_t* coef, int n_blocks) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_blocks) return;
+  const uint32_t s0 = start[b], n = cnt[b];
+  int16_t* c = coef + static_cast<size_t>(b) * 64;
+  for (uint32_t k = 0; k < n; ++k) { const uint32_t e = ent[s0 + k]; c[(e >> 16) & 63u] = static_cast<int16_t>(e & 0xFFFFu); }
+}
+
 struct ColorArgs {
   const uint8_t* Y; const uint8_t* Cb; const uint8_t* Cr;
   int pitch_y, pitch_c;            // plane row pitches
@@ -157,6 +166,14 @@ __global__ __launch_bounds__(256) void ist_jpeg_color_kernel(const ColorArgs A) 
 }
 
 }  // namespace
+
+int jpeg_launch_scatter(const uint32_t* d_ent, const uint32_t* d_start, const uint8_t* d_cnt, int16_t* d_coef, int n_blocks, void* stream_) {
+  if (n_blocks <= 0) return IST_OK;
+  hipLaunchKernelGGL(ist_jpeg_scatter_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream_), d_ent, d_start, d_cnt, d_coef, n_blocks);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(IST_E_HIP, std::string("JPEG scatter launch failed: ") + hipGetErrorString(e));
+  return IST_OK;
+}
 
 int jpeg_launch_reconstruct(const JpegDeviceJob& J, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);

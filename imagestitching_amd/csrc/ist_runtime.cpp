@@ -341,6 +341,56 @@ int ist_stitch_png(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* co
 }
 
 // ---- JPEG decode: entropy decoding on the host, reconstruction on the GPU (ist_jpeg.cpp / ist_jpeg_kernels.hip) ----------
+extern "C++" {
+namespace {
+struct JpegDevLayout { size_t coef[3], q[3], plane[3], ent[3], start[3], cnt[3]; };
+
+// device bytes one decoded image needs, carved from the caller's arena at *off (256-byte granules)
+void jpeg_layout(const JpegImage& J, size_t* off, JpegDevLayout* L) {
+  auto take = [&](size_t bytes) { const size_t at = *off; *off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
+  std::memset(L, 0, sizeof(*L));
+  for (int c = 0; c < J.ncomp; ++c) {
+    const JpegComp& C = J.comp[c];
+    const size_t nblk = static_cast<size_t>(C.blocks_x) * C.blocks_y;
+    L->coef[c] = take(nblk * 128);
+    L->q[c] = take(128);
+    L->plane[c] = take(nblk * 64);
+    if (C.sparse) { L->ent[c] = take(C.ent.size() * 4 + 4); L->start[c] = take(nblk * 4); L->cnt[c] = take(nblk); }
+  }
+}
+
+// H2D of the coefficients (sparse entries are scattered into a zeroed plane on the GPU) + the reconstruction launches
+int jpeg_enqueue(const JpegImage& J, uint8_t* d, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch, hipStream_t stream) {
+  JpegDeviceJob job;
+  job.width = J.width; job.height = J.height; job.ncomp = J.ncomp; job.hmax = J.hmax; job.vmax = J.vmax;
+  for (int c = 0; c < 3; ++c) { job.d_coef[c] = nullptr; job.d_q[c] = nullptr; job.d_plane[c] = nullptr; job.h[c] = job.v[c] = 1; job.blocks_x[c] = job.blocks_y[c] = 0; }
+  for (int c = 0; c < J.ncomp; ++c) {
+    const JpegComp& C = J.comp[c];
+    const size_t nblk = static_cast<size_t>(C.blocks_x) * C.blocks_y;
+    int16_t* d_coef = reinterpret_cast<int16_t*>(d + L.coef[c]);
+    if (C.sparse) {
+      IST_HIP(hipMemsetAsync(d_coef, 0, nblk * 128, stream));
+      if (!C.ent.empty()) IST_HIP(hipMemcpyAsync(d + L.ent[c], C.ent.data(), C.ent.size() * 4, hipMemcpyHostToDevice, stream));
+      IST_HIP(hipMemcpyAsync(d + L.start[c], C.start.data(), nblk * 4, hipMemcpyHostToDevice, stream));
+      IST_HIP(hipMemcpyAsync(d + L.cnt[c], C.cnt.data(), nblk, hipMemcpyHostToDevice, stream));
+      const int rc = jpeg_launch_scatter(reinterpret_cast<const uint32_t*>(d + L.ent[c]), reinterpret_cast<const uint32_t*>(d + L.start[c]), d + L.cnt[c], d_coef, static_cast<int>(nblk), stream);
+      if (rc) return rc;
+    } else {
+      if (C.coef.size() != nblk * 64) return fail(IST_E_DECODE, "JPEG component without coefficients");
+      IST_HIP(hipMemcpyAsync(d_coef, C.coef.data(), nblk * 128, hipMemcpyHostToDevice, stream));
+    }
+    IST_HIP(hipMemcpyAsync(d + L.q[c], C.q, 128, hipMemcpyHostToDevice, stream));
+    job.d_coef[c] = d_coef;
+    job.d_q[c] = reinterpret_cast<const uint16_t*>(d + L.q[c]);
+    job.d_plane[c] = d + L.plane[c];
+    job.h[c] = C.h; job.v[c] = C.v; job.blocks_x[c] = C.blocks_x; job.blocks_y[c] = C.blocks_y;
+  }
+  job.out = d_out; job.out_pitch = out_pitch;
+  return jpeg_launch_reconstruct(job, stream);
+}
+}  // namespace
+}  // extern "C++"
+
 int ist_jpeg_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation) {
   JpegImage J;
   const int rc = jpeg_parse_and_entropy_decode(file, len, &J, true);
@@ -360,31 +410,16 @@ int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   // one device allocation: coefficients + tables + sample planes + RGBA
-  size_t off = 0, o_coef[3] = {0, 0, 0}, o_q[3] = {0, 0, 0}, o_plane[3] = {0, 0, 0};
+  size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
-  for (int c = 0; c < J.ncomp; ++c) {
-    o_coef[c] = take(J.comp[c].coef.size() * 2);
-    o_q[c] = take(128);
-    o_plane[c] = take(static_cast<size_t>(J.comp[c].blocks_x) * 8 * J.comp[c].blocks_y * 8);
-  }
+  JpegDevLayout L;
+  jpeg_layout(J, &off, &L);
   const size_t row = static_cast<size_t>(J.width) * 4;
   const size_t o_out = take(row * J.height);
   uint8_t* d = nullptr;
   IST_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
   struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
-  JpegDeviceJob job;
-  job.width = J.width; job.height = J.height; job.ncomp = J.ncomp; job.hmax = J.hmax; job.vmax = J.vmax;
-  for (int c = 0; c < 3; ++c) { job.d_coef[c] = nullptr; job.d_q[c] = nullptr; job.d_plane[c] = nullptr; job.h[c] = job.v[c] = 1; job.blocks_x[c] = job.blocks_y[c] = 0; }
-  for (int c = 0; c < J.ncomp; ++c) {
-    IST_HIP(hipMemcpyAsync(d + o_coef[c], J.comp[c].coef.data(), J.comp[c].coef.size() * 2, hipMemcpyHostToDevice, ctx->stream));
-    IST_HIP(hipMemcpyAsync(d + o_q[c], J.comp[c].q, 128, hipMemcpyHostToDevice, ctx->stream));
-    job.d_coef[c] = reinterpret_cast<const int16_t*>(d + o_coef[c]);
-    job.d_q[c] = reinterpret_cast<const uint16_t*>(d + o_q[c]);
-    job.d_plane[c] = d + o_plane[c];
-    job.h[c] = J.comp[c].h; job.v[c] = J.comp[c].v; job.blocks_x[c] = J.comp[c].blocks_x; job.blocks_y[c] = J.comp[c].blocks_y;
-  }
-  job.out = d + o_out; job.out_pitch = row;
-  rc = jpeg_launch_reconstruct(job, ctx->stream);
+  rc = jpeg_enqueue(J, d, L, d + o_out, row, ctx->stream);
   if (rc) return rc;
   IST_HIP(copy_rows(out, out_pitch, d + o_out, row, row, static_cast<size_t>(J.height), hipMemcpyDeviceToHost, ctx->stream));
   IST_HIP(hipStreamSynchronize(ctx->stream));
@@ -486,16 +521,11 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
   std::vector<size_t> o_img(static_cast<size_t>(n));
-  struct JOff { size_t coef[3], q[3], plane[3]; };
-  std::vector<JOff> jo(static_cast<size_t>(n));
+  std::vector<JpegDevLayout> jo(static_cast<size_t>(n));
   for (int i = 0; i < n; ++i) {
     const Dec& D = dec[static_cast<size_t>(i)];
     o_img[static_cast<size_t>(i)] = take(static_cast<size_t>(D.w) * 4 * D.h);
-    if (D.jpeg) for (int c = 0; c < D.J.ncomp; ++c) {
-      jo[static_cast<size_t>(i)].coef[c] = take(D.J.comp[c].coef.size() * 2);
-      jo[static_cast<size_t>(i)].q[c] = take(128);
-      jo[static_cast<size_t>(i)].plane[c] = take(static_cast<size_t>(D.J.comp[c].blocks_x) * 8 * D.J.comp[c].blocks_y * 8);
-    }
+    if (D.jpeg) jpeg_layout(D.J, &off, &jo[static_cast<size_t>(i)]);
   }
   const size_t canvas_pitch = static_cast<size_t>(out_plan->canvas_w) * 4;
   const size_t o_canvas = take(canvas_pitch * static_cast<size_t>(out_plan->canvas_h));
@@ -513,20 +543,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
     const size_t row = static_cast<size_t>(D.w) * 4;
     dsrc[static_cast<size_t>(i)] = img; dpitch[static_cast<size_t>(i)] = row;
     if (!D.jpeg) { IST_HIP(hipMemcpyAsync(img, D.px.data(), D.px.size(), hipMemcpyHostToDevice, ctx->stream)); continue; }
-    JpegDeviceJob job;
-    job.width = D.w; job.height = D.h; job.ncomp = D.J.ncomp; job.hmax = D.J.hmax; job.vmax = D.J.vmax;
-    for (int c = 0; c < 3; ++c) { job.d_coef[c] = nullptr; job.d_q[c] = nullptr; job.d_plane[c] = nullptr; job.h[c] = job.v[c] = 1; job.blocks_x[c] = job.blocks_y[c] = 0; }
-    for (int c = 0; c < D.J.ncomp; ++c) {
-      const JOff& o = jo[static_cast<size_t>(i)];
-      IST_HIP(hipMemcpyAsync(d + o.coef[c], D.J.comp[c].coef.data(), D.J.comp[c].coef.size() * 2, hipMemcpyHostToDevice, ctx->stream));
-      IST_HIP(hipMemcpyAsync(d + o.q[c], D.J.comp[c].q, 128, hipMemcpyHostToDevice, ctx->stream));
-      job.d_coef[c] = reinterpret_cast<const int16_t*>(d + o.coef[c]);
-      job.d_q[c] = reinterpret_cast<const uint16_t*>(d + o.q[c]);
-      job.d_plane[c] = d + o.plane[c];
-      job.h[c] = D.J.comp[c].h; job.v[c] = D.J.comp[c].v; job.blocks_x[c] = D.J.comp[c].blocks_x; job.blocks_y[c] = D.J.comp[c].blocks_y;
-    }
-    job.out = img; job.out_pitch = row;
-    rc = jpeg_launch_reconstruct(job, ctx->stream);
+    rc = jpeg_enqueue(D.J, d, jo[static_cast<size_t>(i)], img, row, ctx->stream);
     if (rc) return rc;
   }
   lap("H2D + JPEG reconstruct (GPU)", ctx->stream);

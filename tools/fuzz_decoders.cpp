@@ -48,7 +48,7 @@ static int coef_hashes(int argc, char** argv) {
     const int rc = ist::jpeg_parse_and_entropy_decode(f.data(), int64_t(f.size()), &J, false);
     if (rc != IST_OK) { printf("%s error %d %s\n", argv[a], rc, ist_last_error()); continue; }
     uint64_t h = 1469598103934665603ull;
-    for (int c = 0; c < J.ncomp; ++c) for (int16_t v : J.comp[c].coef) { h ^= uint16_t(v); h *= 1099511628211ull; }
+    for (int c = 0; c < J.ncomp; ++c) for (int16_t v : ist::jpeg_dense_coefficients(J.comp[c])) { h ^= uint16_t(v); h *= 1099511628211ull; }
     printf("%s %dx%d scans=%d %016llx\n", argv[a], J.width, J.height, J.scans, (unsigned long long)h);
   }
   return 0;
