@@ -5,7 +5,7 @@
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(dirname "$HERE"); C=$ROOT/imagestitching_amd/csrc
 OUT=${IST_FUZZ_BIN:-/tmp/ist_fuzz}
-FLAGS="-std=c++17 -O1 -g -fsanitize=address,undefined,float-cast-overflow -fno-sanitize-recover=undefined,float-cast-overflow -ffp-contract=off -I$ROOT/include -I$C"
+FLAGS="-std=c++17 -O1 -g -fsanitize=address,undefined,float-cast-overflow -fno-sanitize-recover=undefined,float-cast-overflow -ffp-contract=off -DIST_FUZZ_NO_CRC -I$ROOT/include -I$C"
 export ASAN_OPTIONS=detect_leaks=0:allocator_may_return_null=1
 if [ "$1" = compile ]; then
   shift
