@@ -146,7 +146,7 @@ int exif_orientation(const uint8_t* d, size_t n) {
 
 }  // namespace
 
-int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, bool header_only) {
+int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, bool header_only, JpegGpuScan* gs) {
   if (!f || n < 4 || f[0] != 0xFF || f[1] != 0xD8) return fail(IST_E_DECODE, "not a JPEG file");
   Huff dc[4], ac[4];
   uint16_t qt[4][64]; bool have_q[4] = {false, false, false, false};
@@ -237,6 +237,46 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
       const bool dc_scan = Ss == 0, need_ac = !progressive || !dc_scan, need_dc = dc_scan && Ah == 0;
       for (int s = 0; s < ns; ++s) {
         if ((need_dc && !dc[td[s]].present) || (need_ac && !ac[ta[s]].present)) return fail(IST_E_DECODE, "JPEG scan uses an undefined Huffman table");
+      }
+      // the GPU entropy decoder takes baseline files whose single scan interleaves all components, without restarts
+      if (gs && !progressive && J->scans == 0 && ns == J->ncomp && restart_interval == 0) {
+        for (int c = 0; c < J->ncomp; ++c) {
+          if (!have_q[J->comp[c].tq]) return fail(IST_E_DECODE, "JPEG component uses an undefined quantisation table");
+          std::memcpy(J->comp[c].q, qt[J->comp[c].tq], sizeof J->comp[c].q);
+        }
+        gs->slots = 0;
+        for (int s2 = 0; s2 < ns; ++s2) {
+          const JpegComp& C = J->comp[ci[s2]];
+          for (int k = 0; k < C.h * C.v; ++k) { gs->slot_comp[gs->slots] = static_cast<uint8_t>(ci[s2]); gs->slot_idx[gs->slots] = static_cast<uint8_t>(k); ++gs->slots; }
+          gs->dc_tab[ci[s2]] = static_cast<uint8_t>(td[s2]); gs->ac_tab[ci[s2]] = static_cast<uint8_t>(4 + ta[s2]);
+        }
+        for (int t = 0; t < 8; ++t) {
+          const Huff& h = t < 4 ? dc[t] : ac[t - 4];
+          JpegHuffTable& o = gs->tables[t];
+          std::memset(&o, 0, sizeof o);
+          if (!h.present) { for (int l = 0; l < 18; ++l) o.maxcode[l] = -1; continue; }
+          std::memcpy(o.look, h.look, sizeof o.look);
+          o.maxcode[0] = -1; o.maxcode[17] = 0x7FFFFFFF;
+          for (int l = 1; l <= 16; ++l) { o.maxcode[l] = h.maxcode[l]; o.valoff[l] = h.valptr[l] - h.mincode[l]; }
+          std::memcpy(o.vals, h.vals, sizeof o.vals);
+        }
+        // de-stuff: FF 00 -> FF; the scan ends at the first real marker
+        const uint8_t* q = d + dl; const uint8_t* qe = f + n;
+        gs->stream.clear(); gs->stream.reserve(static_cast<size_t>(qe - q) + 16);
+        while (q < qe) {
+          const uint8_t* ff = static_cast<const uint8_t*>(std::memchr(q, 0xFF, static_cast<size_t>(qe - q)));
+          if (!ff) { gs->stream.insert(gs->stream.end(), q, qe); q = qe; break; }
+          gs->stream.insert(gs->stream.end(), q, ff);
+          if (ff + 1 < qe && ff[1] == 0x00) { gs->stream.push_back(0xFF); q = ff + 2; continue; }
+          if (ff + 1 < qe && ff[1] == 0xFF) { q = ff + 1; continue; }            // fill byte
+          q = ff; break;                                                          // a marker (or a lone FF at the end)
+        }
+        gs->bits = static_cast<int64_t>(gs->stream.size()) * 8;
+        gs->stream.insert(gs->stream.end(), 16, 0);
+        gs->eligible = true;
+        pos = q - f;
+        J->scans++;
+        continue;
       }
       // allocate coefficient planes on first use; copy the quantisation tables in use
       for (int c = 0; c < J->ncomp; ++c) {

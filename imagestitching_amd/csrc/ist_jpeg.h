@@ -53,9 +53,28 @@ struct JpegImage {
   JpegComp comp[3];
 };
 
+// ---- what the GPU entropy decoder (ist_jpeg_gpu.hip) needs from the container: the de-stuffed scan and its tables ----
+struct JpegHuffTable {                 // one Huffman table in the form both decoders use
+  uint16_t look[512];                  // 9-bit look-ahead: (length << 8) | symbol, 0 = longer than 9 bits
+  int32_t maxcode[18];                 // largest code of each length (-1: none)
+  int32_t valoff[17];                  // vals index = code + valoff[length]
+  uint8_t vals[256];
+};
+struct JpegGpuScan {
+  bool eligible = false;               // baseline, ONE interleaved scan over all components, no restart interval
+  std::vector<uint8_t> stream;         // entropy-coded bytes with the FF00 stuffing removed, + 16 zero bytes
+  int64_t bits = 0;                    // valid bits in stream
+  int slots = 0;                       // blocks per MCU
+  uint8_t slot_comp[10], slot_idx[10]; // per MCU slot: component, block index inside the component's h x v group
+  uint8_t dc_tab[3], ac_tab[3];        // per component: index into tables[] (0-3 DC, 4-7 AC)
+  JpegHuffTable tables[8];
+};
+
 // container parsing + Huffman decoding (host).  header_only stops after the frame header (size, sampling, orientation
 // if the EXIF segment precedes it).  Returns IST_OK or an error code with the thread-local message set.
-int jpeg_parse_and_entropy_decode(const uint8_t* file, int64_t len, JpegImage* out, bool header_only);
+int jpeg_parse_and_entropy_decode(const uint8_t* file, int64_t len, JpegImage* out, bool header_only, JpegGpuScan* gpu_scan = nullptr);
+// With gpu_scan: when the file qualifies (gpu_scan->eligible) the scan is NOT decoded on the host; the components then
+// carry neither dense nor sparse coefficients and jpeg_gpu_entropy_decode fills the device planes.
 
 // GPU stages (ist_jpeg_kernels.hip): coefficient planes (device) -> RGBA8 (device).  d_coef[c] / d_q[c] per component,
 // planes = scratch for the reconstructed sample planes.  Asynchronous on `stream`.
@@ -72,6 +91,12 @@ int jpeg_launch_reconstruct(const JpegDeviceJob& job, void* stream);
 int jpeg_launch_scatter(const uint32_t* d_ent, const uint32_t* d_start, const uint8_t* d_cnt, int16_t* d_coef, int n_blocks, void* stream);
 // host-side expansion of one component to the dense form (tests, tools)
 std::vector<int16_t> jpeg_dense_coefficients(const JpegComp& c);
+
+// GPU entropy decoding of a batch of eligible images (self-synchronising parallel Huffman decoding).  d_coef[c] are the
+// dense device planes (blocks_x*blocks_y*64 int16 each) the reconstruction kernels read.  ok[i] = 0 when image i failed
+// the end-of-scan validation: the caller then decodes that image on the host.  Synchronises `stream`.
+struct JpegGpuItem { const JpegImage* J; const JpegGpuScan* S; int16_t* d_coef[3]; };
+int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<uint8_t>* ok, void* stream);
 
 }  // namespace ist
 

@@ -360,7 +360,7 @@ void jpeg_layout(const JpegImage& J, size_t* off, JpegDevLayout* L) {
 }
 
 // H2D of the coefficients (sparse entries are scattered into a zeroed plane on the GPU) + the reconstruction launches
-int jpeg_enqueue(const JpegImage& J, uint8_t* d, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch, hipStream_t stream) {
+int jpeg_enqueue(const JpegImage& J, uint8_t* d, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch, hipStream_t stream, bool coef_on_device = false) {
   JpegDeviceJob job;
   job.width = J.width; job.height = J.height; job.ncomp = J.ncomp; job.hmax = J.hmax; job.vmax = J.vmax;
   for (int c = 0; c < 3; ++c) { job.d_coef[c] = nullptr; job.d_q[c] = nullptr; job.d_plane[c] = nullptr; job.h[c] = job.v[c] = 1; job.blocks_x[c] = job.blocks_y[c] = 0; }
@@ -368,7 +368,9 @@ int jpeg_enqueue(const JpegImage& J, uint8_t* d, const JpegDevLayout& L, uint8_t
     const JpegComp& C = J.comp[c];
     const size_t nblk = static_cast<size_t>(C.blocks_x) * C.blocks_y;
     int16_t* d_coef = reinterpret_cast<int16_t*>(d + L.coef[c]);
-    if (C.sparse) {
+    if (coef_on_device) {
+      // the GPU entropy decoder already filled the plane
+    } else if (C.sparse) {
       IST_HIP(hipMemsetAsync(d_coef, 0, nblk * 128, stream));
       if (!C.ent.empty()) IST_HIP(hipMemcpyAsync(d + L.ent[c], C.ent.data(), C.ent.size() * 4, hipMemcpyHostToDevice, stream));
       IST_HIP(hipMemcpyAsync(d + L.start[c], C.start.data(), nblk * 4, hipMemcpyHostToDevice, stream));
@@ -472,7 +474,9 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
     t_prev = t;
   };
   // 1. host side of decoding, one thread per image
-  struct Dec { int rc = 0; std::string err; bool jpeg = false; JpegImage J; int w = 0, h = 0, orient = 0; std::vector<uint8_t> px; };
+  struct Dec { int rc = 0; std::string err; bool jpeg = false; JpegImage J; JpegGpuScan G; int w = 0, h = 0, orient = 0; std::vector<uint8_t> px; };
+  // baseline JPEGs: Huffman decoding on the GPU (ist_jpeg_gpu.hip); IST_JPEG_HOST_HUFFMAN=1 keeps it on the host threads
+  static const bool gpu_huffman = std::getenv("IST_JPEG_HOST_HUFFMAN") == nullptr;
   std::vector<Dec> dec(static_cast<size_t>(n));
   {
     std::vector<std::thread> th;
@@ -481,7 +485,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
       const uint8_t* f = files[i]; const int64_t len = lens[i];
       D.jpeg = f && len >= 2 && f[0] == 0xFF && f[1] == 0xD8;
       if (D.jpeg) {
-        D.rc = jpeg_parse_and_entropy_decode(f, len, &D.J, false);
+        D.rc = jpeg_parse_and_entropy_decode(f, len, &D.J, false, gpu_huffman ? &D.G : nullptr);
         D.w = D.J.width; D.h = D.J.height; D.orient = D.J.orientation;
       } else {                 // PNG, BMP, GIF: host decoders
         int32_t w = 0, h = 0, o = 0;
@@ -496,7 +500,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
     if (dec[static_cast<size_t>(i)].rc != IST_OK)
       return fail(dec[static_cast<size_t>(i)].rc, "图片" + std::to_string(i) + "解码异常: " + dec[static_cast<size_t>(i)].err);   // index.js:1512-1514
 
-  lap("entropy decode (host threads)", nullptr);
+  lap("decode on host threads", nullptr);
   // 2. plan (orientation from the file, like getImageInfo -> index.js:734)
   std::vector<ist_image_desc> descs(static_cast<size_t>(n));
   for (int i = 0; i < n; ++i) {
@@ -535,6 +539,40 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   IST_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
   struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
   lap("plan + device arena", nullptr);
+  // entropy decoding of the eligible JPEGs on the GPU; an image that fails its validation goes back to the host decoder
+  {
+    std::vector<JpegGpuItem> items; std::vector<int> who;
+    for (int i = 0; i < n; ++i) {
+      Dec& D = dec[static_cast<size_t>(i)];
+      if (!D.jpeg || !D.G.eligible) continue;
+      JpegGpuItem it; it.J = &D.J; it.S = &D.G;
+      for (int c = 0; c < 3; ++c) it.d_coef[c] = c < D.J.ncomp ? reinterpret_cast<int16_t*>(d + jo[static_cast<size_t>(i)].coef[c]) : nullptr;
+      items.push_back(it); who.push_back(i);
+    }
+    std::vector<uint8_t> okv;
+    rc = jpeg_gpu_entropy_decode(items, &okv, ctx->stream);
+    if (rc) return rc;
+    for (size_t k = 0; k < who.size(); ++k) {
+      if (okv[k]) continue;
+      Dec& D = dec[static_cast<size_t>(who[k])];
+      D.G.eligible = false;
+      JpegImage host;
+      rc = jpeg_parse_and_entropy_decode(files[who[k]], lens[who[k]], &host, false, nullptr);
+      if (rc) return fail(rc, "图片" + std::to_string(who[k]) + "解码异常: " + g_last_error);
+      // the arena has no room for sparse entries of this image: upload the dense planes
+      for (int c = 0; c < host.ncomp; ++c) {
+        const std::vector<int16_t> dense = jpeg_dense_coefficients(host.comp[c]);
+        IST_HIP(hipMemcpy(d + jo[static_cast<size_t>(who[k])].coef[c], dense.data(), dense.size() * 2, hipMemcpyHostToDevice));
+      }
+      D.G.eligible = true;          // (the planes are on the device now: enqueue skips the upload)
+    }
+    if (timing) {
+      int good = 0;
+      for (uint8_t v : okv) good += v ? 1 : 0;
+      std::fprintf(stderr, "[ist timing] GPU Huffman: %d of %zu eligible JPEGs decoded on the GPU, %zu went back to the host decoder\n", good, okv.size(), okv.size() - static_cast<size_t>(good));
+    }
+    lap("entropy decode (GPU)", ctx->stream);
+  }
   std::vector<const void*> dsrc(static_cast<size_t>(n));
   std::vector<size_t> dpitch(static_cast<size_t>(n));
   for (int i = 0; i < n; ++i) {
@@ -543,7 +581,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
     const size_t row = static_cast<size_t>(D.w) * 4;
     dsrc[static_cast<size_t>(i)] = img; dpitch[static_cast<size_t>(i)] = row;
     if (!D.jpeg) { IST_HIP(hipMemcpyAsync(img, D.px.data(), D.px.size(), hipMemcpyHostToDevice, ctx->stream)); continue; }
-    rc = jpeg_enqueue(D.J, d, jo[static_cast<size_t>(i)], img, row, ctx->stream);
+    rc = jpeg_enqueue(D.J, d, jo[static_cast<size_t>(i)], img, row, ctx->stream, D.G.eligible);
     if (rc) return rc;
   }
   lap("H2D + JPEG reconstruct (GPU)", ctx->stream);

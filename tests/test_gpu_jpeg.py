@@ -112,3 +112,59 @@ def test_jpeg_unsupported_and_damaged_files():
     with pytest.raises(ist.StitchError) as e:
         ist.decode_image(good[:len(good) // 3])
     assert e.value.code == -6
+
+
+@pytest.mark.parametrize("subsampling,quality,optimize", [(0, 92, False), (1, 85, True), (2, 75, False), (2, 96, True), (2, 30, False)])
+def test_gpu_entropy_decoder_in_the_file_pipeline(tmp_path, subsampling, quality, optimize):
+    """stitch_files decodes baseline JPEGs with the GPU Huffman decoder (ist_jpeg_gpu.hip): same-width images stitched
+    vertically with the nearest filter are a pure concatenation, so the PNG must hold PIL's pixels bit for bit."""
+    paths, want = [], []
+    for k, (h, w) in enumerate([(203, 317), (64, 317), (411, 317), (8, 317)]):
+        a = _photo(40 + 5 * k + subsampling, h, w)
+        data = _jpeg(a, quality=quality, subsampling=subsampling, optimize=optimize)
+        p = tmp_path / ("g%d.jpg" % k)
+        p.write_bytes(data)
+        paths.append(str(p))
+        want.append(_pil(data))
+    grey = io.BytesIO()
+    Image.fromarray(_photo(77, 100, 317)).convert("L").save(grey, "JPEG", quality=80)
+    (tmp_path / "grey.jpg").write_bytes(grey.getvalue())
+    paths.append(str(tmp_path / "grey.jpg"))
+    want.append(_pil(grey.getvalue()))
+    res = ist.stitch_files(paths, "vertical", {"filter": "nearest"})
+    assert np.array_equal(ist.decode_png(res["png"]), np.concatenate(want, 0))
+
+
+def test_gpu_entropy_decoder_full_size_and_mixed_inputs(tmp_path):
+    """a 12 MP 4:2:0 photo (15 000 subsequences), a progressive file and a PNG in one call: GPU Huffman, host Huffman and
+    host inflate side by side"""
+    a = _photo(91, 3024, 4032)
+    base = _jpeg(a, quality=88, subsampling=2)
+    prog = _jpeg(_photo(92, 240, 4032), quality=80, subsampling=2, progressive=True)
+    (tmp_path / "a.jpg").write_bytes(base)
+    (tmp_path / "b.jpg").write_bytes(prog)
+    Image.fromarray(_photo(93, 100, 4032)).save(tmp_path / "c.png")
+    res = ist.stitch_files([str(tmp_path / "a.jpg"), str(tmp_path / "b.jpg"), str(tmp_path / "c.png")], "vertical", {"filter": "nearest"})
+    want = np.concatenate([_pil(base), _pil(prog), np.asarray(Image.open(tmp_path / "c.png").convert("RGBA"))], 0)
+    assert np.array_equal(ist.decode_png(res["png"]), want)
+
+
+def test_gpu_entropy_decoder_hands_damaged_scans_to_the_host_decoder(tmp_path):
+    a = _photo(95, 120, 160)
+    good = _jpeg(a, quality=85, subsampling=2)
+    sos = good.find(b"\xff\xda")
+    bad = bytearray(good)
+    for i in range(sos + 40, len(bad) - 2, 97):           # flip bits all over the scan: block count / codes go wrong
+        bad[i] ^= 0x55
+        if bad[i] == 0xFF:
+            bad[i] = 0x7F
+    (tmp_path / "good.jpg").write_bytes(good)
+    (tmp_path / "bad.jpg").write_bytes(bytes(bad))
+    res = ist.stitch_files([str(tmp_path / "good.jpg")], "vertical", {"filter": "nearest"})
+    assert np.array_equal(ist.decode_png(res["png"]), _pil(good))
+    try:                                                     # either the host decoder rejects it, or both decoders agree
+        res = ist.stitch_files([str(tmp_path / "bad.jpg")], "vertical", {"filter": "nearest"})
+    except ist.StitchError as e:
+        assert "解码异常" in str(e)
+    else:
+        assert np.array_equal(ist.decode_png(res["png"]), ist.decode_image(bytes(bad)))
