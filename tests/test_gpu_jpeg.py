@@ -168,3 +168,47 @@ def test_gpu_entropy_decoder_hands_damaged_scans_to_the_host_decoder(tmp_path):
         assert "解码异常" in str(e)
     else:
         assert np.array_equal(ist.decode_png(res["png"]), ist.decode_image(bytes(bad)))
+
+
+def test_gpu_entropy_decoder_agrees_with_the_host_decoder_on_mutated_scans(tmp_path):
+    """Mutation fuzzing on the GPU box: whatever a damaged scan looks like, the file pipeline (GPU Huffman with its
+    validation + host fall-back) must behave like the host decoder alone: the same pixels, or an error from both."""
+    rng = np.random.default_rng(4242)
+    seeds = [_jpeg(_photo(60, 120, 160), quality=85, subsampling=2), _jpeg(_photo(61, 97, 131), quality=60, subsampling=0, optimize=True)]
+    outcomes = {"same": 0, "both_fail": 0}
+    for case in range(80):
+        good = seeds[case % 2]
+        sos = good.find(b"\xff\xda")
+        start = sos + 14
+        bad = bytearray(good)
+        kind = case % 4
+        if kind == 0:                                   # a few bit flips inside the scan
+            for _ in range(int(rng.integers(1, 4))):
+                i = int(rng.integers(start, len(bad) - 2)); bad[i] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:                                 # random bytes
+            for _ in range(int(rng.integers(1, 6))):
+                bad[int(rng.integers(start, len(bad) - 2))] = int(rng.integers(0, 255))
+        elif kind == 2:                                 # truncate the scan (keep EOI)
+            cut = int(rng.integers(start + 4, len(bad) - 2)); bad = bad[:cut] + b"\xff\xd9"
+        else:                                           # garbage inserted in the middle
+            at = int(rng.integers(start, len(bad) - 2)); bad[at:at] = bytes(int(v) for v in rng.integers(0, 255, int(rng.integers(1, 40))))
+        for i in range(start, len(bad) - 2):            # keep the mutation inside the entropy data: no accidental markers
+            if bad[i] == 0xFF and bad[i + 1] != 0x00:
+                bad[i] = 0xFE
+        p = tmp_path / ("m%d.jpg" % case)
+        p.write_bytes(bytes(bad))
+        try:
+            host = ist.decode_image(bytes(bad))         # host Huffman + GPU reconstruction
+        except ist.StitchError:
+            host = None
+        try:
+            pipe = ist.decode_png(ist.stitch_files([str(p)], "vertical", {"filter": "nearest"})["png"])
+        except ist.StitchError:
+            pipe = None
+        if host is None or pipe is None:
+            assert host is None and pipe is None, case
+            outcomes["both_fail"] += 1
+        else:
+            assert np.array_equal(pipe, host), case
+            outcomes["same"] += 1
+    assert outcomes["same"] > 20
