@@ -23,6 +23,7 @@
 // which also produces the error message.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -234,6 +235,15 @@ __global__ __launch_bounds__(1024) void ist_jpeg_dc_kernel(const DevImg* imgs) {
 int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<uint8_t>* ok, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const size_t n_img = items.size();
+  static const bool timing = std::getenv("IST_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(stream);
+    const auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[ist timing]   huffman/%-20s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   int kSubBits = kSubBitsDefault;
   if (const char* e = std::getenv("IST_JPEG_SUB_BITS")) { const int v = std::atoi(e); if (v >= 256 && v <= 65536) kSubBits = v; }
   ok->assign(n_img, 0);
@@ -297,6 +307,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   JG_HIP(hipMemsetAsync(d + o_err, 0, 4 * n_img, stream));
   JG_HIP(hipMemcpyAsync(d + o_img, H.data(), sizeof(DevImg) * n_img, hipMemcpyHostToDevice, stream));
   JG_HIP(hipMemcpyAsync(d + o_sub, sub_img.data(), 2 * static_cast<size_t>(ns), hipMemcpyHostToDevice, stream));
+  lap("alloc + uploads");
   const DevImg* d_img = reinterpret_cast<const DevImg*>(d + o_img);
   const uint16_t* d_sub = reinterpret_cast<const uint16_t*>(d + o_sub);
   uint32_t* P[2] = {reinterpret_cast<uint32_t*>(d + o_p0), reinterpret_cast<uint32_t*>(d + o_p1)};
@@ -323,6 +334,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   }
   if (std::getenv("IST_TIMING")) std::fprintf(stderr, "[ist timing] GPU Huffman: %d subsequences, %s after %d passes\n", ns, converged ? "fixed point" : "NO fixed point", passes_run);
   if (!converged) { JG_HIP(hipStreamSynchronize(stream)); return IST_OK; }      // every ok[] stays 0: the host decodes
+  lap("sync passes");
   // ---- block indices, coefficient write, DC integration
   hipLaunchKernelGGL(ist_scan_u32_kernel, dim3(1), dim3(1024), 0, stream, d_nblk, d_excl, ns);
   JG_HIP(hipGetLastError());
@@ -331,6 +343,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   JG_HIP(hipGetLastError());
   hipLaunchKernelGGL(ist_jpeg_dc_kernel, dim3(static_cast<unsigned>(3 * n_img)), dim3(1024), 0, stream, d_img);
   JG_HIP(hipGetLastError());
+  lap("scan + write + DC");
   // ---- validation: exactly the blocks the frame header promises, and nothing the host decoder would reject
   std::vector<uint32_t> excl(static_cast<size_t>(ns) + 1), err(n_img);
   JG_HIP(hipMemcpyAsync(excl.data(), d_excl, 4 * (static_cast<size_t>(ns) + 1), hipMemcpyDeviceToHost, stream));
@@ -341,6 +354,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     const uint32_t blocks = excl[static_cast<size_t>(I.first_sub + I.n_sub)] - excl[static_cast<size_t>(I.first_sub)];
     (*ok)[k] = (blocks == static_cast<uint32_t>(I.total_blocks) && err[k] == 0) ? 1 : 0;
   }
+  lap("validation");
 #undef JG_HIP
   return IST_OK;
 }
