@@ -24,6 +24,11 @@ static void one(const std::vector<uint8_t>& f, long* ok, long* bad) {
     ist::JpegImage J;
     rc = ist::jpeg_parse_and_entropy_decode(p, n, &J, true);
     if (rc == IST_OK && int64_t(J.width) * J.height <= (1 << 24)) rc = ist::jpeg_parse_and_entropy_decode(p, n, &J, false);
+    if (rc == IST_OK) {                                        // the container walk that feeds the GPU entropy decoder (de-stuffing, tables)
+      ist::JpegImage J2; ist::JpegGpuScan G;
+      (void)ist::jpeg_parse_and_entropy_decode(p, n, &J2, false, &G);
+      if (G.eligible && (G.slots < 1 || G.slots > 10 || G.bits < 0 || G.stream.size() < size_t(G.bits / 8) + 16)) abort();
+    }
   } else {
     const bool misc = n >= 4 && ((p[0] == 'B' && p[1] == 'M') || !memcmp(p, "GIF8", 4));
     rc = misc ? ist_misc_info(p, n, &w, &h) : ist_png_info(p, n, &w, &h);
