@@ -239,7 +239,7 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
         if ((need_dc && !dc[td[s]].present) || (need_ac && !ac[ta[s]].present)) return fail(IST_E_DECODE, "JPEG scan uses an undefined Huffman table");
       }
       // the GPU entropy decoder takes baseline files whose single scan interleaves all components, without restarts
-      if (gs && !progressive && J->scans == 0 && ns == J->ncomp && restart_interval == 0) {
+      if (gs && !progressive && J->scans == 0 && ns == J->ncomp && restart_interval == 0 && (f + n) - (d + dl) < (1ll << 28)) {      // (32-bit bit positions on the GPU)
         for (int c = 0; c < J->ncomp; ++c) {
           if (!have_q[J->comp[c].tq]) return fail(IST_E_DECODE, "JPEG component uses an undefined quantisation table");
           std::memcpy(J->comp[c].q, qt[J->comp[c].tq], sizeof J->comp[c].q);
