@@ -126,6 +126,9 @@ def test_stitch_files_png_in_png_out(tmp_path):
     assert (res["width"], res["height"]) == (ref.shape[1], ref.shape[0])
     assert U.max_abs_diff(got, ref) <= 1
     assert np.array_equal(ist.decode_png(res["png"]), got)          # own decoder reads own encoder's files
+    view = ist.stitch_files(paths, "horizontal", {"mode": "min", "gap": 2}, copy=False)["png"]      # zero-copy hand-over
+    assert isinstance(view, memoryview) and bytes(view) == res["png"]
+    del view
     with pytest.raises(ist.StitchError) as e:
         (tmp_path / "bad.png").write_bytes(b"not a png at all, definitely not, no no no no no no no no no no no")
         ist.stitch_files([paths[0], str(tmp_path / "bad.png")], "vertical")
