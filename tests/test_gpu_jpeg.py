@@ -8,6 +8,7 @@ import pytest
 from PIL import Image
 
 import imagestitching_amd as ist
+from oracle import oracle as O
 from tests import util as U
 
 pytestmark = pytest.mark.gpu
@@ -212,3 +213,54 @@ def test_gpu_entropy_decoder_agrees_with_the_host_decoder_on_mutated_scans(tmp_p
             assert np.array_equal(pipe, host), case
             outcomes["same"] += 1
     assert outcomes["same"] > 20
+
+
+def test_random_file_sets_through_the_whole_pipeline(tmp_path):
+    """End-to-end differential test: random sets of files (baseline / progressive JPEG with EXIF orientations, PNG with
+    and without alpha, BMP, GIF), random direction / mode / gap / filter, through ist_stitch_files_png (GPU Huffman,
+    reconstruction, stitch, compressed PNG) against PIL's decoders + the CPU oracle."""
+    rng = np.random.default_rng(31337)
+    for case in range(80):
+        n = int(rng.integers(1, 6))
+        paths, bitmaps, orients = [], [], []
+        for k in range(n):
+            h, w = int(rng.integers(8, 200)), int(rng.integers(8, 200))
+            a = _photo(1000 + 10 * case + k, h, w)
+            kind = int(rng.integers(0, 6))
+            p = tmp_path / ("c%d_%d" % (case, k))
+            o = 1
+            if kind <= 1:
+                o = int(rng.integers(1, 9))
+                ex = Image.Exif()
+                ex[0x0112] = o
+                kw = {"quality": int(rng.integers(40, 96)), "subsampling": int(rng.integers(0, 3)), "exif": ex}
+                if kind == 1:
+                    kw["progressive"] = True
+                p = p.with_suffix(".jpg"); Image.fromarray(a).save(p, "JPEG", **kw)
+            elif kind == 2:
+                p = p.with_suffix(".png"); Image.fromarray(a).save(p, "PNG")
+            elif kind == 3:
+                rgba = np.concatenate([a, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], -1)
+                p = p.with_suffix(".png"); Image.fromarray(rgba, "RGBA").save(p, "PNG")
+            elif kind == 4:
+                p = p.with_suffix(".bmp"); Image.fromarray(a).save(p, "BMP")
+            else:
+                p = p.with_suffix(".gif"); Image.fromarray(a).convert("P", palette=Image.ADAPTIVE).save(p, "GIF")
+            bm = np.array(Image.open(p).convert("RGBA"))
+            bm[bm[..., 3] == 0] = 0
+            paths.append(str(p)); bitmaps.append(bm); orients.append(o)
+        direction = "vertical" if rng.integers(0, 2) else "horizontal"
+        opts = {"mode": ["min", "max", "original"][int(rng.integers(0, 3))], "gap": int(rng.integers(0, 2)) * 5,
+                "filter": "nearest" if rng.integers(0, 2) else "bilinear"}
+        # natural sizes follow the orientation, as getImageInfo reports them (the C side reads the EXIF tag itself)
+        descs = []
+        for bm, o in zip(bitmaps, orients):
+            hh, ww = bm.shape[:2]
+            descs.append({"width": ww, "height": hh, "orientation": o})
+        rc, pd, rl = O.plan(descs, direction, opts["mode"], opts["gap"], U.oracle_limits(opts))
+        assert rc == 0
+        ref = O.render(pd, rl, descs, bitmaps, opts["filter"], 4)
+        res = ist.stitch_files(paths, direction, opts)
+        got = ist.decode_png(res["png"])
+        assert got.shape == ref.shape, (case, got.shape, ref.shape)
+        assert U.max_abs_diff(got, ref) <= (0 if opts["filter"] == "nearest" else 1), (case, opts, orients)
