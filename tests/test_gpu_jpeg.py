@@ -264,3 +264,15 @@ def test_random_file_sets_through_the_whole_pipeline(tmp_path):
         got = ist.decode_png(res["png"])
         assert got.shape == ref.shape, (case, got.shape, ref.shape)
         assert U.max_abs_diff(got, ref) <= (0 if opts["filter"] == "nearest" else 1), (case, opts, orients)
+
+
+def test_sixty_four_files_in_one_call(tmp_path):
+    """BASELINE configs[4] has 64 inputs: 64 JPEGs (one GPU Huffman batch, 64 decode threads) stitched in one call"""
+    paths, bitmaps = [], []
+    for k in range(64):
+        a = _photo(3000 + k, 40 + (k % 7), 96)
+        p = tmp_path / ("f%02d.jpg" % k)
+        Image.fromarray(a).save(p, "JPEG", quality=60 + (k % 35), subsampling=k % 3)
+        paths.append(str(p)); bitmaps.append(_pil(p.read_bytes()))
+    res = ist.stitch_files(paths, "vertical", {"filter": "nearest"})
+    assert np.array_equal(ist.decode_png(res["png"]), np.concatenate(bitmaps, 0))
