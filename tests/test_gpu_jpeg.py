@@ -145,8 +145,11 @@ def test_gpu_entropy_decoder_full_size_and_mixed_inputs(tmp_path):
     (tmp_path / "a.jpg").write_bytes(base)
     (tmp_path / "b.jpg").write_bytes(prog)
     Image.fromarray(_photo(93, 100, 4032)).save(tmp_path / "c.png")
-    res = ist.stitch_files([str(tmp_path / "a.jpg"), str(tmp_path / "b.jpg"), str(tmp_path / "c.png")], "vertical", {"filter": "nearest"})
-    want = np.concatenate([_pil(base), _pil(prog), np.asarray(Image.open(tmp_path / "c.png").convert("RGBA"))], 0)
+    rst = _jpeg(_photo(94, 64, 4032), quality=85, subsampling=2, restart_marker_blocks=7)      # restart intervals: host Huffman
+    assert b"\xff\xdd" in rst
+    (tmp_path / "d.jpg").write_bytes(rst)
+    res = ist.stitch_files([str(tmp_path / "a.jpg"), str(tmp_path / "b.jpg"), str(tmp_path / "c.png"), str(tmp_path / "d.jpg")], "vertical", {"filter": "nearest"})
+    want = np.concatenate([_pil(base), _pil(prog), np.asarray(Image.open(tmp_path / "c.png").convert("RGBA")), _pil(rst)], 0)
     assert np.array_equal(ist.decode_png(res["png"]), want)
 
 
