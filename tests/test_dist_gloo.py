@@ -132,3 +132,15 @@ def test_overlapping_draws_are_refused():
         D.ShardedStitch(imgs, "vertical", None, 0, 2, 0)
     ok = D.ShardedStitch([{"width": 40, "height": 30, "orientation": 7}] * 2, "vertical", None, 0, 2, 0)
     assert sorted(ok.boxes) == [1]                            # image 0 is drawn entirely off-canvas
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_sharded_stitch_more_ranks_than_two(world, tmp_path):
+    """several senders, uneven ownership (5 images over 3 or 4 ranks; with 4 ranks rank 0 owns two, the others one):
+    the grouped send/recv batch must pair up per (sender, root) in image order"""
+    pixels = [U.rand_image(200 + i, h, w) for i, (w, h) in enumerate(SIZES)]
+    opts = {"filter": "bilinear", "mode": "min", "gap": 2}
+    out = str(tmp_path / "canvas.npy")
+    mp.spawn(_worker, args=(world, _free_port(), "vertical", opts, out), nprocs=world, join=True)
+    ref, _, _ = U.oracle_stitch(pixels, "vertical", opts)
+    assert np.array_equal(np.load(out), ref)
