@@ -134,9 +134,10 @@ def test_overlapping_draws_are_refused():
     assert sorted(ok.boxes) == [1]                            # image 0 is drawn entirely off-canvas
 
 
-@pytest.mark.parametrize("world", [3, 4])
+@pytest.mark.parametrize("world", [3, 4, 8])
 def test_sharded_stitch_more_ranks_than_two(world, tmp_path):
-    """several senders, uneven ownership (5 images over 3 or 4 ranks; with 4 ranks rank 0 owns two, the others one):
+    """several senders, uneven ownership (5 images over 3, 4 or 8 ranks; with 4 ranks rank 0 owns two, with 8 ranks three
+    ranks own nothing and only join the barrier):
     the grouped send/recv batch must pair up per (sender, root) in image order"""
     pixels = [U.rand_image(200 + i, h, w) for i, (w, h) in enumerate(SIZES)]
     opts = {"filter": "bilinear", "mode": "min", "gap": 2}
