@@ -238,6 +238,10 @@ def run_sharded(args):
         sec = float(dt.item()) / args.steps
         mp = sh.plan.canvas_w * sh.plan.canvas_h / 1e6
         in_place = sum(1 for i in sh.remote if sh.in_place[i])
+        # bytes the gather moves into GPU 0 per step, and what that is per xGMI link (one link per sending GPU)
+        gather_bytes = sum((sh.boxes[i][2] - sh.boxes[i][0]) * (sh.boxes[i][3] - sh.boxes[i][1]) * 4 for i in sh.remote)
+        senders = len({D.owner_of(i, world) for i in sh.remote})
+        busiest = max([sum((sh.boxes[i][2] - sh.boxes[i][0]) * (sh.boxes[i][3] - sh.boxes[i][1]) * 4 for i in sh.remote if D.owner_of(i, world) == r) for r in range(world) if r != 0] or [0])
         line = {
             "metric": "stitched megapixels/sec (9x12 MP vertical)", "value": round(mp / sec, 1), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec * 1e3, 5),
@@ -246,7 +250,10 @@ def run_sharded(args):
                                    "GPU 0 with one grouped RCCL send/recv batch (%d bands received in place)" % (world, in_place),
                        "timed_region": "per-rank band launches + gather + root launch; inputs resident in each owner's HBM"},
             "roofline": None, "cpu_baseline": None,
-            "extra": {"local_launches_only_ms_per_step": round(float(loc.item()) / args.steps * 1e3, 5),
+            "extra": {"gather": {"bytes_into_gpu0_per_step": gather_bytes, "sending_gpus": senders, "busiest_link_bytes": busiest,
+                                 "GBs_into_gpu0": round(gather_bytes / sec / 1e9, 1), "busiest_link_GBs": round(busiest / sec / 1e9, 1),
+                                 "note": "xGMI is point to point (one link per GPU pair, ~153 GB/s peak per direction pair): the step time is bounded below by busiest_link_bytes / link rate"},
+                      "local_launches_only_ms_per_step": round(float(loc.item()) / args.steps * 1e3, 5),
                       "exchange_ms_per_step_by_difference": round((float(dt.item()) - float(loc.item())) / args.steps * 1e3, 5),
                       "replicas_no_exchange": {"MPs": round(world * mp / (float(rep.item()) / args.steps), 1), "scaling": "weak",
                                                "note": "every GPU stitches its own whole 9x12 MP job"}},
