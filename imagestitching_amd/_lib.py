@@ -89,11 +89,11 @@ SYMBOLS = [
                                    C.POINTER(Region), C.c_void_p, C.c_size_t]),
     ("ist_free", None, [C.c_void_p]),
     ("ist_png_info", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    ("ist_png_decode_rgba8", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t]),
+    ("ist_png_decode_rgba8", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_int64]),
     ("ist_jpeg_info", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    ("ist_jpeg_decode_rgba8", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t]),
+    ("ist_jpeg_decode_rgba8", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_int64]),
     ("ist_image_info", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    ("ist_image_decode_rgba8", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t]),
+    ("ist_image_decode_rgba8", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_int64]),
     ("ist_stitch_files_png", C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_double,
                                        C.POINTER(Limits), C.c_int, C.POINTER(Plan), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int64)]),
     ("ist_png_bound", C.c_int64, [C.c_int64, C.c_int64]),

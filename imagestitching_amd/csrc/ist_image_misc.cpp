@@ -1,8 +1,11 @@
 // ist_image_misc.cpp — the two remaining easy members of SUPPORTED_IMAGE_TYPES (pages/index/index.js:4): BMP and GIF
 // (first frame), decoded on the host into RGBA8.  Reference anchor: loadImageFrom (utils/canvas.js:27-121) — the platform
 // decoder behind Image.src.  Both are lossless formats, so the result is pinned by any conforming decoder (tests: PIL).
+#include <algorithm>
+#include <climits>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "ist_internal.h"
@@ -15,13 +18,14 @@ inline uint32_t le16(const uint8_t* p) { return p[0] | (p[1] << 8); }
 inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (uint32_t(p[3]) << 24); }
 
 // ------------------------------------------------------------------------------------------------ BMP
-struct Bmp { int w = 0, h = 0, bpp = 0; bool top_down = false; uint32_t comp = 0, off = 0, ncol = 0, dib = 0; uint32_t mask[4] = {0, 0, 0, 0}; };
+struct Bmp { int w = 0, h = 0, bpp = 0; bool top_down = false; uint32_t comp = 0, off = 0, ncol = 0, dib = 0; uint32_t mask[4] = {0, 0, 0, 0}; int shift[4] = {0, 0, 0, 0}, bits[4] = {0, 0, 0, 0}; };
 
 int bmp_header(const uint8_t* f, int64_t n, Bmp* B) {
   if (n < 26 || f[0] != 'B' || f[1] != 'M') return fail(IST_E_DECODE, "not a BMP file");
   B->off = le32(f + 10); B->dib = le32(f + 14);
   if (B->dib < 40 || 14 + int64_t(B->dib) > n) return fail(IST_E_UNSUPPORTED, "unsupported BMP header");
   const int32_t w = int32_t(le32(f + 18)), h = int32_t(le32(f + 22));
+  if (h == INT32_MIN) return fail(IST_E_DECODE, "bad BMP size");
   B->w = w; B->h = h < 0 ? -h : h; B->top_down = h < 0;
   B->bpp = int(le16(f + 28)); B->comp = le32(f + 30); B->ncol = le32(f + 46);
   if (B->w < 1 || B->h < 1 || B->w > (1 << 29)) return fail(IST_E_DECODE, "bad BMP size");
@@ -33,13 +37,20 @@ int bmp_header(const uint8_t* f, int64_t n, Bmp* B) {
     B->mask[0] = le32(m); B->mask[1] = le32(m + 4); B->mask[2] = le32(m + 8);
     B->mask[3] = (B->dib >= 56 && 14 + 40 + 16 <= n) ? le32(m + 12) : 0;
   } else if (B->bpp == 16) { B->mask[0] = 0x7C00; B->mask[1] = 0x03E0; B->mask[2] = 0x001F; }
+  // position and width of every bit field, once per file: a mask is one contiguous run of ones (BI_BITFIELDS), or empty
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t m = B->mask[c];
+    if (!m) continue;
+    B->shift[c] = __builtin_ctz(m);
+    B->bits[c] = __builtin_popcount(m);
+    const uint64_t run = ((uint64_t(1) << B->bits[c]) - 1) << B->shift[c];
+    if (run != m) return fail(IST_E_DECODE, "BMP bit-field mask is not contiguous");
+  }
   return IST_OK;
 }
 
-inline uint8_t field(uint32_t v, uint32_t mask) {
+inline uint8_t field(uint32_t v, uint32_t mask, int shift, int bits) {
   if (!mask) return 0;
-  int shift = 0; while (!((mask >> shift) & 1)) ++shift;
-  int bits = 0; while ((mask >> (shift + bits)) & 1) ++bits;
   const uint32_t x = (v & mask) >> shift;
   return bits >= 8 ? uint8_t(x >> (bits - 8)) : uint8_t((x * 255 + ((1u << bits) - 1) / 2) / ((1u << bits) - 1));
 }
@@ -53,6 +64,7 @@ int bmp_decode(const uint8_t* f, int64_t n, uint8_t* out, size_t pitch) {
   const uint8_t* pal = f + 14 + B.dib + (B.comp == 3 && B.dib == 40 ? 12 : 0);
   const uint32_t ncol = B.bpp <= 8 ? (B.ncol ? B.ncol : (1u << B.bpp)) : 0;
   if (B.bpp <= 8 && pal + 4 * size_t(ncol) > f + n) return fail(IST_E_DECODE, "truncated BMP palette");
+  auto F = [&](uint32_t v, int c) { return field(v, B.mask[c], B.shift[c], B.bits[c]); };
   for (int y = 0; y < B.h; ++y) {
     const uint8_t* s = f + B.off + stride * size_t(B.top_down ? y : B.h - 1 - y);
     uint8_t* o = out + size_t(y) * pitch;
@@ -60,11 +72,11 @@ int bmp_decode(const uint8_t* f, int64_t n, uint8_t* out, size_t pitch) {
       if (B.bpp == 24) { o[0] = s[3 * x + 2]; o[1] = s[3 * x + 1]; o[2] = s[3 * x]; o[3] = 255; }
       else if (B.bpp == 32) {
         const uint32_t v = le32(s + 4 * x);
-        if (B.comp == 3) { o[0] = field(v, B.mask[0]); o[1] = field(v, B.mask[1]); o[2] = field(v, B.mask[2]); o[3] = B.mask[3] ? field(v, B.mask[3]) : 255; }
+        if (B.comp == 3) { o[0] = F(v, 0); o[1] = F(v, 1); o[2] = F(v, 2); o[3] = B.mask[3] ? F(v, 3) : 255; }
         else { o[0] = s[4 * x + 2]; o[1] = s[4 * x + 1]; o[2] = s[4 * x]; o[3] = 255; }      // BI_RGB: the 4th byte is padding
       } else if (B.bpp == 16) {
         const uint32_t v = le16(s + 2 * x);
-        o[0] = field(v, B.mask[0]); o[1] = field(v, B.mask[1]); o[2] = field(v, B.mask[2]); o[3] = B.mask[3] ? field(v, B.mask[3]) : 255;
+        o[0] = F(v, 0); o[1] = F(v, 1); o[2] = F(v, 2); o[3] = B.mask[3] ? F(v, 3) : 255;
       } else {
         const int per = 8 / B.bpp;
         const uint32_t idx = (s[x / per] >> ((per - 1 - x % per) * B.bpp)) & ((1u << B.bpp) - 1);
@@ -122,7 +134,8 @@ int gif_decode(const uint8_t* f, int64_t n, uint8_t* out, size_t pitch) {
     // LZW
     const int clear = 1 << min_code, eoi = clear + 1;
     std::vector<uint16_t> prefix(4096); std::vector<uint8_t> suffix(4096), stack(4097);
-    std::vector<uint8_t> idx; idx.reserve(size_t(iw) * ih);
+    // (the descriptor is untrusted: never reserve more than the logical screen can show)
+    std::vector<uint8_t> idx; idx.reserve(std::min(size_t(iw) * ih, size_t(G.w) * G.h));
     int code_size = min_code + 1, next = eoi + 1, prev = -1;
     uint32_t acc = 0; int nbits = 0; size_t dp = 0;
     const size_t want = size_t(iw) * ih;
@@ -178,12 +191,13 @@ int ist_misc_info(const uint8_t* file, int64_t len, int32_t* w, int32_t* h) {
   return fail(IST_E_DECODE, "unknown image format");
 }
 
-int ist_misc_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t pitch) {
+int ist_misc_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t pitch, int64_t out_rows) {
   int32_t w = 0, h = 0;
   const int rc = ist_misc_info(file, len, &w, &h);
   if (rc) return rc;
-  if (!out || pitch < size_t(w) * 4) return fail(IST_E_INVALID, "output buffer too small");
-  return file[0] == 'B' ? bmp_decode(file, len, out, pitch) : gif_decode(file, len, out, pitch);
+  if (!out || pitch < size_t(w) * 4 || out_rows < h) return fail(IST_E_INVALID, "output buffer too small");
+  try { return file[0] == 'B' ? bmp_decode(file, len, out, pitch) : gif_decode(file, len, out, pitch); }
+  catch (const std::bad_alloc&) { return fail(IST_E_NOMEM, "out of memory while decoding the image"); }
 }
 
 }  // extern "C"

@@ -9,7 +9,9 @@
 // 8x8 inverse DCT, chroma upsampling, YCbCr->RGB — is independent per block / per pixel and runs on the GPU
 // (ist_jpeg_kernels.hip) on the coefficient planes this file produces.
 // Supported: SOF0 / SOF1, 8-bit, 1 or 3 components, any sampling factors h,v in {1,2} with luma >= chroma, interleaved
-// and non-interleaved scans, restart intervals.  Progressive (SOF2), arithmetic coding, 12-bit, CMYK: IST_E_UNSUPPORTED.
+// and non-interleaved scans, restart intervals; progressive (SOF2: DC/AC first and refinement scans, EOB runs) into dense
+// coefficient planes.  Arithmetic coding, lossless, 12-bit, CMYK: IST_E_UNSUPPORTED.
+// Exactly ONE frame header per file (a second SOF is JERR_SOF_DUPLICATE in libjpeg): every buffer below is sized from it.
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -189,6 +191,7 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
       }
     } else if (m == 0xDD) { if (dl >= 2) restart_interval = static_cast<int>(be16(d)); }
     else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {                 // SOF0 / SOF1 (sequential), SOF2 (progressive)
+      if (have_sof) return fail(IST_E_DECODE, "JPEG with more than one frame header");     // the planes are sized from the first one
       progressive = (m == 0xC2);
       if (dl < 6) return fail(IST_E_DECODE, "bad JPEG frame header");
       if (d[0] != 8) return fail(IST_E_UNSUPPORTED, "only 8-bit JPEG is supported");
@@ -202,6 +205,7 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
         C.id = d[6 + 3 * c]; C.h = d[7 + 3 * c] >> 4; C.v = d[7 + 3 * c] & 15; C.tq = d[8 + 3 * c];
         if (C.h < 1 || C.h > 2 || C.v < 1 || C.v > 2 || C.tq > 3) return fail(IST_E_UNSUPPORTED, "JPEG sampling factors beyond 2 are not supported");
         hmax = std::max(hmax, C.h); vmax = std::max(vmax, C.v);
+        for (int p = 0; p < c; ++p) if (J->comp[p].id == C.id) return fail(IST_E_DECODE, "JPEG frame names a component twice");
       }
       // colour: luma carries the sampling (4:4:4, 4:2:2, 4:2:0, 4:4:0), both chroma planes are 1x1
       if (J->ncomp == 3 && (J->comp[1].h != 1 || J->comp[1].v != 1 || J->comp[2].h != 1 || J->comp[2].v != 1))
@@ -218,6 +222,7 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
     } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) return fail(IST_E_UNSUPPORTED, "this JPEG process (lossless / arithmetic) is not supported");
     else if (m == 0xDA) {                                           // SOS
       if (!have_sof) return fail(IST_E_DECODE, "JPEG scan before frame header");
+      if (dl < 1) return fail(IST_E_DECODE, "bad JPEG scan header");
       const int ns = d[0];
       if (ns < 1 || ns > J->ncomp || dl < 1 + 2 * ns + 3) return fail(IST_E_DECODE, "bad JPEG scan header");
       int ci[3], td[3], ta[3];
@@ -225,6 +230,7 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
         const int id = d[1 + 2 * s]; ci[s] = -1;
         for (int c = 0; c < J->ncomp; ++c) if (J->comp[c].id == id) ci[s] = c;
         if (ci[s] < 0) return fail(IST_E_DECODE, "JPEG scan names an unknown component");
+        for (int p = 0; p < s; ++p) if (ci[p] == ci[s]) return fail(IST_E_DECODE, "JPEG scan names a component twice");   // T.81 B.2.3
         td[s] = d[2 + 2 * s] >> 4; ta[s] = d[2 + 2 * s] & 15;
         if (td[s] > 3 || ta[s] > 3) return fail(IST_E_DECODE, "JPEG scan uses an undefined Huffman table");
       }
@@ -239,7 +245,10 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
         if ((need_dc && !dc[td[s]].present) || (need_ac && !ac[ta[s]].present)) return fail(IST_E_DECODE, "JPEG scan uses an undefined Huffman table");
       }
       // the GPU entropy decoder takes baseline files whose single scan interleaves all components, without restarts
-      if (gs && !progressive && J->scans == 0 && ns == J->ncomp && restart_interval == 0 && (f + n) - (d + dl) < (1ll << 28)) {      // (32-bit bit positions on the GPU)
+      int mcu_blocks = 0;
+      for (int s2 = 0; s2 < ns; ++s2) mcu_blocks += J->comp[ci[s2]].h * J->comp[ci[s2]].v;
+      if (gs && !progressive && J->scans == 0 && ns == J->ncomp && restart_interval == 0 && mcu_blocks <= 10 &&      // (T.81 B.2.3: at most 10 blocks per MCU)
+          (f + n) - (d + dl) < (1ll << 28)) {      // (32-bit bit positions on the GPU)
         for (int c = 0; c < J->ncomp; ++c) {
           if (!have_q[J->comp[c].tq]) return fail(IST_E_DECODE, "JPEG component uses an undefined quantisation table");
           std::memcpy(J->comp[c].q, qt[J->comp[c].tq], sizeof J->comp[c].q);

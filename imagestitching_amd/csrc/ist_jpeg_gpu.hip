@@ -259,6 +259,8 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   for (size_t k = 0; k < n_img; ++k) {
     const JpegImage& J = *items[k].J; const JpegGpuScan& S = *items[k].S;
     if (S.bits >= (1ll << 32) - 65536) return fail(IST_E_UNSUPPORTED, "JPEG scan too large for the GPU entropy decoder");
+    // the kernels index slot_comp / slot_idx (10 entries, T.81 B.2.3) with the MCU slot: never launch outside that
+    if (S.slots < 1 || S.slots > 10) return fail(IST_E_DECODE, "JPEG scan with more than 10 blocks per MCU");
     o_stream[k] = take(S.stream.size());
     o_tab[k] = take(sizeof(S.tables));
     DevImg& I = H[k];

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "ist_internal.h"
@@ -52,7 +53,11 @@ int parse(const uint8_t* f, int64_t n, Header* H, std::vector<Span>* idat, std::
 #else
     (void)crc;
 #endif
+    // IHDR is the first chunk and the only one of its kind (PNG 5.6): info and decode must agree on ONE header,
+    // every buffer of the caller is sized from it
+    if (pos == 8 && std::memcmp(type, "IHDR", 4) != 0) return fail(IST_E_DECODE, "PNG does not start with IHDR");
     if (!std::memcmp(type, "IHDR", 4)) {
+      if (have_ihdr) return fail(IST_E_DECODE, "PNG with more than one IHDR");
       if (len != 13) return fail(IST_E_DECODE, "bad IHDR");
       H->w = be32(data); H->h = be32(data + 4); H->depth = data[8]; H->ctype = data[9]; H->interlace = data[12];
       if (data[10] != 0 || data[11] != 0) return fail(IST_E_DECODE, "unknown PNG compression / filter method");
@@ -207,11 +212,11 @@ int ist_png_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* heig
   return IST_OK;
 }
 
-int ist_png_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch) {
+static int png_decode(const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch, int64_t out_rows) {
   Header H; std::vector<Span> idat; std::vector<uint8_t> plte, trns;
   int rc = parse(file, len, &H, &idat, &plte, &trns, false);
   if (rc) return rc;
-  if (!out || out_pitch < size_t(H.w) * 4) return fail(IST_E_INVALID, "ist_png_decode_rgba8: output buffer too small");
+  if (!out || out_pitch < size_t(H.w) * 4 || out_rows < int64_t(H.h)) return fail(IST_E_INVALID, "ist_png_decode_rgba8: output buffer too small");
   const int channels = H.ctype == 0 ? 1 : H.ctype == 2 ? 3 : H.ctype == 3 ? 1 : H.ctype == 4 ? 2 : 4;
   const int bpp_bits = channels * H.depth;
   const size_t bpp = size_t(bpp_bits + 7) / 8;                          // filter unit in bytes (>= 1)
@@ -262,6 +267,11 @@ int ist_png_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t 
   uint8_t extra;
   if (inf.read(&extra, 1) != 0) return fail(IST_E_DECODE, kShort);
   return IST_OK;
+}
+
+int ist_png_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch, int64_t out_rows) {
+  try { return png_decode(file, len, out, out_pitch, out_rows); }
+  catch (const std::bad_alloc&) { return fail(IST_E_NOMEM, "out of memory while decoding the PNG"); }
 }
 
 }  // extern "C"

@@ -403,12 +403,12 @@ int ist_jpeg_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* hei
   return IST_OK;
 }
 
-int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch) {
+int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch, int64_t out_rows) {
   if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
   JpegImage J;
   int rc = jpeg_parse_and_entropy_decode(file, len, &J, false);
   if (rc) return rc;
-  if (!out || out_pitch < static_cast<size_t>(J.width) * 4) return fail(IST_E_INVALID, "ist_jpeg_decode_rgba8: output buffer too small");
+  if (!out || out_pitch < static_cast<size_t>(J.width) * 4 || out_rows < J.height) return fail(IST_E_INVALID, "ist_jpeg_decode_rgba8: output buffer too small");
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   // one device allocation: coefficients + tables + sample planes + RGBA
@@ -430,7 +430,7 @@ int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_
 
 // format-agnostic front door: PNG (host decode) or JPEG (host entropy decode + GPU reconstruction)
 extern "C" int ist_misc_info(const uint8_t* file, int64_t len, int32_t* w, int32_t* h);
-extern "C" int ist_misc_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t pitch);
+extern "C" int ist_misc_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t pitch, int64_t out_rows);
 static bool is_jpeg(const uint8_t* f, int64_t n) { return f && n >= 2 && f[0] == 0xFF && f[1] == 0xD8; }
 static bool is_misc(const uint8_t* f, int64_t n) { return f && n >= 4 && ((f[0] == 'B' && f[1] == 'M') || !std::memcmp(f, "GIF8", 4)); }
 
@@ -441,10 +441,10 @@ int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* he
   return ist_png_info(file, len, width, height);
 }
 
-int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch) {
-  if (is_jpeg(file, len)) return ist_jpeg_decode_rgba8(ctx, file, len, out, out_pitch);
-  if (is_misc(file, len)) return ist_misc_decode_rgba8(file, len, out, out_pitch);
-  return ist_png_decode_rgba8(file, len, out, out_pitch);
+int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch, int64_t out_rows) {
+  if (is_jpeg(file, len)) return ist_jpeg_decode_rgba8(ctx, file, len, out, out_pitch, out_rows);
+  if (is_misc(file, len)) return ist_misc_decode_rgba8(file, len, out, out_pitch, out_rows);
+  return ist_png_decode_rgba8(file, len, out, out_pitch, out_rows);
 }
 
 // ---- the whole onStitch for files, device-resident: only file bytes go in and only PNG bytes come out over PCIe -------
@@ -490,7 +490,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
       } else {                 // PNG, BMP, GIF: host decoders
         int32_t w = 0, h = 0, o = 0;
         D.rc = ist_image_info(f, len, &w, &h, &o);
-        if (D.rc == IST_OK) { D.w = w; D.h = h; D.px.resize(static_cast<size_t>(w) * h * 4); D.rc = ist_image_decode_rgba8(nullptr, f, len, D.px.data(), static_cast<size_t>(w) * 4); }
+        if (D.rc == IST_OK) { D.w = w; D.h = h; D.px.resize(static_cast<size_t>(w) * h * 4); D.rc = ist_image_decode_rgba8(nullptr, f, len, D.px.data(), static_cast<size_t>(w) * 4, h); }
       }
       if (D.rc != IST_OK) D.err = g_last_error;        // thread-local in the worker: carry it out
     });

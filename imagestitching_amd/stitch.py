@@ -245,7 +245,7 @@ def decode_png(data):
     w, h = C.c_int32(0), C.c_int32(0)
     L.check(L.lib.ist_png_info(buf, len(buf), C.byref(w), C.byref(h)))
     out = np.empty((h.value, w.value, 4), np.uint8)
-    L.check(L.lib.ist_png_decode_rgba8(buf, len(buf), out.ctypes.data, out.strides[0]))
+    L.check(L.lib.ist_png_decode_rgba8(buf, len(buf), out.ctypes.data, out.strides[0], out.shape[0]))
     return out
 
 
@@ -265,7 +265,7 @@ def decode_image(data, device=0):
     w, h, _ = image_info(buf)
     out = np.empty((h, w, 4), np.uint8)
     ctx = _ctx(device) if buf[:2] == b"\xff\xd8" else None          # only JPEG needs the GPU
-    L.check(L.lib.ist_image_decode_rgba8(ctx, buf, len(buf), out.ctypes.data, out.strides[0]))
+    L.check(L.lib.ist_image_decode_rgba8(ctx, buf, len(buf), out.ctypes.data, out.strides[0], out.shape[0]))
     return out
 
 

@@ -176,18 +176,20 @@ IST_API void ist_free(void* p);
 
 /* ---- decode: PNG file -> RGBA8 (host; the Image.src step, utils/canvas.js:27-121, for 'png' inputs, index.js:4) ---- */
 /* colour types 0/2/3/4/6, bit depths 1-16 (16-bit keeps the high byte), tRNS, plain or Adam7-interlaced.  JPEG / WebP /
- * HEIC return IST_E_UNSUPPORTED; damaged files IST_E_DECODE ('图片N解码异常' analogue). */
+ * HEIC return IST_E_UNSUPPORTED; damaged files IST_E_DECODE ('图片N解码异常' analogue).
+ * Every decode entry point takes the CAPACITY of the output buffer (out_pitch bytes per row, out_rows rows) and fails
+ * with IST_E_INVALID when the file's own header asks for more: the header is untrusted input. */
 IST_API int ist_png_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height);
-IST_API int ist_png_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch);
+IST_API int ist_png_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch, int64_t out_rows);
 /* JPEG (baseline / extended sequential / progressive, 8 bit, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0, restart
  * intervals): Huffman decoding on the host, dequantise + IDCT + upsampling + colour conversion on the GPU.  *orientation = EXIF tag 0x0112
  * (0 when absent) - what getImageInfo feeds the planner (index.js:734).  Lossless / arithmetic-coded JPEG: IST_E_UNSUPPORTED. */
 IST_API int ist_jpeg_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation);
-IST_API int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch);
+IST_API int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch, int64_t out_rows);
 /* by signature: PNG, JPEG, BMP (uncompressed, 1-32 bit) or GIF (first frame) - SUPPORTED_IMAGE_TYPES (index.js:4) minus
  * WebP.  ctx may be NULL for everything except JPEG (whose reconstruction runs on the GPU). */
 IST_API int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation);
-IST_API int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch);
+IST_API int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch, int64_t out_rows);
 
 /* ---- files in, file out: the whole onStitch (decode -> plan -> resample+blit -> PNG export; index.js:1441-1581) ---- */
 /* files[i] = PNG or JPEG file bytes.  Huffman / inflate on host threads (one per image), everything else on the GPU;

@@ -500,7 +500,7 @@ static napi_value js_decode_image(napi_env env, napi_callback_info info) {
   if (is_jpeg && !ctx) { napi_throw(env, make_error(env, IST_E_NO_DEVICE, g_ctx_err)); return NULL; }
   void* out_data = NULL; napi_value buf, o;
   if (napi_create_buffer(env, (size_t)w * (size_t)h * 4, &out_data, &buf) != napi_ok) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
-  rc = ist_image_decode_rgba8(ctx, (const uint8_t*)p, (int64_t)len, (uint8_t*)out_data, (size_t)w * 4);
+  rc = ist_image_decode_rgba8(ctx, (const uint8_t*)p, (int64_t)len, (uint8_t*)out_data, (size_t)w * 4, (int64_t)h);
   if (rc < 0) return throw_ist(env, rc);
   napi_create_object(env, &o);
   set_num(env, o, "width", w); set_num(env, o, "height", h); set_num(env, o, "orientation", orient ? orient : 1);
@@ -524,7 +524,7 @@ static napi_value js_decode_png(napi_env env, napi_callback_info info) {
   if (rc < 0) return throw_ist(env, rc);
   void* out_data = NULL; napi_value buf, o;
   if (napi_create_buffer(env, (size_t)w * (size_t)h * 4, &out_data, &buf) != napi_ok) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
-  rc = ist_png_decode_rgba8((const uint8_t*)p, (int64_t)len, (uint8_t*)out_data, (size_t)w * 4);
+  rc = ist_png_decode_rgba8((const uint8_t*)p, (int64_t)len, (uint8_t*)out_data, (size_t)w * 4, (int64_t)h);
   if (rc < 0) return throw_ist(env, rc);
   napi_create_object(env, &o);
   set_num(env, o, "width", w); set_num(env, o, "height", h);
