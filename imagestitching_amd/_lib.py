@@ -18,6 +18,7 @@ VERTICAL, HORIZONTAL = 0, 1
 MODE_MIN, MODE_MAX, MODE_ORIGINAL = 0, 1, 2
 PLATFORM_OTHER, PLATFORM_IOS, PLATFORM_ANDROID = 0, 1, 2
 FILTER_NEAREST, FILTER_BILINEAR = 0, 1
+SPLIT_IMAGE, SPLIT_BAND = 0, 1
 
 IST_OK, IST_NOTHING_TO_DO = 0, 1
 ERROR_NAMES = {-1: "IST_E_INVALID", -2: "IST_E_SIZE_UNAVAILABLE", -3: "IST_E_OUTPUT_SIZE", -4: "IST_E_NO_CONTEXT",
@@ -55,6 +56,12 @@ class Region(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
 
 
+class Part(C.Structure):
+    _fields_ = [("image", C.c_int32), ("op", C.c_int32), ("slot", C.c_int32),
+                ("X0", C.c_int32), ("Y0", C.c_int32), ("X1", C.c_int32), ("Y1", C.c_int32),
+                ("sx0", C.c_int32), ("sy0", C.c_int32), ("sx1", C.c_int32), ("sy1", C.c_int32), ("in_place", C.c_int32)]
+
+
 class JobInfo(C.Structure):
     _fields_ = [("canvas_w", C.c_int64), ("canvas_h", C.c_int64), ("n_ops", C.c_int32), ("n_cells", C.c_int32),
                 ("n_tiles", C.c_int64), ("out_pixels", C.c_int64), ("src_pixels_touched", C.c_int64),
@@ -73,6 +80,8 @@ SYMBOLS = [
     ("ist_plan_free", None, [C.POINTER(Plan)]),
     ("ist_plan_ops", C.c_int, [C.POINTER(Plan), C.POINTER(ImageDesc), C.c_int, C.POINTER(Op), C.POINTER(C.c_int)]),
     ("ist_op_box", C.c_int, [C.POINTER(Op), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int32)]),
+    ("ist_shard_parts", C.c_int, [C.POINTER(Op), C.c_int, C.c_int64, C.c_int64, C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(Part), C.c_int, C.POINTER(C.c_int)]),
     ("ist_ctx_create", C.c_void_p, [C.c_int]),
     ("ist_ctx_destroy", None, [C.c_void_p]),
     ("ist_ctx_set_png_level", C.c_int, [C.c_void_p, C.c_int]),
@@ -88,6 +97,7 @@ SYMBOLS = [
                                    C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
                                    C.POINTER(Region), C.c_void_p, C.c_size_t]),
     ("ist_free", None, [C.c_void_p]),
+    ("ist_pool_trim", None, []),
     ("ist_png_info", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("ist_png_decode_rgba8", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_int64]),
     ("ist_jpeg_info", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

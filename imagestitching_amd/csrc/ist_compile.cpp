@@ -117,14 +117,33 @@ static int64_t distinct_taps(double k, double o, int lo, int hi, int clo, int ch
   return static_cast<int64_t>(std::unique(idx.begin(), idx.end()) - idx.begin());
 }
 
-// FILL / COPY tile shape.  IST_COPY_TILE=WxH is a tuning knob for benchmarks (W = 256, 512, 1024, ...).
-static int g_tile_w = 256, g_tile_h = 8;      // measured optimum on MI355X: ~64 KB of loads in flight per CU
-static const int g_lds_run = 2;                    // pipeline stages per workgroup on the SAMPLE_LDS path
-static const int64_t g_lds_budget_words = 6144;    // 24 KiB footprint budget per workgroup: measured optimum (IST_LDS_BUDGET bytes overrides)
-static void read_tile_knob() {
-  const char* e = std::getenv("IST_COPY_TILE");
+// Shape of a compiled job.  Production compiles use the constants below (the measured optima on MI355X) and touch
+// neither the environment nor any mutable global, so jobs can be compiled concurrently on any number of threads.  A
+// process started with IST_TUNING=1 (tools/sweep_*.py, tools/exp_*.py: single-threaded benchmarks) re-reads the knobs at
+// every compile: IST_COPY_TILE=WxH (W = 256, 512, ...), IST_LDS_BUDGET (bytes), IST_LDS_RUN, IST_NO_LDS, IST_NO_BANDS,
+// IST_NO_TILE_TABLE.
+struct CompileKnobs {
+  int tile_w = 256, tile_h = 8;        // FILL / COPY: ~64 KB of loads in flight per CU
+  int lds_run = 2;                     // pipeline stages per workgroup on the SAMPLE_LDS path
+  int64_t lds_budget_words = 6144;     // 24 KiB footprint budget per workgroup
+  bool no_lds = false, no_bands = false, no_tile_table = false;
+};
+bool tuning_mode() {
+  static const bool on = [] { const char* e = std::getenv("IST_TUNING"); return e && *e && std::strcmp(e, "0") != 0; }();
+  return on;
+}
+static CompileKnobs read_knobs() {
+  CompileKnobs k;
+  if (!tuning_mode()) return k;
   int w = 0, h = 0;
-  if (e && std::sscanf(e, "%dx%d", &w, &h) == 2 && w >= 256 && (w & (w - 1)) == 0 && h >= 1 && h <= 4096) { g_tile_w = w; g_tile_h = h; }
+  const char* e = std::getenv("IST_COPY_TILE");
+  if (e && std::sscanf(e, "%dx%d", &w, &h) == 2 && w >= 256 && (w & (w - 1)) == 0 && h >= 1 && h <= 4096) { k.tile_w = w; k.tile_h = h; }
+  if ((e = std::getenv("IST_LDS_BUDGET")) != nullptr) k.lds_budget_words = std::max<int64_t>(256, std::atoll(e) / 4);
+  if ((e = std::getenv("IST_LDS_RUN")) != nullptr) k.lds_run = std::min(16, std::max(1, std::atoi(e)));
+  k.no_lds = std::getenv("IST_NO_LDS") != nullptr;
+  k.no_bands = std::getenv("IST_NO_BANDS") != nullptr;
+  k.no_tile_table = std::getenv("IST_NO_TILE_TABLE") != nullptr;
+  return k;
 }
 
 int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,
@@ -135,7 +154,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
   const bool aa = (filter & IST_FILTER_EDGE_AA) != 0;
   filter &= 0xFF;
   if (filter != IST_FILTER_NEAREST && filter != IST_FILTER_BILINEAR) return fail(IST_E_INVALID, "unknown filter");
-  read_tile_knob();
+  const CompileKnobs knobs = read_knobs();
   out->canvas_w = canvas_w; out->canvas_h = canvas_h; out->filter = filter | (aa ? IST_FILTER_EDGE_AA : 0);
   out->ops.clear(); out->cells.clear(); out->stacks.clear(); out->bands.clear(); out->tiles.clear();
   out->lds_words = 0; out->lds_half = 0;
@@ -275,7 +294,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
       cell.path = PATH_GENERAL;
       // one quarter-turned draw over an opaque colour, bilinear: stage the footprint transposed in LDS
       if (!partial && cell.stack_len == 1 && (out->ops[cell.op].flags & OPF_SWAP) && filter == IST_FILTER_BILINEAR &&
-          (bg_opaque || (out->ops[cell.op].flags & OPF_OPAQUE)) && !std::getenv("IST_NO_LDS")) {
+          (bg_opaque || (out->ops[cell.op].flags & OPF_OPAQUE)) && !knobs.no_lds) {
         const DevOp& r = out->ops[cell.op];
         const double akx = std::fabs(r.kx), aky = std::fabs(r.ky);
         if (r.cx1 > r.cx0 && r.cy1 > r.cy0 && akx <= 128.0 && aky <= 128.0) {
@@ -293,11 +312,11 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
         }
       }
     }
-    if (cell.path == PATH_SAMPLE && filter == IST_FILTER_BILINEAR && !std::getenv("IST_NO_LDS")) {
+    if (cell.path == PATH_SAMPLE && filter == IST_FILTER_BILINEAR && !knobs.no_lds) {
       // stage the tile's source footprint in LDS when it fits the budget with at least 4 output rows per tile
       const DevOp& r = out->ops[cell.op];
       const double akx = std::fabs(r.kx), aky = std::fabs(r.ky);
-      const int64_t budget = std::getenv("IST_LDS_BUDGET") ? std::atoll(std::getenv("IST_LDS_BUDGET")) / 4 : g_lds_budget_words;
+      const int64_t budget = knobs.lds_budget_words;
       if (r.cx1 > r.cx0 && r.cy1 > r.cy0 && akx <= 4.0 && aky <= 8.0) {
         const int64_t wl = (static_cast<int64_t>(std::floor(255.0 * akx)) + 3 + 3) & ~3LL;      // pixels per LDS row
         int th = 0; int64_t need = 0;
@@ -307,7 +326,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
         }
         if (th) {
           // a workgroup walks `run` stages down its 256-pixel column (see tile_sample_lds)
-          const int run = std::getenv("IST_LDS_RUN") ? std::min(16, std::max(1, std::atoi(std::getenv("IST_LDS_RUN")))) : g_lds_run;
+          const int run = knobs.lds_run;
           cell.path = PATH_SAMPLE_LDS; cell.tile_w = 256; cell.sub_h = th; cell.tile_h = th * run;
           out->lds_half = std::max<int32_t>(out->lds_half, static_cast<int32_t>(need));
           out->lds_words = std::max<int32_t>(out->lds_words, out->lds_half);
@@ -317,7 +336,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     if (cell.path == PATH_SAMPLE_LDS || cell.path == PATH_SWAP_LDS) {}
     else if (cell.path == PATH_GENERAL) { cell.tile_w = 64; cell.tile_h = 64; }
     else if (cell.path == PATH_SAMPLE) { cell.tile_w = 256; cell.tile_h = 32; }
-    else { cell.tile_w = g_tile_w; cell.tile_h = g_tile_h; }   // FILL / COPY: tile_w = 256 << n
+    else { cell.tile_w = knobs.tile_w; cell.tile_h = knobs.tile_h; }   // FILL / COPY: tile_w = 256 << n
     const int64_t w = cell.X1 - cell.X0, h = cell.Y1 - cell.Y0;
     cell.tiles_x = static_cast<int32_t>((w + cell.tile_w - 1) / cell.tile_w);
     const int64_t tiles_y = (h + cell.tile_h - 1) / cell.tile_h;
@@ -326,7 +345,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     if (!out->bands.empty()) {
       DevBand& b = out->bands.back();
       const DevCell& f = out->cells[b.first_cell];
-      if (f.Y0 == cell.Y0 && f.Y1 == cell.Y1 && f.tile_h == cell.tile_h && !std::getenv("IST_NO_BANDS")) {
+      if (f.Y0 == cell.Y0 && f.Y1 == cell.Y1 && f.tile_h == cell.tile_h && !knobs.no_bands) {
         cell.band_x = b.tiles_per_row;
         b.tiles_per_row += cell.tiles_x;
         b.n_cells += 1;
@@ -359,7 +378,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
   // the table pays when tiles have a long set-up (resample paths: -3..5 % measured); pure fill/copy jobs keep the
   // prefix search, whose few cache lines stay hot in the scalar cache (a per-tile entry is a cold miss: +3 % measured)
   const bool resamples = info.tiles_sample + info.tiles_general > 0;
-  if (resamples && tiles <= kMaxTileTable && !std::getenv("IST_NO_TILE_TABLE")) {
+  if (resamples && tiles <= kMaxTileTable && !knobs.no_tile_table) {
     out->tiles.reserve(static_cast<size_t>(tiles));
     for (const DevBand& b : out->bands) {
       const DevCell& f = out->cells[b.first_cell];

@@ -1,0 +1,55 @@
+// ist_ctx.h — the two opaque handles of the C-ABI, shared by the runtime (ist_runtime.cpp) and the device-group layer
+// (ist_mgpu.cpp).  Reference anchors: a context stands for the canvas node obtained at pages/index/index.js:1196-1204; a
+// job for the offscreen canvas + the draws recorded on it (utils/canvas.js:131-150, index.js:1391-1428, 1532-1551).
+#ifndef IST_CTX_H_
+#define IST_CTX_H_
+
+#include <hip/hip_runtime_api.h>
+
+#include <memory>
+#include <mutex>
+
+#include "ist_host.h"
+#include "ist_internal.h"
+
+struct ist_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;          // host-buffer entry points run here; the device path takes the caller's stream
+  void* scratch_src = nullptr; size_t scratch_src_bytes = 0;
+  void* scratch_dst = nullptr; size_t scratch_dst_bytes = 0;
+  void* scratch_dec = nullptr; size_t scratch_dec_bytes = 0;   // JPEG coefficient / sample planes of ist_decode_files_device
+  std::mutex mu;                         // one host-path stitch in flight per context (index.js:772 isStitching)
+  int png_level = 1;                     // 1: Paeth + run-length + Huffman; 0: stored deflate blocks (ist_ctx_set_png_level)
+  std::unique_ptr<ist::Stager> stager;   // pinned staging ring, built on first use
+};
+
+struct ist_job {
+  ist_ctx* ctx = nullptr;
+  ist::Compiled host;
+  uint8_t* d_tables = nullptr;           // ONE device allocation holding the five tables below
+  ist::DevOp* d_ops = nullptr;
+  ist::DevCell* d_cells = nullptr;
+  ist::DevBand* d_bands = nullptr;
+  int32_t* d_stacks = nullptr;
+  ist::DevTile* d_tiles = nullptr;
+  int max_image = -1;
+};
+
+namespace ist {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// grow-only device scratch
+int grow_device(void** p, size_t* have, size_t need);
+
+}  // namespace ist
+
+#endif  // IST_CTX_H_

@@ -97,6 +97,9 @@ struct Compiled {
   ist_job_info info{};
 };
 
+// true when the process was started with IST_TUNING=1 (decided once): only then are tuning knobs read from the environment
+bool tuning_mode();
+
 // resolve + cell decomposition (host, pure CPU).  Returns IST_OK or an error code (g_last_error set).
 int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,
                 const ist_image_desc* images, int n_images, int filter, const ist_region* clip, Compiled* out);

@@ -669,23 +669,22 @@ __global__ __launch_bounds__(256) void ist_stitch_kernel(const LaunchArgs A, con
   }
 }
 
-static unsigned g_dyn_lds = 0;   // IST_DYN_LDS tuning knob: unused dynamic LDS per workgroup caps the workgroups per CU
 
 template <int PATHS, int V, bool PERSIST>
-static void launch_one(const LaunchArgs& args, int64_t n_tiles, hipStream_t stream, int persist_blocks) {
+static void launch_one(const LaunchArgs& args, int64_t n_tiles, hipStream_t stream, int persist_blocks, unsigned dyn_lds) {
   const unsigned grid = PERSIST ? static_cast<unsigned>(std::min<int64_t>(n_tiles, persist_blocks)) : static_cast<unsigned>(n_tiles);
-  const unsigned dyn = std::max(g_dyn_lds, static_cast<unsigned>(args.lds_words) * 4u);
+  const unsigned dyn = std::max(dyn_lds, static_cast<unsigned>(args.lds_words) * 4u);   // dyn_lds: IST_DYN_LDS tuning knob (unused LDS caps the workgroups per CU)
   hipLaunchKernelGGL((ist_stitch_kernel<PATHS, V, PERSIST>), dim3(grid), dim3(256), dyn, stream, args, n_tiles);
 }
 
 template <int PATHS>
-static void launch_variant(int v, bool persist, const LaunchArgs& a, int64_t n, hipStream_t s, int pb) {
-  if (persist) { launch_one<PATHS, 0, true>(a, n, s, pb); return; }      // grid-stride form of the shipped variant
+static void launch_variant(int v, bool persist, const LaunchArgs& a, int64_t n, hipStream_t s, int pb, unsigned dl) {
+  if (persist) { launch_one<PATHS, 0, true>(a, n, s, pb, dl); return; }      // grid-stride form of the shipped variant
   switch (v) {
-    case 1: launch_one<PATHS, 1, false>(a, n, s, pb); break;
-    case 2: launch_one<PATHS, 2, false>(a, n, s, pb); break;
-    case 3: launch_one<PATHS, 3, false>(a, n, s, pb); break;
-    default: launch_one<PATHS, 0, false>(a, n, s, pb); break;
+    case 1: launch_one<PATHS, 1, false>(a, n, s, pb, dl); break;
+    case 2: launch_one<PATHS, 2, false>(a, n, s, pb, dl); break;
+    case 3: launch_one<PATHS, 3, false>(a, n, s, pb, dl); break;
+    default: launch_one<PATHS, 0, false>(a, n, s, pb, dl); break;
   }
 }
 
@@ -693,16 +692,16 @@ int launch_stitch(const LaunchArgs& args, int64_t n_tiles, bool lean, void* stre
   if (n_tiles <= 0) return IST_OK;
   // tuning knobs, read only when the process was started with IST_TUNING=1 (tools/sweep_*.py): IST_VARIANT = copy variant
   // + 100 * persistent; IST_PERSIST_BLOCKS; IST_FULL_KERNEL; IST_DYN_LDS.  Production launches touch no environment.
-  static const bool tuning = std::getenv("IST_TUNING") != nullptr;
+  const bool tuning = tuning_mode();
   const int knob = tuning && std::getenv("IST_VARIANT") ? std::atoi(std::getenv("IST_VARIANT")) : 0;
   const int pb = tuning && std::getenv("IST_PERSIST_BLOCKS") ? std::atoi(std::getenv("IST_PERSIST_BLOCKS")) : 2048;
   const bool full = tuning && std::getenv("IST_FULL_KERNEL") != nullptr;
-  g_dyn_lds = tuning && std::getenv("IST_DYN_LDS") ? static_cast<unsigned>(std::atoi(std::getenv("IST_DYN_LDS"))) : 0u;
+  const unsigned dl = tuning && std::getenv("IST_DYN_LDS") ? static_cast<unsigned>(std::atoi(std::getenv("IST_DYN_LDS"))) : 0u;
   const int v = knob % 100;
   const bool persist = knob >= 100;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (lean && !full) launch_variant<HAS_FILL | HAS_COPY>(v, persist, args, n_tiles, s, pb);
-  else launch_variant<HAS_FILL | HAS_COPY | HAS_SAMPLE | HAS_GENERAL>(v, persist, args, n_tiles, s, pb);
+  if (lean && !full) launch_variant<HAS_FILL | HAS_COPY>(v, persist, args, n_tiles, s, pb, dl);
+  else launch_variant<HAS_FILL | HAS_COPY | HAS_SAMPLE | HAS_GENERAL>(v, persist, args, n_tiles, s, pb, dl);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(IST_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return IST_OK;

@@ -270,6 +270,4 @@ int ist_plan_ops(const ist_plan* plan, const ist_image_desc* images, int n_image
   return IST_OK;
 }
 
-void ist_free(void* p) { std::free(p); }
-
 }  // extern "C"

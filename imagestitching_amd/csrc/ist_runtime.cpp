@@ -14,6 +14,7 @@
 #include <mutex>
 #include <thread>
 
+#include "ist_ctx.h"
 #include "ist_internal.h"
 #include "ist_jpeg.h"
 #include "ist_launch.h"
@@ -26,67 +27,36 @@ using namespace ist;
     if (e_ != hipSuccess) return fail(IST_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
   } while (0)
 
-struct ist_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;          // used by the host-buffer path only
-  void* scratch_src = nullptr; size_t scratch_src_bytes = 0;
-  void* scratch_dst = nullptr; size_t scratch_dst_bytes = 0;
-  std::mutex mu;                         // one host-path stitch in flight per context (index.js:772 isStitching)
-  int png_level = 1;                     // 1: Paeth + run-length + Huffman; 0: stored deflate blocks (ist_ctx_set_png_level)
-};
+namespace ist {
+int ctx_png_level(const ist_ctx* ctx) { return ctx ? ctx->png_level : 0; }
 
-namespace ist { int ctx_png_level(const ist_ctx* ctx) { return ctx ? ctx->png_level : 0; } }
-
-struct ist_job {
-  ist_ctx* ctx = nullptr;
-  Compiled host;
-  DevOp* d_ops = nullptr;
-  DevCell* d_cells = nullptr;
-  DevBand* d_bands = nullptr;
-  int32_t* d_stacks = nullptr;
-  DevTile* d_tiles = nullptr;
-  int max_image = -1;
-};
-
-namespace {
-
-struct DeviceGuard {
-  int prev = -1;
-  bool ok = false;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    ok = hipSetDevice(dev) == hipSuccess;
-  }
-  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
-
-// Optionally page-locks a caller buffer for the duration of one call so that the copy engines DMA straight from / to
-// it (measured on the 9 x 12 MP host path: 42 ms instead of 50 ms).  OFF unless IST_HOST_PIN=1: registering arbitrary
-// caller memory (heap blocks that share pages with other allocations) is the one exotic runtime feature on this path and
-// is not worth a robustness risk for a path that is not the metric.  Best effort when on: failures fall back to plain copies.
-struct PinScope {
-  std::vector<void*> pinned;
-  void pin(const void* p, size_t bytes) {
-    static const bool on = std::getenv("IST_HOST_PIN") && std::atoi(std::getenv("IST_HOST_PIN")) == 1;
-    if (!on || !p || bytes < (1u << 20)) return;
-    if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) pinned.push_back(const_cast<void*>(p));
-    else (void)hipGetLastError();
-  }
-  ~PinScope() { for (void* p : pinned) (void)hipHostUnregister(p); }
-};
-
-// rows that are contiguous on both sides are ONE linear copy: the 2-D (rect) path of the runtime is only taken when a
-// pitch really differs (it has its own size limits and is slower for tall, narrow images)
-hipError_t copy_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t row, size_t rows, hipMemcpyKind kind, hipStream_t st) {
-  if (dpitch == row && spitch == row) return hipMemcpyAsync(dst, src, row * rows, kind, st);
-  return hipMemcpy2DAsync(dst, dpitch, src, spitch, row, rows, kind, st);
-}
-
-int grow(void** p, size_t* have, size_t need) {
+int grow_device(void** p, size_t* have, size_t need) {
   if (*have >= need) return IST_OK;
   if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
   IST_HIP(hipMalloc(p, need));
   *have = need;
+  return IST_OK;
+}
+}  // namespace ist
+
+namespace {
+
+Stager& stager_of(ist_ctx* ctx) {
+  if (!ctx->stager) ctx->stager.reset(new Stager(ctx->device));
+  return *ctx->stager;
+}
+
+// A buffer the library hands to the caller (freed with ist_free): a pinned block from the pool, filled by ONE linear DMA
+// from device memory, no host copy.  Synchronises `stream`.
+int read_back_pooled(const void* dev, size_t bytes, hipStream_t stream, uint8_t** out) {
+  uint8_t* host = static_cast<uint8_t*>(pool_take(bytes));
+  if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
+  if (hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+    (void)hipGetLastError();
+    pool_give(host);
+    return fail(IST_E_HIP, "result readback failed");
+  }
+  *out = host;
   return IST_OK;
 }
 
@@ -127,6 +97,8 @@ void ist_ctx_destroy(ist_ctx* ctx) {
   DeviceGuard g(ctx->device);
   if (ctx->scratch_src) (void)hipFree(ctx->scratch_src);
   if (ctx->scratch_dst) (void)hipFree(ctx->scratch_dst);
+  if (ctx->scratch_dec) (void)hipFree(ctx->scratch_dec);
+  ctx->stager.reset();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -144,21 +116,28 @@ ist_job* ist_job_create(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const 
     return nullptr;
   for (const DevOp& o : job->host.ops) job->max_image = std::max(job->max_image, o.image);
   DeviceGuard g(ctx->device);
-  auto upload = [&](void** dptr, const void* src, size_t bytes) -> bool {
-    if (bytes == 0) { *dptr = nullptr; return true; }
-    if (hipMalloc(dptr, bytes) != hipSuccess) return false;
-    return hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
-  };
+  // the five tables travel as ONE allocation and ONE copy (256-byte aligned sections)
   const Compiled& h = job->host;
-  const bool ok = upload(reinterpret_cast<void**>(&job->d_ops), h.ops.data(), h.ops.size() * sizeof(DevOp)) &&
-                  upload(reinterpret_cast<void**>(&job->d_cells), h.cells.data(), h.cells.size() * sizeof(DevCell)) &&
-                  upload(reinterpret_cast<void**>(&job->d_bands), h.bands.data(), h.bands.size() * sizeof(DevBand)) &&
-                  upload(reinterpret_cast<void**>(&job->d_stacks), h.stacks.data(), h.stacks.size() * sizeof(int32_t)) &&
-                  upload(reinterpret_cast<void**>(&job->d_tiles), h.tiles.data(), h.tiles.size() * sizeof(DevTile));
-  if (!ok) {
-    fail(IST_E_HIP, "uploading the op tables failed");
-    ist_job_destroy(job.release());
-    return nullptr;
+  const size_t bytes[5] = {h.ops.size() * sizeof(DevOp), h.cells.size() * sizeof(DevCell), h.bands.size() * sizeof(DevBand),
+                           h.stacks.size() * sizeof(int32_t), h.tiles.size() * sizeof(DevTile)};
+  const void* from[5] = {h.ops.data(), h.cells.data(), h.bands.data(), h.stacks.data(), h.tiles.data()};
+  size_t at[5], total = 0;
+  for (int k = 0; k < 5; ++k) { at[k] = total; total += (bytes[k] + 255) & ~static_cast<size_t>(255); }
+  if (total) {
+    std::vector<uint8_t> blob(total, 0);
+    for (int k = 0; k < 5; ++k) if (bytes[k]) std::memcpy(blob.data() + at[k], from[k], bytes[k]);
+    if (hipMalloc(reinterpret_cast<void**>(&job->d_tables), total) != hipSuccess ||
+        hipMemcpy(job->d_tables, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess) {      // blocking: the tables are in place when this returns
+      (void)hipGetLastError();
+      fail(IST_E_HIP, "uploading the op tables failed");
+      ist_job_destroy(job.release());
+      return nullptr;
+    }
+    job->d_ops = bytes[0] ? reinterpret_cast<DevOp*>(job->d_tables + at[0]) : nullptr;
+    job->d_cells = bytes[1] ? reinterpret_cast<DevCell*>(job->d_tables + at[1]) : nullptr;
+    job->d_bands = bytes[2] ? reinterpret_cast<DevBand*>(job->d_tables + at[2]) : nullptr;
+    job->d_stacks = bytes[3] ? reinterpret_cast<int32_t*>(job->d_tables + at[3]) : nullptr;
+    job->d_tiles = bytes[4] ? reinterpret_cast<DevTile*>(job->d_tables + at[4]) : nullptr;
   }
   return job.release();
 }
@@ -210,21 +189,18 @@ void ist_job_destroy(ist_job* job) {
   if (!job) return;
   if (job->ctx) {
     DeviceGuard g(job->ctx->device);
-    if (job->d_ops) (void)hipFree(job->d_ops);
-    if (job->d_cells) (void)hipFree(job->d_cells);
-    if (job->d_bands) (void)hipFree(job->d_bands);
-    if (job->d_stacks) (void)hipFree(job->d_stacks);
-    if (job->d_tiles) (void)hipFree(job->d_tiles);
+    if (job->d_tables) (void)hipFree(job->d_tables);
   }
   delete job;
 }
 
 // host sources -> device scratch -> fused launch into ctx->scratch_dst (left on the device, stream NOT synchronised).
-// Caller holds ctx->mu.  pins keeps the caller's buffers page-locked until it goes out of scope.
+// The scratch holds exactly the rendered region, rows contiguous (the launch addresses it as if it were the canvas: dst is
+// biased by the region's origin), so every readback is one linear copy.  Caller holds ctx->mu.
 static int render_to_scratch(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
                              const ist_op* ops, int n_ops, const ist_image_desc* images, const uint8_t* const* src,
                              const size_t* src_pitch, int n_images, int filter, const ist_region* region,
-                             PinScope* pins) {
+                             int64_t* out_w, int64_t* out_h) {
   ist_job* job = ist_job_create(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, n_images, filter, region);
   if (!job) return g_last_code ? g_last_code : IST_E_INVALID;
   struct JobFree { ist_job* j; ~JobFree() { ist_job_destroy(j); } } jf{job};
@@ -240,27 +216,33 @@ static int render_to_scratch(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, c
     off[i] = total;
     total += (static_cast<size_t>(job->host.img_w[i]) * 4 * job->host.img_h[i] + 255) & ~static_cast<size_t>(255);
   }
-  int rc = grow(&ctx->scratch_src, &ctx->scratch_src_bytes, total ? total : 256);
+  int rc = grow_device(&ctx->scratch_src, &ctx->scratch_src_bytes, total ? total : 256);
   if (rc) return rc;
-  const size_t canvas_pitch = static_cast<size_t>(canvas_w) * 4;
-  rc = grow(&ctx->scratch_dst, &ctx->scratch_dst_bytes, canvas_pitch * static_cast<size_t>(canvas_h));
+  const int64_t rw = job->host.rx1 - job->host.rx0, rh = job->host.ry1 - job->host.ry0;
+  const size_t pitch = static_cast<size_t>(rw) * 4;
+  rc = grow_device(&ctx->scratch_dst, &ctx->scratch_dst_bytes, pitch * static_cast<size_t>(rh));
   if (rc) return rc;
   std::vector<const void*> dsrc(static_cast<size_t>(n_images), nullptr);
   std::vector<size_t> dpitch(static_cast<size_t>(n_images), 0);
+  std::vector<RowsCopy> up;
   for (int i = 0; i < n_images; ++i) {
     if (!used[i]) continue;
     const size_t row = static_cast<size_t>(job->host.img_w[i]) * 4;
     const size_t hp = src_pitch ? src_pitch[i] : row;
     if (hp < row) return fail(IST_E_INVALID, "src_pitch too small");
-    pins->pin(src[i], hp * static_cast<size_t>(job->host.img_h[i] - 1) + row);
     uint8_t* d = static_cast<uint8_t*>(ctx->scratch_src) + off[i];
-    IST_HIP(copy_rows(d, row, src[i], hp, row, static_cast<size_t>(job->host.img_h[i]), hipMemcpyHostToDevice, ctx->stream));
+    up.push_back(RowsCopy{d, src[i], nullptr, hp, row, static_cast<size_t>(job->host.img_h[i])});
     dsrc[i] = d; dpitch[i] = row;
   }
-  rc = ist_job_launch(job, dsrc.data(), dpitch.data(), n_images, ctx->scratch_dst, canvas_pitch, ctx->stream);
+  rc = stager_of(ctx).upload(up, ctx->stream);
+  if (rc) return rc;
+  const uintptr_t biased = reinterpret_cast<uintptr_t>(ctx->scratch_dst) - (static_cast<uintptr_t>(job->host.ry0) * pitch + static_cast<uintptr_t>(job->host.rx0) * 4);
+  rc = ist_job_launch(job, dsrc.data(), dpitch.data(), n_images, reinterpret_cast<void*>(biased), pitch, ctx->stream);
   if (rc) return rc;
   // the job's device tables are freed when `jf` goes out of scope: the launch must have consumed them
   IST_HIP(hipStreamSynchronize(ctx->stream));
+  if (out_w) *out_w = rw;
+  if (out_h) *out_h = rh;
   return IST_OK;
 }
 
@@ -272,23 +254,19 @@ int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uin
   if (!dst) return fail(IST_E_INVALID, "ist_render_rgba8: dst is NULL");
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
-  PinScope pins;
-  int rc = render_to_scratch(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, src, src_pitch, n_images, filter, region, &pins);
-  if (rc) return rc;
-  // readback of the requested region (same-size export, index.js:1577-1579; or getImageData, 1564)
-  const size_t canvas_pitch = static_cast<size_t>(canvas_w) * 4;
-  int64_t rx = 0, ry = 0, rw = canvas_w, rh = canvas_h;
+  // the region that will be read back (same-size export, index.js:1577-1579; or getImageData, 1564): check the caller's
+  // pitch before any work is queued
+  int64_t rw = canvas_w, rh = canvas_h;
   if (region) {
-    rx = std::max<int64_t>(0, region->x); ry = std::max<int64_t>(0, region->y);
+    const int64_t rx = std::max<int64_t>(0, region->x), ry = std::max<int64_t>(0, region->y);
     rw = std::min<int64_t>(canvas_w, static_cast<int64_t>(region->x) + region->w) - rx;
     rh = std::min<int64_t>(canvas_h, static_cast<int64_t>(region->y) + region->h) - ry;
   }
-  if (dst_pitch < static_cast<size_t>(rw) * 4) return fail(IST_E_INVALID, "dst_pitch too small");
-  pins.pin(dst, dst_pitch * static_cast<size_t>(rh - 1) + static_cast<size_t>(rw) * 4);
-  const uint8_t* from = static_cast<const uint8_t*>(ctx->scratch_dst) + static_cast<size_t>(ry) * canvas_pitch + static_cast<size_t>(rx) * 4;
-  IST_HIP(copy_rows(dst, dst_pitch, from, canvas_pitch, static_cast<size_t>(rw) * 4, static_cast<size_t>(rh), hipMemcpyDeviceToHost, ctx->stream));
-  IST_HIP(hipStreamSynchronize(ctx->stream));
-  return IST_OK;
+  if (rw > 0 && dst_pitch < static_cast<size_t>(rw) * 4) return fail(IST_E_INVALID, "dst_pitch too small");
+  int rc = render_to_scratch(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, src, src_pitch, n_images, filter, region, &rw, &rh);
+  if (rc) return rc;
+  std::vector<RowsCopy> down{RowsCopy{ctx->scratch_dst, nullptr, dst, dst_pitch, static_cast<size_t>(rw) * 4, static_cast<size_t>(rh)}};
+  return stager_of(ctx).download(down, ctx->stream);
 }
 
 // PNG of a rendered op list: the canvas never leaves the device, only the PNG bytes cross PCIe
@@ -300,8 +278,7 @@ int ist_render_png(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8
   *out_png = nullptr; *out_len = 0;
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
-  PinScope pins;
-  int rc = render_to_scratch(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, src, src_pitch, n_images, filter, nullptr, &pins);
+  int rc = render_to_scratch(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, src, src_pitch, n_images, filter, nullptr, nullptr, nullptr);
   if (rc) return rc;
   const int64_t cap = ist_png_bound(canvas_w, canvas_h);
   void* dpng = nullptr;
@@ -310,11 +287,9 @@ int ist_render_png(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8
   int64_t len = 0;
   rc = ist_png_encode_device(ctx, ctx->scratch_dst, static_cast<size_t>(canvas_w) * 4, canvas_w, canvas_h, dpng, cap, &len, ctx->stream);
   if (rc) return rc;
-  uint8_t* host = static_cast<uint8_t*>(std::malloc(static_cast<size_t>(len)));
-  if (!host) return fail(IST_E_NOMEM, "out of memory for the PNG");
-  pins.pin(host, static_cast<size_t>(len));
-  if (hipMemcpyAsync(host, dpng, static_cast<size_t>(len), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-      hipStreamSynchronize(ctx->stream) != hipSuccess) { std::free(host); return fail(IST_E_HIP, "PNG readback failed"); }
+  uint8_t* host = nullptr;
+  rc = read_back_pooled(dpng, static_cast<size_t>(len), ctx->stream, &host);
+  if (rc) return rc;
   *out_png = host; *out_len = len;
   return IST_OK;
 }
@@ -423,9 +398,10 @@ int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_
   struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
   rc = jpeg_enqueue(J, d, L, d + o_out, row, ctx->stream);
   if (rc) return rc;
-  IST_HIP(copy_rows(out, out_pitch, d + o_out, row, row, static_cast<size_t>(J.height), hipMemcpyDeviceToHost, ctx->stream));
-  IST_HIP(hipStreamSynchronize(ctx->stream));
-  return IST_OK;
+  std::vector<RowsCopy> down{RowsCopy{d + o_out, nullptr, out, out_pitch, row, static_cast<size_t>(J.height)}};
+  rc = stager_of(ctx).download(down, ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);              // nothing of this call may still read the arena `fr` releases
+  return rc;
 }
 
 // format-agnostic front door: PNG (host decode) or JPEG (host entropy decode + GPU reconstruction)
@@ -575,15 +551,18 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   }
   std::vector<const void*> dsrc(static_cast<size_t>(n));
   std::vector<size_t> dpitch(static_cast<size_t>(n));
+  std::vector<RowsCopy> host_px;                  // PNG / BMP / GIF bitmaps decoded on the host
   for (int i = 0; i < n; ++i) {
     const Dec& D = dec[static_cast<size_t>(i)];
     uint8_t* img = d + o_img[static_cast<size_t>(i)];
     const size_t row = static_cast<size_t>(D.w) * 4;
     dsrc[static_cast<size_t>(i)] = img; dpitch[static_cast<size_t>(i)] = row;
-    if (!D.jpeg) { IST_HIP(hipMemcpyAsync(img, D.px.data(), D.px.size(), hipMemcpyHostToDevice, ctx->stream)); continue; }
+    if (!D.jpeg) { host_px.push_back(RowsCopy{img, D.px.data(), nullptr, row, row, static_cast<size_t>(D.h)}); continue; }
     rc = jpeg_enqueue(D.J, d, jo[static_cast<size_t>(i)], img, row, ctx->stream, D.G.eligible);
     if (rc) return rc;
   }
+  rc = stager_of(ctx).upload(host_px, ctx->stream);
+  if (rc) return rc;
   lap("H2D + JPEG reconstruct (GPU)", ctx->stream);
   // 4. the stitch: one fused launch from the decoded bitmaps (HBM) into the canvas (HBM)
   static const uint8_t transparent[4] = {0, 0, 0, 0};
@@ -598,10 +577,9 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   rc = ist_png_encode_device(ctx, d + o_canvas, canvas_pitch, out_plan->canvas_w, out_plan->canvas_h, d + o_png, png_cap, &len, ctx->stream);
   if (rc) return rc;
   lap("PNG encode (GPU)", ctx->stream);
-  uint8_t* host = static_cast<uint8_t*>(std::malloc(static_cast<size_t>(len)));
-  if (!host) return fail(IST_E_NOMEM, "out of memory for the PNG");
-  if (hipMemcpyAsync(host, d + o_png, static_cast<size_t>(len), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-      hipStreamSynchronize(ctx->stream) != hipSuccess) { std::free(host); return fail(IST_E_HIP, "PNG readback failed"); }
+  uint8_t* host = nullptr;
+  rc = read_back_pooled(d + o_png, static_cast<size_t>(len), ctx->stream, &host);
+  if (rc) return rc;
   lap("PNG D2H", nullptr);
   *out_png = host; *out_len = len;
   pg.keep = true;
@@ -616,11 +594,11 @@ int ist_png_encode_rgba8(ist_ctx* ctx, const uint8_t* pixels, size_t pitch, int6
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   const size_t row = static_cast<size_t>(w) * 4;
-  int rc = grow(&ctx->scratch_dst, &ctx->scratch_dst_bytes, row * static_cast<size_t>(h));
+  int rc = grow_device(&ctx->scratch_dst, &ctx->scratch_dst_bytes, row * static_cast<size_t>(h));
   if (rc) return rc;
-  PinScope pins;
-  pins.pin(pixels, pitch * static_cast<size_t>(h - 1) + row);
-  IST_HIP(copy_rows(ctx->scratch_dst, row, pixels, pitch, row, static_cast<size_t>(h), hipMemcpyHostToDevice, ctx->stream));
+  std::vector<RowsCopy> up{RowsCopy{ctx->scratch_dst, pixels, nullptr, pitch, row, static_cast<size_t>(h)}};
+  rc = stager_of(ctx).upload(up, ctx->stream);
+  if (rc) return rc;
   const int64_t cap = ist_png_bound(w, h);
   void* dpng = nullptr;
   IST_HIP(hipMalloc(&dpng, static_cast<size_t>(cap)));
@@ -628,9 +606,9 @@ int ist_png_encode_rgba8(ist_ctx* ctx, const uint8_t* pixels, size_t pitch, int6
   int64_t len = 0;
   rc = ist_png_encode_device(ctx, ctx->scratch_dst, row, w, h, dpng, cap, &len, ctx->stream);
   if (rc) return rc;
-  uint8_t* host = static_cast<uint8_t*>(std::malloc(static_cast<size_t>(len)));
-  if (!host) return fail(IST_E_NOMEM, "out of memory for the PNG");
-  if (hipMemcpy(host, dpng, static_cast<size_t>(len), hipMemcpyDeviceToHost) != hipSuccess) { std::free(host); return fail(IST_E_HIP, "PNG readback failed"); }
+  uint8_t* host = nullptr;
+  rc = read_back_pooled(dpng, static_cast<size_t>(len), ctx->stream, &host);
+  if (rc) return rc;
   *out_png = host; *out_len = len;
   return IST_OK;
 }
@@ -649,15 +627,26 @@ int ist_stitch_rgba8(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* 
   int n_ops = 0;
   rc = ist_plan_ops(out_plan, images, n_images, ops.data(), &n_ops);
   if (rc != IST_OK) { ist_plan_free(out_plan); return rc; }
-  const size_t pitch = static_cast<size_t>(out_plan->canvas_w) * 4;
-  uint8_t* px = static_cast<uint8_t*>(std::malloc(pitch * static_cast<size_t>(out_plan->canvas_h)));
-  if (!px) { ist_plan_free(out_plan); return fail(IST_E_NOMEM, "out of memory for the output canvas"); }
   static const uint8_t transparent[4] = {0, 0, 0, 0};
-  rc = ist_render_rgba8(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, images, src,
-                        src_pitch, n_images, filter, nullptr, px, pitch);
-  if (rc != IST_OK) { std::free(px); ist_plan_free(out_plan); return rc; }
-  *out_pixels = px;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard g(ctx->device);
+    rc = render_to_scratch(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, images, src, src_pitch,
+                           n_images, filter, nullptr, nullptr, nullptr);
+    // the export (index.js:1577-1579): the whole canvas in one DMA into a pinned block of the pool
+    if (rc == IST_OK)
+      rc = read_back_pooled(ctx->scratch_dst, static_cast<size_t>(out_plan->canvas_w) * 4 * static_cast<size_t>(out_plan->canvas_h), ctx->stream, out_pixels);
+  }
+  if (rc != IST_OK) { ist_plan_free(out_plan); return rc; }
   return IST_OK;
 }
+
+// buffers handed out by the library: pinned blocks go back to the pool, anything else was malloc'ed
+void ist_free(void* p) {
+  if (!p) return;
+  if (!pool_give(p)) std::free(p);
+}
+
+void ist_pool_trim(void) { pool_trim(); }
 
 }  // extern "C"

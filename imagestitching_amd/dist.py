@@ -1,19 +1,26 @@
-"""Multi-GPU stitch: disjoint image subsets per rank + ONE gather of finished bands to the root (RCCL over xGMI).
+"""Multi-GPU stitch, one process per GPU: disjoint parts per rank + ONE gather of finished bands to the root (RCCL over xGMI).
 
 Reference anchor: the per-image loop of onStitch (pages/index/index.js:1439-1554) — iterations share only the
-cursor, which the planner precomputes, so every image's destination box is an independent unit.  Layout
-(BASELINE.json north_star / SURVEY.md section 8e): one process per GPU, image i -> rank i mod world; each rank renders
-its images into compact bands (canvas-space boxes); the root assembles the strip:
-  * boxes that span the full canvas width are contiguous byte ranges of the canvas -> received IN PLACE
-    (the root's own launch leaves those rows untouched: op kind HOLE);
-  * other boxes (horizontal strips, centred 'original' rects) are received into staging bands and placed by the
-    root's fused launch as 1:1 draws (one extra read+write of the band on the root).
+cursor, which the planner precomputes, so every draw's destination box (and any range of its rows) is an independent
+unit.  Layout (BASELINE.json north_star / SURVEY.md section 8e): the job is cut into PARTS by the C-ABI's own
+ist_shard_parts (the single-process device group, ist_mgpu_*, cuts the same way):
+  split="image"  image i -> rank i mod world (BASELINE configs[3]: images round-robin; 9 images on 8 GPUs leave GPU 0
+                 with two)
+  split="band"   canvas rows dealt out so that every rank renders the same number of output pixels; a rank then needs
+                 only the source rows its rows sample (still disjoint input subsets, up to one shared row at a cut)
+Each rank renders its parts into compact bands; the root assembles the strip:
+  * parts that span the full canvas width are contiguous byte ranges of the canvas -> received IN PLACE while the root's
+    own launch runs (that launch leaves those rows untouched: op kind HOLE);
+  * other parts (horizontal strips, centred 'original' rects) are received into staging bands; each is placed by its own
+    small launch as soon as ITS receive has completed, so placement overlaps the receives still in flight.
 The exchange is one grouped batch of point-to-point sends/recvs (RCCL has no gatherv): torch.distributed
-batch_isend_irecv -> ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd.
+batch_isend_irecv -> ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd.  No ring, no all-gather: xGMI is point to
+point and every peer has its own link to the root.
 
 The render backend is injected so that the sharding / assembly logic can be covered on CPU with gloo
 (tests pass an oracle-backed renderer; the product default is the HIP path and nothing else).
 """
+import ctypes as C
 import importlib
 
 from . import _lib as L
@@ -21,96 +28,122 @@ from . import _lib as L
 S = importlib.import_module(".stitch", __package__)   # the package attribute `stitch` is the function, not the module
 
 OP_FILL, OP_DRAW, OP_HOLE = 0, 1, 2
+_SPLITS = {"image": L.SPLIT_IMAGE, "band": L.SPLIT_BAND}
 
 
 def owner_of(image_index, world):
-    """BASELINE configs[3]: images round-robin over the GPUs."""
+    """BASELINE configs[3] (split="image"): images round-robin over the GPUs."""
     return image_index % world
 
 
-def _boxes(plan, filter_name):
-    """Canvas-space pixel boxes of every draw, from the C-ABI's own resolve step (ist_op_box: pure CPU)."""
-    import ctypes as C
+class Part:
+    """One unit of work: canvas box (X0, Y0, X1, Y1) of draw `op` (image `image`), rendered by `slot`."""
+    __slots__ = ("index", "image", "op", "slot", "X0", "Y0", "X1", "Y1", "sy0", "sy1", "in_place")
+
+    def __init__(self, index, c):
+        self.index = index
+        self.image, self.op, self.slot = c.image, c.op, c.slot
+        self.X0, self.Y0, self.X1, self.Y1 = c.X0, c.Y0, c.X1, c.Y1
+        self.sy0, self.sy1 = c.sy0, c.sy1
+        self.in_place = bool(c.in_place)
+
+    @property
+    def shape(self):
+        return (self.Y1 - self.Y0, self.X1 - self.X0, 4)
+
+    @property
+    def nbytes(self):
+        return (self.Y1 - self.Y0) * (self.X1 - self.X0) * 4
+
+
+def shard_parts(plan, filter_code, n_slots, split):
+    """ist_shard_parts through the C-ABI (pure CPU)."""
     ops, n_ops = plan.ops()
-    boxes = {}
-    box = (C.c_int32 * 4)()
-    f = {"nearest": L.FILTER_NEAREST, "bilinear": L.FILTER_BILINEAR}[filter_name]
-    for k in range(1, n_ops):
-        rc = L.check(L.lib.ist_op_box(C.byref(ops[k]), plan.canvas_w, plan.canvas_h, f, box))
-        if rc == 0 and box[2] > box[0] and box[3] > box[1]:      # a draw clipped away entirely (the reference's orientation-7 first image) has no band
-            boxes[ops[k].image] = (box[0], box[1], box[2], box[3], k)
-    return boxes
-
-
-def _overlap(p, q):
-    return p[0] < q[2] and q[0] < p[2] and p[1] < q[3] and q[1] < p[3]
+    cap = n_ops + n_slots + 8
+    arr = (L.Part * cap)()
+    cnt = C.c_int(0)
+    L.check(L.lib.ist_shard_parts(ops, n_ops, plan.canvas_w, plan.canvas_h, plan._descs, plan.n_images, filter_code,
+                                  n_slots, _SPLITS[split], arr, cap, C.byref(cnt)))
+    return [Part(k, arr[k]) for k in range(cnt.value)]
 
 
 class ShardedStitch:
     """One stitch job sharded over `world` ranks.  Construct on every rank with identical arguments."""
 
-    def __init__(self, images, direction, opts=None, rank=0, world=1, root=0):
-        self.rank, self.world, self.root = rank, world, root
+    def __init__(self, images, direction, opts=None, rank=0, world=1, root=0, split="image"):
+        self.rank, self.world, self.root, self.split = rank, world, root, split
         self.opts = S._merge(opts)
-        if self.opts.get("edgeAA"):
-            raise L.StitchError(-7, "edge anti-aliasing blends neighbouring images in one pixel row: stitch on one GPU")
         self.plan = S.plan(images, direction, self.opts)
         if self.plan is None:
             raise ValueError("nothing to stitch")
         self.n = len(images)
-        self.boxes = _boxes(self.plan, self.opts["filter"])
-        bl = [self.boxes[i] for i in sorted(self.boxes)]
-        for i in range(len(bl)):
-            for j in range(i + 1, len(bl)):
-                if _overlap(bl[i], bl[j]):
-                    raise L.StitchError(-7, "overlapping draws cannot be sharded across GPUs (stitch on one GPU)")
-        self.mine = [i for i in range(self.n) if owner_of(i, world) == rank and i in self.boxes]
-        self.remote = [i for i in range(self.n) if owner_of(i, world) != root and i in self.boxes]
-        cw = self.plan.canvas_w
-        # a box that spans the full width is a contiguous byte range of the canvas -> in-place receive
-        self.in_place = {i: (self.boxes[i][0] == 0 and self.boxes[i][2] == cw) for i in self.boxes}
+        self.filter = S._filter_of(self.opts)
+        # edge anti-aliasing makes neighbouring draws share a pixel row: ist_shard_parts refuses (IST_E_UNSUPPORTED)
+        self.parts = shard_parts(self.plan, self.filter, world, split)
+        self.slot = (rank - root) % world
+        self.mine = [p for p in self.parts if p.slot == self.slot]
+        self.remote = [p for p in self.parts if p.slot != 0]
+
+    def rank_of(self, part):
+        return (part.slot + self.root) % self.world
+
+    def rows_needed(self, slot=None):
+        """{image: (first_row, end_row)} of the source rows the slot's parts sample: what that rank must hold."""
+        slot = self.slot if slot is None else slot
+        need = {}
+        for p in self.parts:
+            if p.slot != slot:
+                continue
+            a, b = need.get(p.image, (p.sy0, p.sy1))
+            need[p.image] = (min(a, p.sy0), max(b, p.sy1))
+        return need
 
     # ---- op lists ------------------------------------------------------------------------------------------------
-    def band_ops(self, i):
-        """ops + clip for rendering image i's band on its owner: white fill + that draw, clipped to its box."""
+    def band_ops(self, part):
+        """ops + clip for rendering a part on its owner: white fill + that draw, clipped to the part's box."""
         ops, _ = self.plan.ops()
-        X0, Y0, X1, Y1, k = self.boxes[i]
-        sel = (L.Op * 2)(ops[0], ops[k])
-        return sel, 2, (X0, Y0, X1 - X0, Y1 - Y0)
+        sel = (L.Op * 2)(ops[0], ops[part.op])
+        return sel, 2, (part.X0, part.Y0, part.X1 - part.X0, part.Y1 - part.Y0)
 
     def root_ops(self):
-        """ops for the root's single fused launch: fill, its own draws, HOLEs for in-place bands, 1:1 draws for
-        staged bands.  Returns (ops, n_ops, descs, n_images, staged) where staged[j] = image index behind extra
-        source slot n + j."""
+        """ops of the root's own fused launch: the fill, every draw the root owns a part of, and a HOLE over every part
+        another rank delivers (listed last: the launch then writes nothing there, whatever lies under it)."""
         ops, n_ops = self.plan.ops()
-        staged = [i for i in self.remote if not self.in_place[i]]
-        out = [ops[0]]
-        for k in range(1, n_ops):
-            o = ops[k]
-            i = o.image
-            if owner_of(i, self.world) == self.root:
-                out.append(o)
-                continue
-            if i not in self.boxes:
-                continue
-            X0, Y0, X1, Y1, _ = self.boxes[i]
+        own = sorted({p.op for p in self.parts if p.slot == 0})
+        out = [ops[0]] + [ops[k] for k in own]
+        for p in self.remote:
             r = L.Op()
+            r.kind, r.image = OP_HOLE, -1
             r.m[:] = [1.0, 0.0, 0.0, 1.0, 0.0, 0.0]
-            r.d[:] = [float(X0), float(Y0), float(X1 - X0), float(Y1 - Y0)]
-            if self.in_place[i]:
-                r.kind, r.image = OP_HOLE, -1
-            else:
-                r.kind, r.image = OP_DRAW, self.n + staged.index(i)
-                r.s[:] = [0.0, 0.0, float(X1 - X0), float(Y1 - Y0)]
+            r.d[:] = [float(p.X0), float(p.Y0), float(p.X1 - p.X0), float(p.Y1 - p.Y0)]
             out.append(r)
-        descs = (L.ImageDesc * (self.n + len(staged)))()
-        for i in range(self.n):
-            descs[i] = self.plan._descs[i]
-        for j, i in enumerate(staged):
-            X0, Y0, X1, Y1, _ = self.boxes[i]
-            descs[self.n + j] = L.ImageDesc(X1 - X0, Y1 - Y0, 1, 0, 0, 1, 0)   # finished band: opaque
-        arr = (L.Op * len(out))(*out)
-        return arr, len(out), descs, self.n + len(staged), staged
+        return (L.Op * len(out))(*out), len(out)
+
+    @staticmethod
+    def place_ops(part):
+        """ops + descs + clip of the launch that places one staged band: a 1:1 draw of the band at the part's box."""
+        r = L.Op()
+        r.kind, r.image = OP_DRAW, 0
+        r.m[:] = [1.0, 0.0, 0.0, 1.0, 0.0, 0.0]
+        w, h = part.X1 - part.X0, part.Y1 - part.Y0
+        r.s[:] = [0.0, 0.0, float(w), float(h)]
+        r.d[:] = [float(part.X0), float(part.Y0), float(w), float(h)]
+        descs = (L.ImageDesc * 1)(L.ImageDesc(w, h, 1, 0, 0, 1, 0))          # a finished band: opaque
+        return (L.Op * 1)(r), 1, descs, (part.X0, part.Y0, w, h)
+
+
+class SourceRows:
+    """Rows [first_row, first_row + tensor.shape[0]) of an image: what a rank holds of an image it renders a band of.
+    The buffer must be readable for 16 bytes past its last row (allocate one spare row, see alloc_rows)."""
+
+    def __init__(self, tensor, first_row=0):
+        self.tensor, self.first_row = tensor, int(first_row)
+
+
+def alloc_rows(torch, rows, width, device):
+    """An HxWx4 uint8 view of a buffer with one spare row behind it (the resample paths may read up to 12 bytes past the
+    last sampled pixel of a row)."""
+    return torch.empty((rows + 1, width, 4), dtype=torch.uint8, device=device)[:rows]
 
 
 class HipBackend:
@@ -123,69 +156,92 @@ class HipBackend:
         self.device = torch.device("cuda", device)
         self.st = S.Stitcher(device)
         sh = sharded
-        f = sh.opts["filter"]
         self.band_jobs, self.bands = {}, {}
-        if sh.rank != sh.root:
-            for i in sh.mine:
-                ops, n_ops, clip = sh.band_ops(i)
-                self.band_jobs[i] = self.st.compile_ops(sh.plan.canvas_w, sh.plan.canvas_h, ops, n_ops, sh.plan._descs, sh.n, f, clip=clip)
-                X0, Y0, X1, Y1, _ = sh.boxes[i]
-                self.bands[i] = torch.empty((Y1 - Y0, X1 - X0, 4), dtype=torch.uint8, device=self.device)
+        self.place_jobs, self.staging = {}, {}
+        if sh.slot != 0:
+            for p in sh.mine:
+                ops, n_ops, clip = sh.band_ops(p)
+                self.band_jobs[p.index] = self.st.compile_ops(sh.plan.canvas_w, sh.plan.canvas_h, ops, n_ops, sh.plan._descs, sh.n, sh.filter, clip=clip)
+                self.bands[p.index] = torch.empty(p.shape, dtype=torch.uint8, device=self.device)
         else:
-            ops, n_ops, descs, n_img, staged = sh.root_ops()
-            self.root_job = self.st.compile_ops(sh.plan.canvas_w, sh.plan.canvas_h, ops, n_ops, descs, n_img, f)
-            self.staged = staged
-            self.staging = {}
-            for i in staged:
-                X0, Y0, X1, Y1, _ = sh.boxes[i]
-                self.staging[i] = torch.empty((Y1 - Y0, X1 - X0, 4), dtype=torch.uint8, device=self.device)
+            ops, n_ops = sh.root_ops()
+            self.root_job = self.st.compile_ops(sh.plan.canvas_w, sh.plan.canvas_h, ops, n_ops, sh.plan._descs, sh.n, sh.filter)
+            for p in sh.remote:
+                if p.in_place:
+                    continue
+                pops, pn, pdescs, clip = sh.place_ops(p)
+                self.place_jobs[p.index] = self.st.compile_ops(sh.plan.canvas_w, sh.plan.canvas_h, pops, pn, pdescs, 1, "nearest", clip=clip)
+                self.staging[p.index] = torch.empty(p.shape, dtype=torch.uint8, device=self.device)
 
     def new_canvas(self):
         p = self.sh.plan
         return self.torch.empty((p.canvas_h, p.canvas_w, 4), dtype=self.torch.uint8, device=self.device)
 
-    def render_band(self, i, srcs):
-        """Owner side: band i = canvas box of image i, rendered straight into a compact buffer (the launch addresses
-        the band as if it were the canvas: dst is biased by -(Y0*pitch + X0*4), the clip keeps writes inside)."""
-        X0, Y0, X1, Y1, _ = self.sh.boxes[i]
-        band = self.bands[i]
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    @staticmethod
+    def _ptrs(srcs):
+        """device pointer of row 0 (biased for partial holdings) and pitch per image"""
+        ptrs, pitches = [], []
+        for s in srcs:
+            if s is None:
+                ptrs.append(0); pitches.append(0)
+            elif isinstance(s, SourceRows):
+                pitch = s.tensor.stride(0)
+                ptrs.append(s.tensor.data_ptr() - s.first_row * pitch); pitches.append(pitch)
+            else:
+                ptrs.append(s.data_ptr()); pitches.append(s.stride(0))
+        return ptrs, pitches
+
+    def render_band(self, part, srcs):
+        """Owner side: the part's canvas box rendered straight into a compact buffer (the launch addresses the band as if
+        it were the canvas: dst is biased by -(Y0*pitch + X0*4), the clip keeps writes inside)."""
+        band = self.bands[part.index]
         pitch = band.stride(0)
-        ptrs = [0 if t is None else t.data_ptr() for t in srcs]
-        pitches = [0 if t is None else t.stride(0) for t in srcs]
-        self.band_jobs[i].launch_ptrs(ptrs, pitches, band.data_ptr() - (Y0 * pitch + X0 * 4), pitch,
-                                      self.torch.cuda.current_stream(self.device).cuda_stream)
+        ptrs, pitches = self._ptrs(srcs)
+        self.band_jobs[part.index].launch_ptrs(ptrs, pitches, band.data_ptr() - (part.Y0 * pitch + part.X0 * 4), pitch, self._stream())
         return band
 
     def render_root(self, srcs, canvas):
-        full = list(srcs) + [self.staging[i] for i in self.staged]
-        self.root_job.launch(full, canvas)
+        ptrs, pitches = self._ptrs(srcs)
+        self.root_job.launch_ptrs(ptrs, pitches, canvas.data_ptr(), canvas.stride(0), self._stream())
+
+    def place(self, part, canvas):
+        band = self.staging[part.index]
+        self.place_jobs[part.index].launch_ptrs([band.data_ptr()], [band.stride(0)], canvas.data_ptr(), canvas.stride(0), self._stream())
 
 
 def run_step(sh, backend, srcs, canvas, dist):
-    """One sharded stitch.  srcs: per-image source buffers (None for images this rank does not own).
-    canvas: root's output buffer (None elsewhere).  dist: torch.distributed (initialised).  Returns the canvas on root."""
+    """One sharded stitch.  srcs: per-image source buffers (None for images this rank holds nothing of; SourceRows for
+    partial holdings).  canvas: root's output buffer (None elsewhere).  dist: torch.distributed (initialised).
+    Returns the canvas on root."""
     ops = []
-    if sh.rank == sh.root:
-        recv_staged = False
-        for i in sh.remote:
-            X0, Y0, X1, Y1, _ = sh.boxes[i]
-            if sh.in_place[i]:
-                ops.append(dist.P2POp(dist.irecv, canvas[Y0:Y1], owner_of(i, sh.world)))
+    if sh.slot == 0:
+        staged = []
+        for p in sh.remote:
+            if p.in_place:
+                ops.append(dist.P2POp(dist.irecv, canvas[p.Y0:p.Y1], sh.rank_of(p)))
             else:
-                ops.append(dist.P2POp(dist.irecv, backend.staging[i], owner_of(i, sh.world)))
-                recv_staged = True
-        # post the receives first: the communication stream then runs beside the root's own launch, which never
-        # touches the in-place rows (op kind HOLE)
+                ops.append(dist.P2POp(dist.irecv, backend.staging[p.index], sh.rank_of(p)))
+            staged.append(None if p.in_place else p)
+        # post the receives first: they then run beside the root's own launch, which touches none of those pixels
         reqs = dist.batch_isend_irecv(ops) if ops else []
-        if not recv_staged:
-            backend.render_root(srcs, canvas)
-        for r in reqs:
-            r.wait()
-        if recv_staged:
-            backend.render_root(srcs, canvas)          # staged bands are sources of the fused launch
+        backend.render_root(srcs, canvas)
+        # one request per batch (NCCL coalesces the group) or one per op (gloo): either way every receive has landed once
+        # the requests it may belong to are done; staged bands are placed as their receive completes
+        per_op = len(reqs) == len(ops)
+        if not per_op:
+            for r in reqs:
+                r.wait()
+        for k, p in enumerate(staged):
+            if per_op:
+                reqs[k].wait()
+            if p is not None:
+                backend.place(p, canvas)
         return canvas
-    for i in sh.mine:
-        band = backend.render_band(i, srcs)
+    for p in sh.mine:
+        band = backend.render_band(p, srcs)
         ops.append(dist.P2POp(dist.isend, band, sh.root))
     reqs = dist.batch_isend_irecv(ops) if ops else []
     for r in reqs:

@@ -174,41 +174,9 @@ def stitch(images, direction, opts=None, device=0):
         keep.append(a)
         ptrs[i] = a.ctypes.data
         pitches[i] = a.strides[0]
-    # plan on the CPU, then render straight into the numpy result (ist_stitch_rgba8 is the same two steps with a
-    # malloc'ed output; going through it would cost one more 439 MB host copy here)
-    cplan = L.Plan()
-    lim = _limits(o)
-    rc = L.check(L.lib.ist_plan_compute(descs, n, _DIRECTIONS[direction], _MODES[o["mode"]], float(o["gap"] or 0),
-                                        C.byref(lim), C.byref(cplan)))
-    if rc == L.IST_NOTHING_TO_DO:
-        return None
-    try:
-        w, h = int(cplan.canvas_w), int(cplan.canvas_h)
-        ops = (L.Op * (cplan.n_rects + 1))()
-        n_ops = C.c_int(0)
-        L.check(L.lib.ist_plan_ops(C.byref(cplan), descs, n, ops, C.byref(n_ops)))
-        data = np.empty((h, w, 4), np.uint8)
-        clear = (C.c_uint8 * 4)(0, 0, 0, 0)
-        L.check(L.lib.ist_render_rgba8(_ctx(device), w, h, clear, ops, n_ops.value, descs, ptrs, pitches, n,
-                                       _filter_of(o), None, data.ctypes.data, data.strides[0]))
-    finally:
-        L.lib.ist_plan_free(C.byref(cplan))
-    return {"width": w, "height": h, "data": data}
-
-
-def stitch_via_c_abi(images, direction, opts=None, device=0):
-    """Same as stitch() through the one-call C entry point ist_stitch_rgba8 (what the N-API addon binds)."""
-    o = _merge(opts)
-    n = len(images)
-    if n == 0:
-        return None
-    descs = _descs(images)
-    keep, ptrs, pitches = [], (C.c_void_p * n)(), (C.c_size_t * n)()
-    for i, im in enumerate(images):
-        a = np.ascontiguousarray(im["data"] if isinstance(im, dict) else im)
-        keep.append(a)
-        ptrs[i] = a.ctypes.data
-        pitches[i] = a.strides[0]
+    # ist_stitch_rgba8 (what the N-API addon binds): plan, render, and the export as ONE DMA into a pinned block of the
+    # library's pool; the numpy array below is a view of that block (no host copy) and returns it to the pool when it
+    # is garbage collected
     cplan = L.Plan()
     lim = _limits(o)
     out = C.POINTER(C.c_uint8)()
@@ -216,13 +184,50 @@ def stitch_via_c_abi(images, direction, opts=None, device=0):
                                         float(o["gap"] or 0), C.byref(lim), _filter_of(o), C.byref(cplan), C.byref(out)))
     if rc == L.IST_NOTHING_TO_DO:
         return None
-    try:
-        w, h = int(cplan.canvas_w), int(cplan.canvas_h)
-        data = np.ctypeslib.as_array(out, shape=(h, w, 4)).copy()
-    finally:
-        L.lib.ist_free(out)
-        L.lib.ist_plan_free(C.byref(cplan))
-    return {"width": w, "height": h, "data": data}
+    w, h = int(cplan.canvas_w), int(cplan.canvas_h)
+    L.lib.ist_plan_free(C.byref(cplan))
+    return {"width": w, "height": h, "data": _take_pixels(out, w, h)}
+
+
+def _take_pixels(out, w, h):
+    """HxWx4 uint8 view of a library-owned result; ist_free runs when the last view dies."""
+    import weakref
+    raw = (C.c_uint8 * (w * h * 4)).from_address(C.addressof(out.contents))
+    weakref.finalize(raw, L.lib.ist_free, C.cast(out, C.c_void_p))
+    return np.frombuffer(raw, np.uint8).reshape(h, w, 4)
+
+
+def render_ops(canvas_w, canvas_h, ops, n_ops, descs, srcs, filter="bilinear", clear=(0, 0, 0, 0), region=None, device=0):
+    """A recorded Canvas op list -> HxWx4 uint8 (ist_render_rgba8: what the Canvas-2D shim's export / getImageData binds).
+    srcs: list of HxWx4 uint8 arrays (None for images no op draws)."""
+    n = len(srcs)
+    keep, ptrs, pitches = [], (C.c_void_p * max(1, n))(), (C.c_size_t * max(1, n))()
+    for i, a in enumerate(srcs):
+        if a is None:
+            continue
+        a = np.ascontiguousarray(a)
+        keep.append(a)
+        ptrs[i] = a.ctypes.data
+        pitches[i] = a.strides[0]
+    reg, rw, rh = None, int(canvas_w), int(canvas_h)
+    if region is not None:
+        x, y, w, h = [int(v) for v in region]
+        reg = C.byref(L.Region(x, y, w, h))
+        rw, rh = min(canvas_w, x + w) - max(0, x), min(canvas_h, y + h) - max(0, y)
+    data = np.empty((rh, rw, 4), np.uint8)
+    clr = (C.c_uint8 * 4)(*clear)
+    f = (_FILTERS[filter] if isinstance(filter, str) else int(filter))
+    L.check(L.lib.ist_render_rgba8(_ctx(device), int(canvas_w), int(canvas_h), clr, ops, int(n_ops), descs, ptrs, pitches, n,
+                                   f, reg, data.ctypes.data, data.strides[0]))
+    return data
+
+
+def stitch_via_c_abi(images, direction, opts=None, device=0):
+    """stitch() with the result copied into ordinary Python-owned memory (the pinned block goes straight back to the pool)."""
+    r = stitch(images, direction, opts, device)
+    if r is not None:
+        r["data"] = r["data"].copy()
+    return r
 
 
 def _take_png(out, n, copy=True):

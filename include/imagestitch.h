@@ -28,7 +28,7 @@ extern "C" {
 
 #define IST_API __attribute__((visibility("default")))
 
-#define IST_ABI_VERSION 1
+#define IST_ABI_VERSION 2     /* 2: output capacity on the decode calls, pooled pinned results, device groups */
 
 /* error codes */
 enum {
@@ -139,6 +139,25 @@ IST_API int ist_plan_ops(const ist_plan* plan, const ist_image_desc* images, int
  * Pure CPU; what the multi-GPU layer uses to cut a stitch into per-image bands. */
 IST_API int ist_op_box(const ist_op* op, int64_t canvas_w, int64_t canvas_h, int filter, int32_t box[4]);
 
+/* ---- sharding: one stitch cut into parts for a group of GPUs (pure CPU) ----------------------------------------- */
+/* The per-image iterations of onStitch are independent once the cursor is planned (index.js:1439-1554).  A PART is a
+ * canvas box of ONE draw, rendered by one GPU (its slot) over the background alone; the root (slot 0) assembles them.
+ * IST_SPLIT_IMAGE: image i -> slot i mod n_slots (BASELINE configs[3]).  IST_SPLIT_BAND: canvas rows dealt in canvas
+ * order so that every slot renders the same number of output pixels (9 images on 8 GPUs: 1.125 images each); cuts fall
+ * on multiples of 8 rows inside a draw's box.  A slot needs only source rows [sy0, sy1) of the part's image (readable
+ * for 16 bytes past the last row when a partial buffer is passed, biased by -sy0 rows, to ist_job_launch).
+ * Draws that overlap (edge anti-aliasing makes neighbours share a pixel row) cannot be sharded: IST_E_UNSUPPORTED. */
+enum { IST_SPLIT_IMAGE = 0, IST_SPLIT_BAND = 1 };
+typedef struct ist_part {
+  int32_t image, op;          /* source image; index of the draw in the op list */
+  int32_t slot;               /* owner, 0 .. n_slots-1; slot 0 is the root */
+  int32_t X0, Y0, X1, Y1;     /* canvas box, half open */
+  int32_t sx0, sy0, sx1, sy1; /* source columns / rows the part samples, half open */
+  int32_t in_place;           /* the box spans the canvas width: a contiguous byte range of the canvas */
+} ist_part;
+IST_API int ist_shard_parts(const ist_op* ops, int n_ops, int64_t canvas_w, int64_t canvas_h, const ist_image_desc* images,
+                            int n_images, int filter, int n_slots, int split, ist_part* parts, int max_parts, int* n_parts);
+
 /* ---- device path: inputs and output already resident in HBM ------------------------------------------------- */
 IST_API ist_ctx* ist_ctx_create(int device);
 IST_API void ist_ctx_destroy(ist_ctx* ctx);
@@ -162,8 +181,12 @@ IST_API int ist_job_launch(ist_job* job, const void* const* src, const size_t* s
 IST_API void ist_job_destroy(ist_job* job);
 
 /* ---- host path: what stitch(images, direction, opts) binds (host RGBA8 in, host RGBA8 out) ------------------- */
-/* index.js:1251-1581 minus decode (1441-1520) and PNG encode (1579): plan, then render.
- * *out_pixels is malloc'ed by the library (canvas_w*canvas_h*4 bytes, pitch canvas_w*4); free with ist_free. */
+/* Transfers of this group: the library never page-locks or registers memory it does not own.  Caller buffers (pageable,
+ * any pitch) are packed through a ring of pinned chunks by a few host threads; buffers the library RETURNS are pinned
+ * blocks of a process-wide pool, filled by one DMA, and go back to the pool through ist_free (ist_pool_trim releases the
+ * idle ones).
+ * index.js:1251-1581 minus decode (1441-1520) and PNG encode (1579): plan, then render.
+ * *out_pixels is owned by the library (canvas_w*canvas_h*4 bytes, pitch canvas_w*4); release with ist_free. */
 IST_API int ist_stitch_rgba8(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* const* src,
                              const size_t* src_pitch, int n_images, int direction, int mode, double gap,
                              const ist_limits* limits, int filter, ist_plan* out_plan, uint8_t** out_pixels);
@@ -172,7 +195,8 @@ IST_API int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, c
                              const ist_op* ops, int n_ops, const ist_image_desc* images,
                              const uint8_t* const* src, const size_t* src_pitch, int n_images, int filter,
                              const ist_region* region, uint8_t* dst, size_t dst_pitch);
-IST_API void ist_free(void* p);
+IST_API void ist_free(void* p);                /* any buffer the library returned through an out pointer */
+IST_API void ist_pool_trim(void);              /* release the idle pinned blocks ist_free is keeping for reuse */
 
 /* ---- decode: PNG file -> RGBA8 (host; the Image.src step, utils/canvas.js:27-121, for 'png' inputs, index.js:4) ---- */
 /* colour types 0/2/3/4/6, bit depths 1-16 (16-bit keeps the high byte), tRNS, plain or Adam7-interlaced.  JPEG / WebP /
@@ -206,7 +230,7 @@ IST_API int64_t ist_png_bound(int64_t w, int64_t h);
  * pass; the checksums are combined on the host, so the call synchronises `stream` before it returns */
 IST_API int ist_png_encode_device(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* out,
                                   int64_t out_cap, int64_t* out_len, void* stream);
-/* host pixels -> PNG bytes (malloc'ed, free with ist_free) */
+/* host pixels -> PNG bytes (library-owned, release with ist_free) */
 IST_API int ist_png_encode_rgba8(ist_ctx* ctx, const uint8_t* pixels, size_t pitch, int64_t w, int64_t h,
                                  uint8_t** out_png, int64_t* out_len);
 /* recorded Canvas op list -> PNG bytes (wx.canvasToTempFilePath of the shim); the canvas never leaves the device */

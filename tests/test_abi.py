@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libimagestitch.so does not export %s" % name
     bound = {n for n, _, _ in L.SYMBOLS}
     assert bound == set(_declared()), "python binding and header disagree: %s" % (bound ^ set(_declared()))
-    assert L.lib.ist_abi_version() == 1
+    assert L.lib.ist_abi_version() == 2
 
 
 def test_header_compiles_as_plain_c(tmp_path):

@@ -1,5 +1,6 @@
-"""world_size-2 coverage of the multi-GPU layout (imagestitching_amd/dist.py) on CPU with gloo: sharding by image,
-band rendering, in-place vs staged receives, root assembly.  The render backend is the oracle here (test-only
+"""world_size >= 2 coverage of the multi-GPU layout (imagestitching_amd/dist.py) on CPU with gloo: the part table of
+ist_shard_parts (by image and by band), band rendering from PARTIAL source holdings, in-place vs staged receives, the
+root's own launch with HOLEs and the per-band placement launches.  The render backend is the oracle here (test-only
 injection); the product backend is HipBackend."""
 import os
 import socket
@@ -23,8 +24,7 @@ class OracleBackend:
         self.O, self.sh, self.pixels = O, sh, pixels
         self.descs = [{"width": a.shape[1], "height": a.shape[0], "orientation": 1} for a in pixels]
         self.bands = {}
-        self.staged = [i for i in sh.remote if not sh.in_place[i]]
-        self.staging = {i: torch.empty((sh.boxes[i][3] - sh.boxes[i][1], sh.boxes[i][2] - sh.boxes[i][0], 4), dtype=torch.uint8) for i in self.staged}
+        self.staging = {p.index: torch.empty(p.shape, dtype=torch.uint8) for p in sh.remote if not p.in_place}
 
     def new_canvas(self):
         return torch.full((self.sh.plan.canvas_h, self.sh.plan.canvas_w, 4), 0x5A, dtype=torch.uint8)
@@ -35,22 +35,31 @@ class OracleBackend:
                 {"kind": "hole", "rect": list(o.d)} if o.kind == 2 else
                 {"kind": "draw", "image": o.image, "m": list(o.m), "s": list(o.s), "d": list(o.d)} for o in arr[:n]]
 
-    def render_band(self, i, srcs):
-        ops, n, clip = self.sh.band_ops(i)
-        full = self.O.render_ops(self.sh.plan.canvas_w, self.sh.plan.canvas_h, self._ops(ops, n), self.descs,
-                                 [np.zeros((d["height"], d["width"], 4), np.uint8) if s is None else s.numpy() for d, s in zip(self.descs, srcs)],
-                                 self.sh.opts["filter"])
+    def _full(self, srcs):
+        """whole bitmaps for the oracle: rows a rank does not hold are poisoned, so a band that sampled outside its
+        holding would not match"""
+        from imagestitching_amd.dist import SourceRows
+        out = []
+        for d, s in zip(self.descs, srcs):
+            a = np.full((d["height"], d["width"], 4), 0xEE, np.uint8)
+            if isinstance(s, SourceRows):
+                a[s.first_row:s.first_row + s.tensor.shape[0]] = s.tensor.numpy()
+            elif s is not None:
+                a[:] = s.numpy()
+            out.append(a)
+        return out
+
+    def render_band(self, part, srcs):
+        ops, n, clip = self.sh.band_ops(part)
+        full = self.O.render_ops(self.sh.plan.canvas_w, self.sh.plan.canvas_h, self._ops(ops, n), self.descs, self._full(srcs), self.sh.opts["filter"])
         x, y, w, h = clip
-        self.bands[i] = torch.from_numpy(np.ascontiguousarray(full[y:y + h, x:x + w]))
-        return self.bands[i]
+        self.bands[part.index] = torch.from_numpy(np.ascontiguousarray(full[y:y + h, x:x + w]))
+        return self.bands[part.index]
 
     def render_root(self, srcs, canvas):
-        ops, n, descs, n_img, staged = self.sh.root_ops()
+        ops, n = self.sh.root_ops()
         lst = self._ops(ops, n)
-        d2 = list(self.descs) + [{"width": self.staging[i].shape[1], "height": self.staging[i].shape[0], "orientation": 1} for i in staged]
-        px = [np.zeros((d["height"], d["width"], 4), np.uint8) if s is None else s.numpy() for d, s in zip(self.descs, srcs)]
-        px += [self.staging[i].numpy() for i in staged]
-        img = self.O.render_ops(self.sh.plan.canvas_w, self.sh.plan.canvas_h, [o for o in lst if o["kind"] != "hole"], d2, px, self.sh.opts["filter"])
+        img = self.O.render_ops(self.sh.plan.canvas_w, self.sh.plan.canvas_h, [o for o in lst if o["kind"] != "hole"], self.descs, self._full(srcs), self.sh.opts["filter"])
         keep = np.ones(img.shape[:2], bool)
         for o in lst:
             if o["kind"] == "hole":
@@ -59,17 +68,28 @@ class OracleBackend:
         c = canvas.numpy()
         c[keep] = img[keep]
 
+    def place(self, part, canvas):
+        canvas[part.Y0:part.Y1, part.X0:part.X1] = self.staging[part.index]
 
-def _worker(rank, world, port, direction, opts, out_path):
+
+def _holdings(sh, pixels, slot):
+    """what a rank holds: only the source rows its parts sample (None for images it renders nothing of)"""
+    from imagestitching_amd.dist import SourceRows
+    need = sh.rows_needed(slot)
+    return [SourceRows(torch.from_numpy(np.ascontiguousarray(a[need[i][0]:need[i][1]])), need[i][0]) if i in need else None
+            for i, a in enumerate(pixels)]
+
+
+def _worker(rank, world, port, direction, opts, split, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from imagestitching_amd import dist as D
         pixels = [U.rand_image(200 + i, h, w) for i, (w, h) in enumerate(SIZES)]
         imgs = U.hip_images(pixels)
-        sh = D.ShardedStitch(imgs, direction, opts, rank, world, 0)
+        sh = D.ShardedStitch(imgs, direction, opts, rank, world, 0, split=split)
         be = OracleBackend(sh, pixels)
-        srcs = [torch.from_numpy(a) if D.owner_of(i, world) == rank else None for i, a in enumerate(pixels)]
+        srcs = _holdings(sh, pixels, sh.slot)
         canvas = be.new_canvas() if rank == 0 else None
         for _ in range(2):      # two steps: buffers are reusable
             D.run_step(sh, be, srcs, canvas, dist)
@@ -88,19 +108,24 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("split", ["image", "band"])
 @pytest.mark.parametrize("direction,opts,expect_in_place", [
     ("vertical", {"filter": "bilinear", "mode": "min", "gap": 4}, True),       # full-width rows: received in place
-    ("horizontal", {"filter": "bilinear", "mode": "max", "gap": 0}, False),    # column bands: staged + fused blit
+    ("horizontal", {"filter": "bilinear", "mode": "max", "gap": 0}, False),    # column bands: staged, placed one by one
     ("vertical", {"filter": "nearest", "mode": "original", "gap": 3}, False),  # centred rects: staged
 ])
-def test_sharded_stitch_world2_matches_single_process(direction, opts, expect_in_place, tmp_path):
+def test_sharded_stitch_world2_matches_single_process(direction, opts, expect_in_place, split, tmp_path):
     from imagestitching_amd import dist as D
     pixels = [U.rand_image(200 + i, h, w) for i, (w, h) in enumerate(SIZES)]
-    sh = D.ShardedStitch(U.hip_images(pixels), direction, opts, 0, 2, 0)
-    assert sh.mine == [0, 2, 4] and sh.remote == [1, 3]
-    assert all(sh.in_place[i] == expect_in_place for i in sh.remote)
+    sh = D.ShardedStitch(U.hip_images(pixels), direction, opts, 0, 2, 0, split=split)
+    if split == "image":
+        assert [p.image for p in sh.mine] == [0, 2, 4] and [p.image for p in sh.remote] == [1, 3]
+    if direction == "vertical" and opts["mode"] == "min":
+        assert all(p.in_place == expect_in_place for p in sh.remote)
+    elif direction == "horizontal":
+        assert not any(p.in_place for p in sh.remote)
     out = str(tmp_path / "canvas.npy")
-    mp.spawn(_worker, args=(2, _free_port(), direction, opts, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), direction, opts, split, out), nprocs=2, join=True)
     got = np.load(out)
     ref, _, _ = U.oracle_stitch(pixels, direction, opts)
     assert np.array_equal(got, ref)
@@ -110,16 +135,60 @@ def test_round_robin_ownership_and_hole_ops():
     from imagestitching_amd import dist as D
     imgs = [{"width": 4032, "height": 3024}] * 9
     sh = D.ShardedStitch(imgs, "vertical", None, 0, 8, 0)
-    assert sh.mine == [0, 8]                                   # GPU0 holds images 0 and 8
+    assert [p.image for p in sh.mine] == [0, 8]               # GPU0 holds images 0 and 8
     assert [D.owner_of(i, 8) for i in range(9)] == [0, 1, 2, 3, 4, 5, 6, 7, 0]
-    ops, n, descs, n_img, staged = sh.root_ops()
+    assert [p.slot for p in sh.parts] == [0, 1, 2, 3, 4, 5, 6, 7, 0]
+    ops, n = sh.root_ops()
     kinds = [ops[k].kind for k in range(n)]
-    assert kinds == [0, 1] + [2] * 7 + [1] and staged == []   # fill, own draw, 7 holes, own draw
-    assert all(sh.in_place[i] for i in sh.remote)
-    hole = ops[2]
+    assert kinds == [0, 1, 1] + [2] * 7                        # fill, the root's two draws, 7 holes (last)
+    assert all(p.in_place for p in sh.remote)
+    hole = ops[3]
     assert list(hole.d) == [0.0, 3024.0, 4032.0, 3024.0]
     sh5 = D.ShardedStitch([{"width": 8000, "height": 6000}] * 64, "vertical", None, 3, 8, 0)
-    assert sh5.mine == list(range(3, 64, 8))                  # BASELINE configs[4]: 8 images per GPU
+    assert [p.image for p in sh5.mine] == list(range(3, 64, 8))   # BASELINE configs[4]: 8 images per GPU
+
+
+def test_band_split_balances_nine_images_over_eight_ranks():
+    """by image, 9 images over 8 GPUs leave a 2-image straggler (ceiling 4.5x); by band every rank
+    renders one eighth of the canvas (within one 8-row cut), from the source rows those canvas rows sample"""
+    from imagestitching_amd import dist as D
+    imgs = [{"width": 4032, "height": 3024}] * 9
+    for direction in ("vertical", "horizontal"):
+        sh = D.ShardedStitch(imgs, direction, None, 0, 8, 0, split="band")
+        px = [0] * 8
+        for p in sh.parts:
+            px[p.slot] += (p.X1 - p.X0) * (p.Y1 - p.Y0)
+            assert (p.Y0 - 0) % 8 == 0 or p.Y0 % 3024 == 0
+        total = 9 * 4032 * 3024
+        assert sum(px) == total and max(px) - min(px) <= 8 * 4032 and max(px) <= total / 8 + 8 * 4032
+        # every canvas pixel of every draw belongs to exactly one part
+        cover = {}
+        for p in sh.parts:
+            cover.setdefault(p.image, []).append((p.Y0, p.Y1) if direction == "vertical" else (p.Y0, p.Y1))
+        for i, spans in cover.items():
+            spans.sort()
+            assert spans[0][0] == (3024 * i if direction == "vertical" else 0)
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert spans[-1][1] == (3024 * (i + 1) if direction == "vertical" else 3024)
+        # a rank holds 1.125 images' worth of rows (plus the bilinear tap row at a cut), not two images
+        for slot in range(8):
+            rows = sum(b - a for a, b in sh.rows_needed(slot).values())
+            assert rows <= 3024 * 9 // 8 + 8 + 2
+        # vertical: every part is a contiguous byte range of the canvas; horizontal: none is
+        assert all(p.in_place == (direction == "vertical") for p in sh.parts)
+
+
+def test_band_split_of_scaled_draws_names_the_rows_it_samples():
+    from imagestitching_amd import dist as D
+    imgs = [{"width": 400, "height": 300}, {"width": 300, "height": 400}, {"width": 200, "height": 100}]
+    sh = D.ShardedStitch(imgs, "vertical", {"mode": "max", "filter": "bilinear"}, 0, 4, 0, split="band")
+    for p in sh.parts:
+        r = sh.plan.rects[p.image]
+        k = imgs[p.image]["height"] / r["dh"]
+        lo = k * (p.Y0 - r["dy"] + 0.5) - 0.5
+        hi = k * (p.Y1 - 1 - r["dy"] + 0.5) - 0.5
+        assert p.sy0 <= max(0, int(np.floor(lo))) and p.sy1 >= min(imgs[p.image]["height"], int(np.floor(hi)) + 2)
+        assert 0 <= p.sy0 < p.sy1 <= imgs[p.image]["height"]
 
 
 def test_overlapping_draws_are_refused():
@@ -131,17 +200,38 @@ def test_overlapping_draws_are_refused():
     with pytest.raises(ist.StitchError):
         D.ShardedStitch(imgs, "vertical", None, 0, 2, 0)
     ok = D.ShardedStitch([{"width": 40, "height": 30, "orientation": 7}] * 2, "vertical", None, 0, 2, 0)
-    assert sorted(ok.boxes) == [1]                            # image 0 is drawn entirely off-canvas
+    assert [p.image for p in ok.parts] == [1]                 # image 0 is drawn entirely off-canvas
 
 
-@pytest.mark.parametrize("world", [3, 4, 8])
-def test_sharded_stitch_more_ranks_than_two(world, tmp_path):
-    """several senders, uneven ownership (5 images over 3, 4 or 8 ranks; with 4 ranks rank 0 owns two, with 8 ranks three
-    ranks own nothing and only join the barrier):
-    the grouped send/recv batch must pair up per (sender, root) in image order"""
+def test_edge_antialiasing_is_refused_because_neighbours_share_a_pixel_row():
+    """with IST_FILTER_EDGE_AA two draws blend into the seam row, so no single GPU owns it"""
+    from imagestitching_amd import dist as D
+    import imagestitching_amd as ist
+    imgs = [{"width": 64, "height": 48}] * 3
+    with pytest.raises(ist.StitchError) as e:
+        D.ShardedStitch(imgs, "vertical", {"platform": "ios", "edgeAA": True}, 0, 2, 0)      # superSample 2.2: fractional seams
+    assert e.value.code == -7
+    D.ShardedStitch(imgs, "vertical", {"edgeAA": True}, 0, 2, 0)       # integer seams: nothing overlaps, AA or not
+
+
+@pytest.mark.parametrize("world,split", [(3, "image"), (4, "band"), (8, "image"), (8, "band")])
+def test_sharded_stitch_more_ranks_than_two(world, split, tmp_path):
+    """several senders, uneven ownership (5 images over 3, 4 or 8 ranks; by image with 8 ranks three ranks own nothing
+    and only join the barrier; by band every rank owns a slice and several ranks send two bands):
+    the grouped send/recv batch must pair up per (sender, root) in part order"""
     pixels = [U.rand_image(200 + i, h, w) for i, (w, h) in enumerate(SIZES)]
     opts = {"filter": "bilinear", "mode": "min", "gap": 2}
     out = str(tmp_path / "canvas.npy")
-    mp.spawn(_worker, args=(world, _free_port(), "vertical", opts, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), "vertical", opts, split, out), nprocs=world, join=True)
     ref, _, _ = U.oracle_stitch(pixels, "vertical", opts)
+    assert np.array_equal(np.load(out), ref)
+
+
+def test_horizontal_band_split_three_ranks(tmp_path):
+    """staged bands that are sub-boxes of a draw: placed by their own launches next to the root's own part of it"""
+    pixels = [U.rand_image(200 + i, h, w) for i, (w, h) in enumerate(SIZES)]
+    opts = {"filter": "bilinear", "mode": "min", "gap": 3}
+    out = str(tmp_path / "canvas.npy")
+    mp.spawn(_worker, args=(3, _free_port(), "horizontal", opts, "band", out), nprocs=3, join=True)
+    ref, _, _ = U.oracle_stitch(pixels, "horizontal", opts)
     assert np.array_equal(np.load(out), ref)

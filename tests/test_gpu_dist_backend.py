@@ -12,10 +12,12 @@ SIZES = [(640, 480), (480, 640), (600, 450), (300, 170), (640, 480)]
 
 
 class _LoopbackDist:
-    """Stands in for torch.distributed in ONE process: isend parks the tensor, irecv copies it."""
+    """Stands in for torch.distributed in ONE process: isend parks a copy of the tensor in the sender's mailbox, irecv
+    takes the oldest message from the named peer (the pairing rule of a grouped send/recv batch)."""
 
     def __init__(self):
-        self.mail = []
+        self.mail = {}
+        self.me = None                    # rank that is currently "running"
 
     class _Req:
         def wait(self):
@@ -33,49 +35,115 @@ class _LoopbackDist:
     def batch_isend_irecv(self, ops):
         for op, tensor, peer in ops:
             if op == self.isend:
-                self.mail.append(tensor.clone())
+                self.mail.setdefault(self.me, []).append(tensor.clone())
             else:
-                tensor.copy_(self.mail.pop(0))
+                tensor.copy_(self.mail[peer].pop(0))
         return [self._Req() for _ in ops]
 
+    def empty(self):
+        return not any(self.mail.values())
 
+
+def _run_world(pixels, direction, opts, world, split, check_bands_against=None, tol=0):
+    """every rank of a `world`-rank job on ONE GPU, non-root ranks first (their sends are parked), then the root"""
+    import torch
+    from imagestitching_amd import dist as D
+    imgs = U.hip_images(pixels) if isinstance(pixels[0], np.ndarray) else [{"width": int(t.shape[1]), "height": int(t.shape[0]), "opaque": True} for t in pixels]
+    dev = [torch.from_numpy(a).cuda() if isinstance(a, np.ndarray) else a for a in pixels]
+    loop = _LoopbackDist()
+    launches = 0
+    for rank in list(range(1, world)) + [0]:
+        loop.me = rank
+        sh = D.ShardedStitch(imgs, direction, opts, rank, world, 0, split=split)
+        be = D.HipBackend(sh, 0)
+        need = sh.rows_needed()
+        srcs = []
+        for i, t in enumerate(dev):
+            if i not in need:
+                srcs.append(None)
+                continue
+            a, b = need[i]
+            part = D.alloc_rows(torch, b - a, t.shape[1], t.device)      # the rank holds ONLY these rows (+ the spare row)
+            part.copy_(t[a:b])
+            srcs.append(D.SourceRows(part, a))
+        if rank != 0:
+            assert D.run_step(sh, be, srcs, None, loop) is None
+            launches += len(sh.mine)
+            if check_bands_against is not None:
+                for p in sh.mine:
+                    band = be.bands[p.index].cpu().numpy()
+                    assert band.shape == p.shape
+                    assert U.max_abs_diff(band, check_bands_against[p.Y0:p.Y1, p.X0:p.X1]) <= tol
+            continue
+        canvas = be.new_canvas()
+        canvas.fill_(0x5A)                 # poison: every pixel must be written by exactly the launches of this step
+        out = D.run_step(sh, be, srcs, canvas, loop)
+        torch.cuda.synchronize()
+        assert loop.empty()
+        return sh, be, out
+
+
+@pytest.mark.parametrize("split", ["image", "band"])
 @pytest.mark.parametrize("direction,opts", [
     ("vertical", {"filter": "bilinear", "mode": "min", "gap": 4}),
     ("horizontal", {"filter": "bilinear", "mode": "max", "gap": 0}),
     ("vertical", {"filter": "nearest", "mode": "original", "gap": 3}),
     ("vertical", {"filter": "bilinear", "mode": "min", "gap": 0}),
 ])
-def test_two_rank_layout_on_one_gpu_matches_oracle(direction, opts):
-    import torch
-    from imagestitching_amd import dist as D
+def test_two_rank_layout_on_one_gpu_matches_oracle(direction, opts, split):
     pixels = [U.rand_image(300 + i, h, w) for i, (w, h) in enumerate(SIZES)]
-    imgs = U.hip_images(pixels)
-    world = 2
-    loop = _LoopbackDist()
-    # rank 1 first (its sends are parked), then the root
-    sh1 = D.ShardedStitch(imgs, direction, opts, 1, world, 0)
-    be1 = D.HipBackend(sh1, 0)
-    srcs1 = [torch.from_numpy(a).cuda() if D.owner_of(i, world) == 1 else None for i, a in enumerate(pixels)]
-    assert D.run_step(sh1, be1, srcs1, None, loop) is None
-    # each band must equal the oracle's canvas cropped to the box
     ref, pd, _ = U.oracle_stitch(pixels, direction, opts)
     tol = 0 if opts["filter"] == "nearest" else 1
-    for i in sh1.mine:
-        X0, Y0, X1, Y1, _ = sh1.boxes[i]
-        band = be1.bands[i].cpu().numpy()
-        assert band.shape == (Y1 - Y0, X1 - X0, 4)
-        assert U.max_abs_diff(band, ref[Y0:Y1, X0:X1]) <= tol
-    sh0 = D.ShardedStitch(imgs, direction, opts, 0, world, 0)
-    be0 = D.HipBackend(sh0, 0)
-    srcs0 = [torch.from_numpy(a).cuda() if D.owner_of(i, world) == 0 else None for i, a in enumerate(pixels)]
-    canvas = be0.new_canvas()
-    canvas.fill_(0x5A)
-    out = D.run_step(sh0, be0, srcs0, canvas, loop)
-    torch.cuda.synchronize()
+    sh, be, out = _run_world(pixels, direction, opts, 2, split, check_bands_against=ref, tol=tol)
     got = out.cpu().numpy()
     assert got.shape == ref.shape
     assert U.max_abs_diff(got, ref) <= tol
-    assert not loop.mail
+
+
+@pytest.mark.parametrize("world,split,direction", [(3, "band", "horizontal"), (5, "band", "vertical"), (4, "image", "horizontal")])
+def test_more_ranks_and_band_cuts_through_scaled_draws(world, split, direction):
+    """band cuts through resampled draws: a rank renders rows [Y0, Y1) of a draw from the source rows ist_shard_parts
+    names, and nothing else of that image is on the rank"""
+    pixels = [U.rand_image(340 + i, h, w) for i, (w, h) in enumerate([(403, 302), (302, 403), (400, 300), (192, 108), (640, 480)])]
+    opts = {"filter": "bilinear", "mode": "max", "gap": 2}
+    ref, _, _ = U.oracle_stitch(pixels, direction, opts)
+    sh, be, out = _run_world(pixels, direction, opts, world, split, check_bands_against=ref, tol=1)
+    assert U.max_abs_diff(out.cpu().numpy(), ref) <= 1
+
+
+@pytest.mark.parametrize("split", ["image", "band"])
+def test_baseline_config3_full_size_eight_ranks_on_one_gpu(split):
+    """BASELINE configs[3] at its own size: 9 x 4032x3024 vertical, 8 ranks (image i -> rank i mod 8, or equal bands), all
+    eight ranks' band launches + the in-place receives + the root's HOLE launch in one process.  Size-independent
+    property: with equal widths the strip is exactly the concatenation of the inputs."""
+    import torch
+    srcs = [torch.empty((3024, 4032, 4), dtype=torch.uint8, device="cuda").random_(0, 256) for _ in range(9)]
+    for t in srcs:
+        t[..., 3] = 255
+    sh, be, out = _run_world(srcs, "vertical", {"filter": "bilinear"}, 8, split)
+    assert (sh.plan.canvas_w, sh.plan.canvas_h) == (4032, 27216)
+    n_remote = len(sh.remote)
+    assert n_remote == (7 if split == "image" else len(sh.parts) - len(sh.mine)) and all(p.in_place for p in sh.remote)
+    assert not be.place_jobs                                  # vertical: every band lands in place, nothing is staged
+    assert torch.equal(out, torch.cat(srcs, 0))
+    if split == "band":
+        px = [0] * 8
+        for p in sh.parts:
+            px[p.slot] += (p.X1 - p.X0) * (p.Y1 - p.Y0)
+        assert max(px) - min(px) <= 8 * 4032                  # balanced: no 2-image straggler
+
+
+def test_baseline_config3_geometry_horizontal_staged_bands_full_size():
+    """the same nine photos as a horizontal strip over 8 ranks: every remote band is a column of the canvas, staged
+    and placed by its own launch"""
+    import torch
+    srcs = [torch.empty((3024, 4032, 4), dtype=torch.uint8, device="cuda").random_(0, 256) for _ in range(9)]
+    for t in srcs:
+        t[..., 3] = 255
+    sh, be, out = _run_world(srcs, "horizontal", {"filter": "bilinear"}, 8, "band")
+    assert (sh.plan.canvas_w, sh.plan.canvas_h) == (36288, 3024)
+    assert len(be.place_jobs) == len(sh.remote) and not any(p.in_place for p in sh.remote)
+    assert torch.equal(out, torch.cat(srcs, 1))
 
 
 def test_opaque_hint_does_not_change_opaque_results():

@@ -1,6 +1,7 @@
 """HIP path vs CPU oracle, through the C-ABI.  Bit-exact for nearest; within +-1 LSB per channel for bilinear
 (BASELINE.json north_star).  Needs a real MI355X: run with -m gpu."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -93,13 +94,28 @@ def test_heavy_downscale_uses_the_direct_gather_path(filt):
     _check(px, "vertical", {"filter": filt, "platform": "android", "maxSide": 256, "maxPixels": 256 * 256})
 
 
-def test_direct_gather_path_matches_when_lds_staging_is_disabled(monkeypatch):
-    monkeypatch.setenv("IST_NO_LDS", "1")
-    sizes = [(403, 302), (302, 403), (400, 300), (192, 108)]
-    px = [U.rand_image(130 + i, h, w, opaque=(i != 2)) for i, (w, h) in enumerate(sizes)]
-    for direction in ("vertical", "horizontal"):
-        _check(px, direction, {"filter": "bilinear", "mode": "max", "gap": 2})
-    _check(px, "vertical", {"filter": "bilinear"}, orientations=[2, 3, 4, 1])
+def test_direct_gather_path_matches_when_lds_staging_is_disabled():
+    """Compile knobs are only read by a process STARTED in tuning mode (IST_TUNING=1; production compiles touch no
+    environment), so the knob run is a child process; it checks itself against the oracle."""
+    import subprocess
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r)
+from tests import test_gpu_parity as T, util as U
+sizes = [(403, 302), (302, 403), (400, 300), (192, 108)]
+px = [U.rand_image(130 + i, h, w, opaque=(i != 2)) for i, (w, h) in enumerate(sizes)]
+for direction in ("vertical", "horizontal"):
+    T._check(px, direction, {"filter": "bilinear", "mode": "max", "gap": 2})
+T._check(px, "vertical", {"filter": "bilinear"}, orientations=[2, 3, 4, 1])
+import imagestitching_amd as ist
+p, job = ist.Stitcher(0).compile(U.hip_images(px), "vertical", {"filter": "bilinear", "mode": "max"})
+assert job.info["tiles_sample"] > 0
+print("direct path ok")
+""" % (U.ROOT,)
+    env = dict(os.environ, IST_TUNING="1", IST_NO_LDS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "direct path ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_lds_staged_path_edges():
@@ -265,6 +281,37 @@ def test_config5_shape_64_images_single_gpu():
     want = (src[..., :3] * a + 255 * (255 - a) + 127) // 255
     assert torch.equal(out[..., :3].to(torch.int32), want)
     assert int(out[..., 3].min()) == 255
+
+
+def test_baseline_config4_full_size_64_x_8000x6000_on_one_gpu():
+    """BASELINE configs[4] at its own size on ONE GPU: 64 x 8000x6000 RGBA8 vertical -> 8000x384000 (3072 MP; 12.288 GB in
+    + 12.288 GB out, both resident in HBM), one launch.  Size-independent property: with equal widths the strip is the
+    concatenation of the inputs (bilinear at 1:1 is the identity); checked on the device, image by image."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 30 * (1 << 30):
+        pytest.skip("needs ~25 GB of free HBM")
+    st = ist.Stitcher(0)
+    p, job = st.compile([{"width": 8000, "height": 6000, "opaque": True}] * 64, "vertical", {"filter": "bilinear"})
+    assert (p.canvas_w, p.canvas_h) == (8000, 384000)
+    info = job.info
+    assert info["n_cells"] == 64 and info["tiles_sample"] == 0 and info["tiles_general"] == 0 and info["tiles_fill"] == 0
+    assert info["n_tiles"] == info["tiles_copy"] == 64 * ((8000 + 255) // 256) * (6000 // 8)      # 256 x 8 tiles per image
+    assert info["algorithmic_bytes"] == 8 * 8000 * 384000
+    srcs = []
+    for k in range(64):
+        t = torch.empty((6000, 8000, 4), dtype=torch.uint8, device="cuda")
+        t.view(torch.int32).random_(-2 ** 31, 2 ** 31 - 1)          # 4 random bytes per pixel in one pass
+        t[..., 3] = 255
+        srcs.append(t)
+    out = torch.empty((p.canvas_h, p.canvas_w, 4), dtype=torch.uint8, device="cuda")
+    out[::1000].fill_(0x5A)                                         # poison a sample of rows
+    job.launch(srcs, out)
+    torch.cuda.synchronize()
+    for k in range(64):
+        assert torch.equal(out[6000 * k:6000 * (k + 1)], srcs[k]), "image %d" % k
+    del srcs, out
+    torch.cuda.empty_cache()
 
 
 def test_one_call_c_entry_point_equals_two_step_path():

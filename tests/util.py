@@ -1,7 +1,11 @@
 """Shared helpers for the parity tests (test infrastructure; may use the oracle)."""
+import os
+
 import numpy as np
 
 from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rand_image(seed, h, w, opaque=True):
