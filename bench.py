@@ -8,11 +8,16 @@ CPU oracle timed beside it.
 N = 1  : BASELINE.json configs[1] — 9 x 4032x3024 RGBA vertical stitch, bilinear, inputs resident in HBM, one fused
          launch per step (a "step" = one whole stitch).  Three buffer sets are rotated.
 N > 1  : BASELINE.json configs[3] — the same stitch with image i on GPU i mod N, bands gathered to GPU 0 over RCCL
-         (strong scaling: total work fixed).  See DESIGN.md section 6 for why this cannot beat one GPU when the
-         inputs are already resident in HBM.
-Prints ONE JSON line on rank 0.
+         (strong scaling: total work fixed).
+`value` is always the region BASELINE's contract names: inputs already resident in HBM.  DESIGN.md section 6 explains why
+that region cannot beat one GPU (a 0.14 ms job against a >= 0.3 ms gather over one xGMI link per sender) and on which
+region the >= 6x target is claimed instead; every run therefore also reports, in extra.regions, the SAME stitch timed
+  from_pinned_host  each GPU first uploads the source rows it renders from pinned host memory (its own PCIe link)
+  from_jpeg         each GPU first decodes its images from JPEG bytes (GPU Huffman + IDCT + colour)
+so that the driver's N = 1, 2, 4, 8 lines contain the scaling of all three.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,15 +31,43 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 UNIFORM = [(4032, 3024)] * 9
 MIXED = [(4032, 3024), (3024, 4032), (4000, 3000), (3840, 2160), (4032, 3024), (3024, 4032), (4000, 3000), (3840, 2160), (4032, 3024)]
+KERNEL_SOURCES = ["imagestitching_amd/csrc/ist_kernels.hip", "imagestitching_amd/csrc/ist_compile.cpp", "imagestitching_amd/csrc/ist_internal.h",
+                  "imagestitching_amd/csrc/ist_launch.h"]
+
+
+def kernel_source_sha():
+    """identifies the kernel + tiling a PMC measurement belongs to (profiles/*_pmc.json carry it)"""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def synth_np(k, w, h):
+    """BASELINE.md section 3: image k = default_rng(1000+k) uniform bytes, alpha forced to 255."""
+    import numpy as np
+    a = np.random.default_rng(1000 + k).integers(0, 256, (h, w, 4), dtype=np.uint8)
+    a[..., 3] = 255
+    return a
 
 
 def synth(k, w, h, device):
-    """BASELINE.md section 3: image k = default_rng(1000+k) uniform bytes, alpha forced to 255."""
-    import numpy as np
     import torch
-    a = np.random.default_rng(1000 + k).integers(0, 256, (h, w, 4), dtype=np.uint8)
-    a[..., 3] = 255
-    return torch.from_numpy(a).to(device)
+    return torch.from_numpy(synth_np(k, w, h)).to(device)
+
+
+def photo_jpeg(k, w, h):
+    """a photo-like 12 MP JPEG (smooth structure + sensor-like noise, quality 90, 4:2:0): what a phone hands the page"""
+    import io
+    import numpy as np
+    from PIL import Image
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.stack([128 + 90 * np.sin(xx / (37.0 + k) + yy / 91.0), 128 + 80 * np.cos(xx / 53.0 - yy / (29.0 + k)), 100 + 0.03 * xx + 0.02 * yy], -1)
+    a = (a + np.random.default_rng(k).normal(0, 3.0, a.shape)).clip(0, 255).astype(np.uint8)
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, "JPEG", quality=90, subsampling=2)
+    return b.getvalue()
 
 
 def time_job(job, sets, outs, steps, warmup, torch):
@@ -54,15 +87,23 @@ def time_job(job, sets, outs, steps, warmup, torch):
     return t1 - t0, ev0.elapsed_time(ev1)
 
 
-def cpu_baseline(budget_s=12.0):
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(budget_s=10.0):
     """The CPU oracle (a port: the reference's raster is the closed WeChat client) on the same workload, all host
-    cores by output row bands, bounded to ~budget_s of CPU work."""
+    cores by output row bands, bounded to ~budget_s of CPU work.  Rebuilt on this box with -march=native (BASELINE.md
+    section 3); falls back to the portable build that travelled with the repo."""
+    import subprocess
     import numpy as np
+    build = "-O3 -march=x86-64-v3 (portable build)"
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        os.environ["IST_ORACLE_LIB"] = os.path.join(ROOT, "oracle", "libist_oracle_native.so")
+        build = "-O3 -march=native, built on this box"
+    except Exception:
+        pass
     from oracle import oracle as O
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    px = [np.random.default_rng(1000 + k).integers(0, 256, (3024, 4032, 4), dtype=np.uint8) for k in range(9)]
-    for a in px:
-        a[..., 3] = 255
+    px = [synth_np(k, 4032, 3024) for k in range(9)]
     descs = [{"width": 4032, "height": 3024} for _ in px]
     rc, pd, rl = O.plan(descs, "vertical", "min", 0, O.lifted_limits(1.0))
     out = np.empty((int(pd["canvas_h"]), int(pd["canvas_w"]), 4), np.uint8)
@@ -75,16 +116,74 @@ def cpu_baseline(budget_s=12.0):
             break
     dt = (time.perf_counter() - t0) / reps
     mp = pd["canvas_w"] * pd["canvas_h"] / 1e6
-    # single-thread figure on one repetition, for the record
     t1 = time.perf_counter()
-    O.render(pd, rl, descs, px, "bilinear", 1, out=out)
+    O.render(pd, rl, descs, px, "bilinear", 1, out=out)                # single-thread figure on one repetition, for the record
     st = time.perf_counter() - t1
-    return {"value": round(mp / dt, 1), "unit": "MP/s", "cores": threads, "kind": "port",
-            "sample": "%d x the full 9x4032x3024 vertical bilinear stitch (109.7 MP each), oracle/ist_oracle.c, %d threads by row bands" % (reps, threads),
-            "single_thread_MPs": round(mp / st, 1)}
+    res = {"value": round(mp / dt, 1), "unit": "MP/s", "cores": threads, "kind": "port", "build": build,
+           "sample": "%d x the full 9x4032x3024 vertical bilinear stitch (109.7 MP each), oracle/ist_oracle.c, %d threads by row bands" % (reps, threads),
+           "single_thread_MPs": round(mp / st, 1)}
+    res["cairo"] = cairo_leg(px)
+    return res
 
 
+def cairo_leg(px, budget_s=4.0):
+    """Optional: the same nine 1:1 draws on a cairo image surface — a real Canvas-2D backend — on
+    one host thread, if libcairo.so.2 can be dlopen'ed on this box.  Never required; None when absent."""
+    import ctypes as C
+    import numpy as np
+    try:
+        cairo = C.CDLL("libcairo.so.2")
+    except OSError:
+        return None
+    try:
+        for name, res, args in (("cairo_image_surface_create", C.c_void_p, [C.c_int, C.c_int, C.c_int]),
+                                ("cairo_image_surface_create_for_data", C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+                                ("cairo_create", C.c_void_p, [C.c_void_p]), ("cairo_set_source_surface", None, [C.c_void_p, C.c_void_p, C.c_double, C.c_double]),
+                                ("cairo_get_source", C.c_void_p, [C.c_void_p]), ("cairo_pattern_set_filter", None, [C.c_void_p, C.c_int]),
+                                ("cairo_rectangle", None, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]), ("cairo_fill", None, [C.c_void_p]),
+                                ("cairo_set_source_rgb", None, [C.c_void_p, C.c_double, C.c_double, C.c_double]), ("cairo_paint", None, [C.c_void_p]),
+                                ("cairo_surface_flush", None, [C.c_void_p]), ("cairo_destroy", None, [C.c_void_p]), ("cairo_surface_destroy", None, [C.c_void_p]),
+                                ("cairo_surface_status", C.c_int, [C.c_void_p])):
+            f = getattr(cairo, name)
+            f.restype, f.argtypes = res, args
+        w, h, n = 4032, 3024, len(px)
+        FORMAT_ARGB32, FILTER_BILINEAR = 0, 4
+        # cairo's ARGB32 is premultiplied BGRA in memory; the inputs are opaque, so a channel swap is the whole conversion
+        srcs = [np.ascontiguousarray(a[..., [2, 1, 0, 3]]) for a in px]
+        ssurf = [cairo.cairo_image_surface_create_for_data(a.ctypes.data, FORMAT_ARGB32, w, h, w * 4) for a in srcs]
+        dst = cairo.cairo_image_surface_create(FORMAT_ARGB32, w, h * n)
+        if cairo.cairo_surface_status(dst) != 0:
+            return None
+
+        def once():
+            cr = cairo.cairo_create(dst)
+            cairo.cairo_set_source_rgb(cr, 1.0, 1.0, 1.0)
+            cairo.cairo_paint(cr)                                       # fillRect('#ffffff') over the canvas (index.js:1423-1424)
+            for k, s in enumerate(ssurf):
+                cairo.cairo_set_source_surface(cr, s, 0.0, float(h * k))
+                cairo.cairo_pattern_set_filter(cairo.cairo_get_source(cr), FILTER_BILINEAR)
+                cairo.cairo_rectangle(cr, 0.0, float(h * k), float(w), float(h))
+                cairo.cairo_fill(cr)                                    # drawImage(img, 0,0,w,h, 0,h*k,w,h)
+            cairo.cairo_surface_flush(dst)
+            cairo.cairo_destroy(cr)
+        once()
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and reps < 20:
+            once()
+            reps += 1
+        dt = (time.perf_counter() - t0) / max(reps, 1)
+        for s in ssurf:
+            cairo.cairo_surface_destroy(s)
+        cairo.cairo_surface_destroy(dst)
+        return {"MPs": round(w * h * n / 1e6 / dt, 1), "threads": 1, "reps": reps,
+                "what": "cairo image surface (libcairo.so.2, pixman): white paint + nine 1:1 FILTER_BILINEAR draws, one thread"}
+    except Exception as ex:       # informational only
+        return {"error": repr(ex)}
+
+
+# ---------------------------------------------------------------------------------------------------- N = 1
 def run_single(args):
+    import numpy as np
     import torch
     import imagestitching_amd as ist
     dev = torch.device("cuda", 0)
@@ -92,6 +191,7 @@ def run_single(args):
     st = ist.Stitcher(0)
     nsets = 3
     results = {}
+    head_job = None
     for name, sizes, direction in (("uniform_vertical", UNIFORM, "vertical"), ("uniform_horizontal", UNIFORM, "horizontal"),
                                    ("mixed_vertical", MIXED, "vertical"), ("mixed_horizontal", MIXED, "horizontal")):
         if args.quick and name != "uniform_vertical":
@@ -112,11 +212,62 @@ def run_single(args):
         del sets, outs, job
         torch.cuda.empty_cache()
     head = results["uniform_vertical"]
-    # yardstick: the runtime's own device-to-device copy (torch copy_ = hipMemcpyDtoD kernel) of the same number of
-    # bytes, on the same box in the same process: what a plain copy reaches next to the stitch kernel
-    yard = None
+    extra = {k: {"MPs": round(v["MPs"], 1), "kernel_us": round(v["kernel_us"], 2), "GBs": round(v["GBs"], 1),
+                 "frac": round(v["GBs"] / HBM_PEAK_GBS, 4), "canvas": v["canvas"], "tiles": v["tiles"]} for k, v in results.items()}
+    yard = cpu = None
+    if not args.kernels_only:
+        yard = d2d_yardstick(head["algorithmic_bytes"] // 2, dev, torch)
+        try:
+            extra["regions"] = single_gpu_regions(st, ist, dev, torch, head)
+        except Exception as ex:      # informational legs never take the headline down
+            extra["regions"] = {"error": repr(ex)}
+        try:
+            extra["end_to_end_host_path"] = host_path_leg(ist, np)
+        except Exception as ex:
+            extra["end_to_end_host_path"] = {"error": repr(ex)}
+        try:
+            extra["file_pipeline"] = file_pipeline_leg(ist)
+        except Exception as ex:
+            extra["file_pipeline"] = {"error": repr(ex)}
+        cpu = None if args.no_cpu else cpu_baseline()
+    # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE
+    # doubled per MI355X_MICROARCH.md), collected by profiles/summarize.py.  Only quoted when the measurement belongs to
+    # THIS kernel + tiling (the JSON carries a hash of the kernel sources); otherwise null.
+    traffic, traffic_src = None, "no PMC measurement of this kernel revision is committed (profiles/*_pmc.json)"
+    sha = kernel_source_sha()
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json")), reverse=True):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pm = json.load(f)
+            if pm.get("kernel_source_sha") != sha:
+                continue
+            row = pm["uniform_vertical (BASELINE configs[1])"]
+            traffic = int(row["FETCH_SIZE_bytes"] + row["WRITE_SIZE_bytes"])
+            traffic_src = "profiles/%s (rocprofv3 --pmc passes of this bench at kernel revision %s; bytes per launch)" % (name, sha)
+            break
+        except Exception:
+            continue
+    line = {
+        "metric": "stitched megapixels/sec (9x12 MP vertical)", "value": round(head["MPs"], 1), "unit": "MP/s",
+        "n_gpus": 1, "steps": head["steps"], "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: 9 x 4032x3024 RGBA8 vertical stitch, bilinear resample to common width, "
+                               "caps lifted -> 4032x27216 (109.73 MP); inputs and output resident in HBM, one fused launch per stitch",
+                   "buffer_sets_rotated": nsets, "timed_region": "kernel launches only (no H2D/D2H, no PNG)"},
+        "roofline": {"bound": "hbm", "achieved": round(head["GBs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(head["GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "ist_stitch_kernel", "kernel_us": round(head["kernel_us"], 2),
+                     "algorithmic_bytes_per_launch": head["algorithmic_bytes"], "kernel_source_sha": sha},
+        "cpu_baseline": cpu,
+        "d2d_copy_yardstick": yard,
+        "extra": extra,
+    }
+    print(json.dumps(line))
+
+
+def d2d_yardstick(nbytes, dev, torch):
+    """the runtime's own device-to-device copy (torch copy_) of the same number of bytes, same box, same process"""
     try:
-        nbytes = head["algorithmic_bytes"] // 2
         a = [torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 256) for _ in range(2)]
         b = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
         for i in range(5):
@@ -130,43 +281,104 @@ def run_single(args):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
-        yard = {"us": round(us, 2), "GBs": round(2 * nbytes / (us * 1e-6) / 1e9, 1), "frac": round(2 * nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+        return {"us": round(us, 2), "GBs": round(2 * nbytes / (us * 1e-6) / 1e9, 1), "frac": round(2 * nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 "what": "torch Tensor.copy_ device-to-device, %d bytes read + as many written" % nbytes}
-        del a, b
-        torch.cuda.empty_cache()
     except Exception as ex:       # informational only
-        yard = {"error": repr(ex)}
-    cpu = None if args.no_cpu else cpu_baseline()
-    # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE
-    # doubled per MI355X_MICROARCH.md): collected by profiles/summarize.py, committed as profiles/r01_pmc.json
-    traffic, traffic_src = None, None
+        return {"error": repr(ex)}
+
+
+def single_gpu_regions(st, ist, dev, torch, head, reps=8):
+    """the three timed regions of the N > 1 lines, on ONE GPU (the N = 1 point of their scaling curves)"""
+    imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in UNIFORM]
+    p, job = st.compile(imgs, "vertical", {"filter": "bilinear"})
+    mp = p.canvas_w * p.canvas_h / 1e6
+    out = torch.empty((p.canvas_h, p.canvas_w, 4), dtype=torch.uint8, device=dev)
+    host = [torch.from_numpy(synth_np(k, w, h)).pin_memory() for k, (w, h) in enumerate(UNIFORM)]
+    srcs = [torch.empty((h + 1, w, 4), dtype=torch.uint8, device=dev)[:h] for (w, h) in UNIFORM]
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def from_host():
+        for d, s in zip(srcs, host):
+            d.copy_(s, non_blocking=True)
+        job.launch(srcs, out)
+    t_host = timed(from_host)
+    blobs = [photo_jpeg(k, w, h) for k, (w, h) in enumerate(UNIFORM)]
+
+    def from_jpeg():
+        ist.decode_files_device(blobs, out=srcs)
+        job.launch(srcs, out)
+    t_jpeg = timed(from_jpeg)
+    return {"resident": {"ms_per_step": round(head["ms_per_step"], 4), "MPs": round(head["MPs"], 1), "what": "= value: inputs resident in HBM"},
+            "from_pinned_host": {"ms_per_step": round(t_host * 1e3, 3), "MPs": round(mp / t_host, 1), "h2d_bytes": int(sum(w * h * 4 for w, h in UNIFORM)),
+                                 "what": "9 x 48.8 MB from pinned host memory over this GPU's PCIe link, then the launch"},
+            "from_jpeg": {"ms_per_step": round(t_jpeg * 1e3, 3), "MPs": round(mp / t_jpeg, 1), "jpeg_bytes": int(sum(len(b) for b in blobs)),
+                          "what": "nine 12 MP photo-like JPEGs (q90, 4:2:0) decoded on the GPU (Huffman + IDCT + colour), then the launch"}}
+
+
+def host_path_leg(ist, np, reps=4):
+    """BASELINE.md section 4 / SURVEY 8d 'end to end, reported separately and labelled': numpy in -> plan -> staged H2D ->
+    launch -> D2H into a pooled pinned block, through ist_stitch_rgba8 (what the N-API addon binds)"""
+    px = [synth_np(k, 4032, 3024) for k in range(9)]
+    imgs = [{"width": 4032, "height": 3024, "data": a, "opaque": True} for a in px]
+    ist.stitch(imgs, "vertical", {"filter": "bilinear"})            # warm-up: scratch, staging ring, result pool
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = ist.stitch(imgs, "vertical", {"filter": "bilinear"})
+        ts.append(time.perf_counter() - t0)
+        del r
+    t = sorted(ts)[len(ts) // 2]
+    return {"ms_per_stitch": round(t * 1e3, 2), "MPs": round(109.734912 / t, 1), "pcie_payload_GBs": round(2 * 438.939648e6 / t / 1e9, 2),
+            "what": "PCIe-inclusive: pageable numpy in -> plan -> H2D through the pinned ring -> launch -> one D2H into a pooled pinned block (never `value`)"}
+
+
+def file_pipeline_leg(ist, reps=3):
+    """SURVEY 8f ranks 2-3 measured: nine 12 MP JPEGs -> one PNG through ist_stitch_files_png, per-stage milliseconds from
+    the C side (ist_ctx_last_timing: every phase ends with a stream sync while timing is on)"""
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    paths = []
+    for k, (w, h) in enumerate(UNIFORM):
+        p = os.path.join(tmp, "in%d.jpg" % k)
+        with open(p, "wb") as f:
+            f.write(photo_jpeg(k, w, h))
+        paths.append(p)
+    in_bytes = sum(os.path.getsize(p) for p in paths)
+    ist.stitch_files(paths, "vertical", copy=False)                 # warm-up
+    ist.set_phase_timing(True)
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
-            pm = json.load(f)["uniform_vertical (BASELINE configs[1])"]
-        traffic = int(pm["FETCH_SIZE_bytes"] + pm["WRITE_SIZE_bytes"])
-        traffic_src = "profiles/r01_pmc.json (rocprofv3 --pmc passes of this bench; bytes per launch)"
-    except Exception:
-        pass
-    line = {
-        "metric": "stitched megapixels/sec (9x12 MP vertical)", "value": round(head["MPs"], 1), "unit": "MP/s",
-        "n_gpus": 1, "steps": head["steps"], "warmup": args.warmup, "ms_per_step": round(head["ms_per_step"], 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: 9 x 4032x3024 RGBA8 vertical stitch, bilinear resample to common width, "
-                               "caps lifted -> 4032x27216 (109.73 MP); inputs and output resident in HBM, one fused launch per stitch",
-                   "buffer_sets_rotated": nsets, "timed_region": "kernel launches only (no H2D/D2H, no PNG)"},
-        "roofline": {"bound": "hbm", "achieved": round(head["GBs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(head["GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "ist_stitch_kernel", "kernel_us": round(head["kernel_us"], 2),
-                     "algorithmic_bytes_per_launch": head["algorithmic_bytes"]},
-        "cpu_baseline": cpu,
-        "d2d_copy_yardstick": yard,
-        "extra": {k: {"MPs": round(v["MPs"], 1), "kernel_us": round(v["kernel_us"], 2), "GBs": round(v["GBs"], 1),
-                      "frac": round(v["GBs"] / HBM_PEAK_GBS, 4), "canvas": v["canvas"], "tiles": v["tiles"]}
-                  for k, v in results.items()},
-    }
-    print(json.dumps(line))
+        best, phases, png_len = None, None, 0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = ist.stitch_files(paths, "vertical", copy=False)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, phases, png_len = dt, ist.last_phase_times(), len(res["png"])
+            del res
+    finally:
+        ist.set_phase_timing(False)
+    canvas = 4032 * 27216 * 4
+    rate = lambda b, ms: round(b / (ms * 1e-3) / 1e9, 2) if ms > 0 else None      # noqa: E731
+    return {"ms_end_to_end": round(best * 1e3, 2), "jpeg_bytes_in": in_bytes, "png_bytes_out": png_len,
+            "stages_ms": {k: round(v, 3) for k, v in phases.items()},
+            "stages_GBs": {"entropy_gpu (scan bytes in)": rate(in_bytes, phases["entropy_gpu"]),
+                           "reconstruct (RGBA bytes out)": rate(canvas, phases["reconstruct"]),
+                           "stitch (algorithmic bytes)": rate(2 * canvas, phases["stitch"]),
+                           "png (canvas bytes in)": rate(canvas, phases["png"]),
+                           "d2h (PNG bytes)": rate(png_len, phases["d2h"])},
+            "what": "nine photo-like 12 MP JPEGs -> 4032x27216 PNG (level 1); includes reading the files; stage times carry one stream sync each"}
 
 
+# ---------------------------------------------------------------------------------------------------- N > 1
 def run_sharded(args):
     import torch
     import torch.distributed as dist
@@ -180,83 +392,96 @@ def run_sharded(args):
     dev = torch.device("cuda", local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in UNIFORM]
-    sh = D.ShardedStitch(imgs, "vertical", {"filter": "bilinear"}, rank, world, 0)
-    be = D.HipBackend(sh, local)
-    srcs = [synth(k, w, h, dev) if D.owner_of(k, world) == rank else None for k, (w, h) in enumerate(UNIFORM)]
-    canvas = be.new_canvas() if rank == 0 else None
-    for _ in range(args.warmup):
-        D.run_step(sh, be, srcs, canvas, dist)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        D.run_step(sh, be, srcs, canvas, dist)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    mp = 4032 * 27216 / 1e6
 
-    # phase breakdown (informational): slowest rank's local launches alone, no exchange
-    def local_only():
-        if rank == 0:
-            be.render_root(srcs, canvas)
-        else:
-            for i in sh.mine:
-                be.render_band(i, srcs)
-    for _ in range(3):
-        local_only()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        local_only()
-    torch.cuda.synchronize()
-    loc = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-    dist.all_reduce(loc, op=dist.ReduceOp.MAX)
+    def timed(step, steps, warmup):
+        """the contract's bracket: barrier + synchronize on both sides, MAX over ranks"""
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item()) / steps
+
+    regions, gather = {}, {}
+    value_sec = None
+    for split in ("image", "band"):
+        sh = D.ShardedStitch(imgs, "vertical", {"filter": "bilinear"}, rank, world, 0, split=split)
+        be = D.HipBackend(sh, local)
+        need = sh.rows_needed()
+        # this rank's holdings: only the source rows its parts sample (+ one spare row), in HBM and in pinned host memory
+        full = {i: synth_np(i, *UNIFORM[i]) for i in need}
+        dsrc, hsrc = [None] * len(UNIFORM), {}
+        for i, (a, b) in need.items():
+            t = D.alloc_rows(torch, b - a, UNIFORM[i][0], dev)
+            hsrc[i] = torch.from_numpy(full[i][a:b]).pin_memory()
+            t.copy_(hsrc[i])
+            dsrc[i] = D.SourceRows(t, a)
+        canvas = be.new_canvas() if rank == 0 else None
+
+        def resident():
+            D.run_step(sh, be, dsrc, canvas, dist)
+
+        def from_host():
+            for i in need:
+                dsrc[i].tensor.copy_(hsrc[i], non_blocking=True)
+            D.run_step(sh, be, dsrc, canvas, dist)
+        t_res = timed(resident, args.steps, args.warmup)
+        t_host = timed(from_host, max(5, args.steps // 10), 2)
+        if split == "image":
+            value_sec = t_res
+        regions["resident/" + split] = {"ms_per_step": round(t_res * 1e3, 4), "MPs": round(mp / t_res, 1)}
+        regions["from_pinned_host/" + split] = {"ms_per_step": round(t_host * 1e3, 4), "MPs": round(mp / t_host, 1),
+                                                "h2d_bytes_this_rank": int(sum(t.numel() for t in hsrc.values()))}
+        if split == "image":                       # JPEG inputs are whole files: by image only
+            blobs = [photo_jpeg(i, *UNIFORM[i]) for i in sorted(need)]
+            outs = [dsrc[i].tensor for i in sorted(need)]
+
+            def from_jpeg():
+                if blobs:
+                    ist.decode_files_device(blobs, device=local, out=outs)
+                D.run_step(sh, be, dsrc, canvas, dist)
+            t_jpeg = timed(from_jpeg, max(3, args.steps // 20), 1)
+            regions["from_jpeg/image"] = {"ms_per_step": round(t_jpeg * 1e3, 4), "MPs": round(mp / t_jpeg, 1)}
+        per_sender = {}
+        for p in sh.remote:
+            per_sender[sh.rank_of(p)] = per_sender.get(sh.rank_of(p), 0) + p.nbytes
+        gather[split] = {"bytes_into_gpu0_per_step": int(sum(per_sender.values())), "sending_gpus": len(per_sender),
+                         "busiest_link_bytes": int(max(per_sender.values()) if per_sender else 0),
+                         "bands_in_place": sum(1 for p in sh.remote if p.in_place), "bands_staged": sum(1 for p in sh.remote if not p.in_place),
+                         "output_pixels_per_rank_max_over_mean": round(max(sum((q.X1 - q.X0) * (q.Y1 - q.Y0) for q in sh.parts if q.slot == s) for s in range(world)) / (mp * 1e6 / world), 3)}
+        del be, sh, dsrc, hsrc, canvas
+        torch.cuda.empty_cache()
 
     # informational: N independent replicas (every GPU stitches a whole 9 x 12 MP job; no exchange) = the layout a
     # stitching service would use when jobs are independent
     st = ist.Stitcher(local)
     p_full, job_full = st.compile(imgs, "vertical", {"filter": "bilinear"})
-    full_src = [s_ if s_ is not None else synth(k, w, h, dev) for k, ((w, h), s_) in enumerate(zip(UNIFORM, srcs))]
+    full_src = [synth(k, w, h, dev) for k, (w, h) in enumerate(UNIFORM)]
     full_out = torch.empty((p_full.canvas_h, p_full.canvas_w, 4), dtype=torch.uint8, device=dev)
-    for _ in range(3):
-        job_full.launch(full_src, full_out)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    for _ in range(args.steps):
-        job_full.launch(full_src, full_out)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    rep = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
-    dist.all_reduce(rep, op=dist.ReduceOp.MAX)
+    t_rep = timed(lambda: job_full.launch(full_src, full_out), args.steps, 3)
     if rank == 0:
-        sec = float(dt.item()) / args.steps
-        mp = sh.plan.canvas_w * sh.plan.canvas_h / 1e6
-        in_place = sum(1 for i in sh.remote if sh.in_place[i])
-        # bytes the gather moves into GPU 0 per step, and what that is per xGMI link (one link per sending GPU)
-        gather_bytes = sum((sh.boxes[i][2] - sh.boxes[i][0]) * (sh.boxes[i][3] - sh.boxes[i][1]) * 4 for i in sh.remote)
-        senders = len({D.owner_of(i, world) for i in sh.remote})
-        busiest = max([sum((sh.boxes[i][2] - sh.boxes[i][0]) * (sh.boxes[i][3] - sh.boxes[i][1]) * 4 for i in sh.remote if D.owner_of(i, world) == r) for r in range(world) if r != 0] or [0])
         line = {
-            "metric": "stitched megapixels/sec (9x12 MP vertical)", "value": round(mp / sec, 1), "unit": "MP/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec * 1e3, 5),
+            "metric": "stitched megapixels/sec (9x12 MP vertical)", "value": round(mp / value_sec, 1), "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(value_sec * 1e3, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: 9 x 4032x3024 vertical stitch, image i on GPU i mod %d, bands gathered to "
-                                   "GPU 0 with one grouped RCCL send/recv batch (%d bands received in place)" % (world, in_place),
+                                   "GPU 0 with one grouped RCCL send/recv batch (%d bands received in place)" % (world, gather["image"]["bands_in_place"]),
                        "timed_region": "per-rank band launches + gather + root launch; inputs resident in each owner's HBM"},
             "roofline": None, "cpu_baseline": None,
-            "extra": {"gather": {"bytes_into_gpu0_per_step": gather_bytes, "sending_gpus": senders, "busiest_link_bytes": busiest,
-                                 "GBs_into_gpu0": round(gather_bytes / sec / 1e9, 1), "busiest_link_GBs": round(busiest / sec / 1e9, 1),
-                                 "note": "xGMI is point to point (one link per GPU pair, ~153 GB/s peak per direction pair): the step time is bounded below by busiest_link_bytes / link rate"},
-                      "local_launches_only_ms_per_step": round(float(loc.item()) / args.steps * 1e3, 5),
-                      "exchange_ms_per_step_by_difference": round((float(dt.item()) - float(loc.item())) / args.steps * 1e3, 5),
-                      "replicas_no_exchange": {"MPs": round(world * mp / (float(rep.item()) / args.steps), 1), "scaling": "weak",
-                                               "note": "every GPU stitches its own whole 9x12 MP job"}},
+            "extra": {"regions": regions, "gather": gather,
+                      "regions_note": "value = resident/image (the contract's region and BASELINE's split).  from_pinned_host and from_jpeg add each rank's own "
+                                      "ingest (its PCIe link / its decoder) in front of the same step; /band deals equal output rows to every rank instead of whole images.  "
+                                      "xGMI is point to point: a step is bounded below by busiest_link_bytes / one link's rate.",
+                      "replicas_no_exchange": {"MPs": round(world * mp / t_rep, 1), "scaling": "weak", "note": "every GPU stitches its own whole 9x12 MP job"}},
         }
         print(json.dumps(line))
     dist.destroy_process_group()
@@ -269,7 +494,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--quick", action="store_true", help="headline config only")
+    ap.add_argument("--kernels-only", action="store_true", help="only the resident-input kernel configurations (what the rocprofv3 passes run)")
+    ap.add_argument("--print-kernel-sha", action="store_true")
     args = ap.parse_args()
+    if args.print_kernel_sha:
+        print(kernel_source_sha())
+        return
     if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("IST_BENCH_FORCE_SHARDED"):
         run_sharded(args)
     else:

@@ -90,6 +90,22 @@ SYMBOLS = [
     ("ist_job_info_get", C.c_int, [C.c_void_p, C.POINTER(JobInfo)]),
     ("ist_job_launch", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("ist_job_destroy", None, [C.c_void_p]),
+    ("ist_group_create", C.c_void_p, [C.POINTER(C.c_int), C.c_int]),
+    ("ist_group_destroy", None, [C.c_void_p]),
+    ("ist_group_slots", C.c_int, [C.c_void_p]),
+    ("ist_group_device", C.c_int, [C.c_void_p, C.c_int]),
+    ("ist_group_job_create", C.c_void_p, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(Op), C.c_int,
+                                          C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int]),
+    ("ist_group_job_destroy", None, [C.c_void_p]),
+    ("ist_group_job_parts", C.c_int, [C.c_void_p, C.POINTER(Part), C.c_int, C.POINTER(C.c_int)]),
+    ("ist_group_job_launch", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_void_p, C.c_size_t]),
+    ("ist_group_sync", C.c_int, [C.c_void_p]),
+    ("ist_group_stitch_rgba8", C.c_int, [C.c_void_p, C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int,
+                                         C.c_int, C.c_int, C.c_double, C.POINTER(Limits), C.c_int, C.c_int, C.POINTER(Plan),
+                                         C.POINTER(C.POINTER(C.c_uint8))]),
+    ("ist_stitch_rgba8_multi", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int,
+                                         C.c_int, C.c_int, C.c_double, C.POINTER(Limits), C.c_int, C.c_int, C.POINTER(Plan),
+                                         C.POINTER(C.POINTER(C.c_uint8))]),
     ("ist_stitch_rgba8", C.c_int, [C.c_void_p, C.POINTER(ImageDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int,
                                    C.c_int, C.c_int, C.c_double, C.POINTER(Limits), C.c_int, C.POINTER(Plan),
                                    C.POINTER(C.POINTER(C.c_uint8))]),
@@ -104,6 +120,10 @@ SYMBOLS = [
     ("ist_jpeg_decode_rgba8", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_int64]),
     ("ist_image_info", C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("ist_image_decode_rgba8", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_int64]),
+    ("ist_decode_files_device", C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                          C.POINTER(C.c_int64), C.POINTER(ImageDesc)]),
+    ("ist_ctx_set_timing", C.c_int, [C.c_void_p, C.c_int]),
+    ("ist_ctx_last_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     ("ist_stitch_files_png", C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_double,
                                        C.POINTER(Limits), C.c_int, C.POINTER(Plan), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int64)]),
     ("ist_png_bound", C.c_int64, [C.c_int64, C.c_int64]),

@@ -21,6 +21,8 @@ struct ist_ctx {
   std::mutex mu;                         // one host-path stitch in flight per context (index.js:772 isStitching)
   int png_level = 1;                     // 1: Paeth + run-length + Huffman; 0: stored deflate blocks (ist_ctx_set_png_level)
   std::unique_ptr<ist::Stager> stager;   // pinned staging ring, built on first use
+  bool timing_on = false;                // ist_ctx_set_timing: the file pipeline records its phase times (adds a sync per phase)
+  double last_ms[IST_PHASE_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 struct ist_job {

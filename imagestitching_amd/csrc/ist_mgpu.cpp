@@ -1,0 +1,463 @@
+// ist_mgpu.cpp — one stitch on a GROUP of GPUs from ONE process (the N-API host's way in): parts rendered on their
+// devices, finished bands gathered into the root's canvas with one grouped RCCL send/recv batch over xGMI.
+//
+// Reference anchor: the per-image loop of onStitch (pages/index/index.js:1439-1554) — independent iterations; the seam
+// the mini-program would call is onStitchVertical/Horizontal -> onStitch (index.js:771-788 -> :1186).  BASELINE.json
+// north_star: "partitioned across the 8 GPUs of one node by assigning disjoint input-image subsets per GPU with a single
+// RCCL gather over xGMI".  The one-process-per-GPU variant of the same layout is imagestitching_amd/dist.py (torchrun);
+// both cut the job with ist_shard_parts.
+//
+// Layout of a launch (slot 0 = the root; a device may serve several slots):
+//   * parts of slot 0 are cells of the root's own fused launch;
+//   * every other part has a band job (white fill + that draw, clipped to the part's box).  On the root's DEVICE it
+//     renders straight into the canvas; on another device into a compact band, which ncclSend delivers to the root:
+//     full-width boxes are contiguous canvas bytes and are received IN PLACE (the root launch carries a HOLE there), other
+//     boxes go to a staging band that a 1:1 placement launch copies in behind its receive (same stream);
+//   * one ncclGroupStart/ncclGroupEnd holds every send and receive of the step (RCCL has no gatherv).  xGMI is point to
+//     point: each sender has its own link to the root, so there is no ring and no tree to build.
+// RCCL is dlopen'ed on first use (librccl.so.1): hosts that stay on one GPU never load it.
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "ist_ctx.h"
+#include "ist_internal.h"
+
+using namespace ist;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ RCCL, late bound
+typedef struct ncclComm* ncclComm_t;
+struct Rccl {
+  void* lib = nullptr;
+  int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string error;
+};
+constexpr int kNcclUint8 = 1;        // ncclDataType_t::ncclUint8 (rccl.h)
+
+Rccl* rccl() {
+  static Rccl* R = [] {
+    Rccl* r = new Rccl;
+    // the copy already in the process first (a PyTorch host carries its own librccl.so bound to ITS HIP runtime)
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    for (const char* n : names) if (!r->lib) r->lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    const char* paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    for (const char* n : paths) if (!r->lib) r->lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!r->lib) { r->error = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?"); return r; }
+    auto sym = [&](const char* n) { void* p = dlsym(r->lib, n); if (!p && r->error.empty()) r->error = std::string("librccl: missing symbol ") + n; return p; };
+    r->CommInitAll = reinterpret_cast<decltype(r->CommInitAll)>(sym("ncclCommInitAll"));
+    r->CommDestroy = reinterpret_cast<decltype(r->CommDestroy)>(sym("ncclCommDestroy"));
+    r->GroupStart = reinterpret_cast<decltype(r->GroupStart)>(sym("ncclGroupStart"));
+    r->GroupEnd = reinterpret_cast<decltype(r->GroupEnd)>(sym("ncclGroupEnd"));
+    r->Send = reinterpret_cast<decltype(r->Send)>(sym("ncclSend"));
+    r->Recv = reinterpret_cast<decltype(r->Recv)>(sym("ncclRecv"));
+    r->GetErrorString = reinterpret_cast<decltype(r->GetErrorString)>(sym("ncclGetErrorString"));
+    return r;
+  }();
+  return R;
+}
+
+int nccl_fail(const char* what, int rc) {
+  Rccl* R = rccl();
+  return fail(IST_E_HIP, std::string(what) + ": " + (R->GetErrorString ? R->GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ handles
+struct ist_group {
+  std::vector<int> slot_dev;              // device of every slot, as the caller listed them
+  std::vector<int> devs;                  // distinct devices, devs[0] = the root's
+  std::vector<int> slot_rank;             // slot -> index into devs (= RCCL rank)
+  std::vector<ist_ctx*> ctx;              // one context per distinct device (its stream carries the renders and sends)
+  hipStream_t recv_stream = nullptr;      // root device: receives + placement launches, beside the root's own launch
+  std::vector<ncclComm_t> comm;           // one communicator handle per distinct device; empty while the group is one device
+  bool self_send = false;                 // test knob (IST_TUNING=1 IST_GROUP_SELF_SEND=1): same-device bands also travel through RCCL
+  std::mutex mu;
+};
+
+struct ist_group_job {
+  ist_group* g = nullptr;
+  int64_t cw = 0, ch = 0;
+  int n_images = 0;
+  struct PartRt {
+    ist_part part;
+    int rank = 0;                         // device index of the owner
+    bool local = false;                   // rendered on the root's device straight into the canvas
+    ist_job* band_job = nullptr;          // slot != 0
+    void* band = nullptr;                 // compact band on the owner's device (remote parts)
+    ist_job* place_job = nullptr;         // root: staged band -> canvas
+    void* staging = nullptr;              // root device
+  };
+  std::vector<PartRt> parts;
+  ist_job* root_job = nullptr;
+};
+
+namespace {
+
+void group_job_free(ist_group_job* j) {
+  if (!j) return;
+  for (auto& p : j->parts) {
+    if (p.band_job) ist_job_destroy(p.band_job);
+    if (p.place_job) ist_job_destroy(p.place_job);
+    if (p.band) { DeviceGuard g(j->g->devs[static_cast<size_t>(p.rank)]); (void)hipFree(p.band); }
+    if (p.staging) { DeviceGuard g(j->g->devs[0]); (void)hipFree(p.staging); }
+  }
+  if (j->root_job) ist_job_destroy(j->root_job);
+  delete j;
+}
+
+inline size_t part_bytes(const ist_part& p) { return static_cast<size_t>(p.X1 - p.X0) * 4 * static_cast<size_t>(p.Y1 - p.Y0); }
+
+}  // namespace
+
+extern "C" {
+
+ist_group* ist_group_create(const int* devices, int ndev) {
+  if (!devices || ndev < 1 || ndev > 64) { fail(IST_E_INVALID, "ist_group_create: device list must hold 1..64 entries"); return nullptr; }
+  const int have = ist_device_count();
+  if (have <= 0) { fail(IST_E_NO_DEVICE, "no HIP device: the stitch path has no CPU fallback"); return nullptr; }
+  std::unique_ptr<ist_group> g(new ist_group);
+  for (int s = 0; s < ndev; ++s) {
+    if (devices[s] < 0 || devices[s] >= have) { fail(IST_E_INVALID, "ist_group_create: device " + std::to_string(devices[s]) + " does not exist (" + std::to_string(have) + " visible)"); return nullptr; }
+    g->slot_dev.push_back(devices[s]);
+    size_t r = 0;
+    while (r < g->devs.size() && g->devs[r] != devices[s]) ++r;
+    if (r == g->devs.size()) g->devs.push_back(devices[s]);
+    g->slot_rank.push_back(static_cast<int>(r));
+  }
+  struct Undo { ist_group* g; bool keep = false; ~Undo() { if (!keep) for (ist_ctx* c : g->ctx) ist_ctx_destroy(c); } } undo{g.get()};
+  for (int d : g->devs) {
+    ist_ctx* c = ist_ctx_create(d);
+    if (!c) return nullptr;
+    g->ctx.push_back(c);
+  }
+  {
+    DeviceGuard dg(g->devs[0]);
+    if (hipStreamCreateWithFlags(&g->recv_stream, hipStreamNonBlocking) != hipSuccess) { fail(IST_E_HIP, "hipStreamCreate failed"); return nullptr; }
+  }
+  g->self_send = tuning_mode() && std::getenv("IST_GROUP_SELF_SEND") != nullptr;
+  if (g->devs.size() > 1 || g->self_send) {
+    Rccl* R = rccl();
+    if (!R->error.empty()) { fail(IST_E_NO_DEVICE, "a group of several GPUs needs RCCL: " + R->error); (void)hipStreamDestroy(g->recv_stream); return nullptr; }
+    g->comm.assign(g->devs.size(), nullptr);
+    const int rc = R->CommInitAll(g->comm.data(), static_cast<int>(g->devs.size()), g->devs.data());
+    if (rc != 0) { nccl_fail("ncclCommInitAll", rc); g->comm.clear(); (void)hipStreamDestroy(g->recv_stream); return nullptr; }
+  }
+  undo.keep = true;
+  return g.release();
+}
+
+void ist_group_destroy(ist_group* g) {
+  if (!g) return;
+  for (ncclComm_t c : g->comm) if (c) (void)rccl()->CommDestroy(c);
+  if (g->recv_stream) { DeviceGuard dg(g->devs[0]); (void)hipStreamSynchronize(g->recv_stream); (void)hipStreamDestroy(g->recv_stream); }
+  for (ist_ctx* c : g->ctx) ist_ctx_destroy(c);
+  delete g;
+}
+
+int ist_group_slots(const ist_group* g) { return g ? static_cast<int>(g->slot_dev.size()) : 0; }
+int ist_group_device(const ist_group* g, int slot) {
+  if (!g || slot < 0 || slot >= static_cast<int>(g->slot_dev.size())) return -1;
+  return g->slot_dev[static_cast<size_t>(slot)];
+}
+
+ist_group_job* ist_group_job_create(ist_group* g, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops,
+                                    int n_ops, const ist_image_desc* images, int n_images, int filter, int split) {
+  if (!g) { fail(IST_E_NO_CONTEXT, "无法获取绘图上下文"); return nullptr; }
+  if (!ops || n_ops < 1 || !images || n_images < 1) { fail(IST_E_INVALID, "ist_group_job_create: empty op list"); return nullptr; }
+  const int n_slots = static_cast<int>(g->slot_dev.size());
+  std::vector<ist_part> cut(static_cast<size_t>(n_ops) + static_cast<size_t>(n_slots) + 8);
+  int n_parts = 0;
+  if (ist_shard_parts(ops, n_ops, canvas_w, canvas_h, images, n_images, filter, n_slots, split, cut.data(), static_cast<int>(cut.size()), &n_parts) != IST_OK)
+    return nullptr;
+  std::unique_ptr<ist_group_job, void (*)(ist_group_job*)> job(new ist_group_job, group_job_free);
+  job->g = g; job->cw = canvas_w; job->ch = canvas_h; job->n_images = n_images;
+  static const uint8_t transparent[4] = {0, 0, 0, 0};
+  const uint8_t* clear = clear_rgba ? clear_rgba : transparent;
+  // the root's own launch: every op that is not a sharded draw (fills), the draws slot 0 owns a part of, and - listed
+  // last, so that nothing lies on top of them - a HOLE over every part someone else writes
+  std::vector<ist_op> root_ops;
+  std::vector<char> root_draw(static_cast<size_t>(n_ops), 0), sharded(static_cast<size_t>(n_ops), 0);
+  for (int k = 0; k < n_parts; ++k) { sharded[static_cast<size_t>(cut[k].op)] = 1; if (cut[k].slot == 0) root_draw[static_cast<size_t>(cut[k].op)] = 1; }
+  for (int k = 0; k < n_ops; ++k)
+    if (ops[k].kind != IST_OP_DRAW || root_draw[static_cast<size_t>(k)]) root_ops.push_back(ops[k]);
+  (void)sharded;                               // (a draw that shards into nothing draws nothing: dropping it changes no pixel)
+  for (int k = 0; k < n_parts; ++k) {
+    const ist_part& p = cut[k];
+    ist_group_job::PartRt rt;
+    rt.part = p;
+    rt.rank = g->slot_rank[static_cast<size_t>(p.slot)];
+    rt.local = rt.rank == 0 && !g->self_send;
+    job->parts.push_back(rt);
+    if (p.slot == 0) continue;
+    ist_op hole;
+    std::memset(&hole, 0, sizeof hole);
+    hole.kind = IST_OP_HOLE; hole.image = -1;
+    hole.m[0] = 1.0; hole.m[3] = 1.0;
+    hole.d[0] = p.X0; hole.d[1] = p.Y0; hole.d[2] = p.X1 - p.X0; hole.d[3] = p.Y1 - p.Y0;
+    root_ops.push_back(hole);
+  }
+  job->root_job = ist_job_create(g->ctx[0], canvas_w, canvas_h, clear, root_ops.data(), static_cast<int>(root_ops.size()), images, n_images, filter, nullptr);
+  if (!job->root_job) return nullptr;
+  // the first fill of the list paints the background of every band (index.js:1423-1424)
+  int fill_at = -1;
+  for (int k = 0; k < n_ops && fill_at < 0; ++k) if (ops[k].kind == IST_OP_FILL) fill_at = k;
+  for (auto& rt : job->parts) {
+    const ist_part& p = rt.part;
+    if (p.slot == 0) continue;
+    ist_op two[2]; int n2 = 0;
+    if (fill_at >= 0 && fill_at < p.op) two[n2++] = ops[fill_at];
+    two[n2++] = ops[p.op];
+    const ist_region clip{p.X0, p.Y0, p.X1 - p.X0, p.Y1 - p.Y0};
+    rt.band_job = ist_job_create(g->ctx[static_cast<size_t>(rt.rank)], canvas_w, canvas_h, clear, two, n2, images, n_images, filter, &clip);
+    if (!rt.band_job) return nullptr;
+    if (rt.local) continue;
+    {
+      DeviceGuard dg(g->devs[static_cast<size_t>(rt.rank)]);
+      if (hipMalloc(&rt.band, part_bytes(p)) != hipSuccess) { (void)hipGetLastError(); fail(IST_E_NOMEM, "out of device memory for a band"); return nullptr; }
+    }
+    if (p.in_place) continue;
+    // staged: received into a compact band on the root, then placed by a 1:1 draw clipped to the box
+    DeviceGuard dg(g->devs[0]);
+    if (hipMalloc(&rt.staging, part_bytes(p)) != hipSuccess) { (void)hipGetLastError(); fail(IST_E_NOMEM, "out of device memory for a staging band"); return nullptr; }
+    ist_op put;
+    std::memset(&put, 0, sizeof put);
+    put.kind = IST_OP_DRAW; put.image = 0;
+    put.m[0] = 1.0; put.m[3] = 1.0;
+    put.s[2] = p.X1 - p.X0; put.s[3] = p.Y1 - p.Y0;
+    put.d[0] = p.X0; put.d[1] = p.Y0; put.d[2] = p.X1 - p.X0; put.d[3] = p.Y1 - p.Y0;
+    ist_image_desc band_desc;
+    std::memset(&band_desc, 0, sizeof band_desc);
+    band_desc.width = p.X1 - p.X0; band_desc.height = p.Y1 - p.Y0; band_desc.orientation = 1; band_desc.opaque = 1;
+    rt.place_job = ist_job_create(g->ctx[0], canvas_w, canvas_h, clear, &put, 1, &band_desc, 1, IST_FILTER_NEAREST, &clip);
+    if (!rt.place_job) return nullptr;
+  }
+  return job.release();
+}
+
+void ist_group_job_destroy(ist_group_job* job) { group_job_free(job); }
+
+int ist_group_job_parts(const ist_group_job* job, ist_part* parts, int max_parts, int* n_parts) {
+  if (!job || !n_parts) return fail(IST_E_INVALID, "ist_group_job_parts: NULL argument");
+  *n_parts = static_cast<int>(job->parts.size());
+  if (!parts) return IST_OK;
+  if (max_parts < *n_parts) return fail(IST_E_INVALID, "ist_group_job_parts: part table too small");
+  for (size_t k = 0; k < job->parts.size(); ++k) parts[k] = job->parts[k].part;
+  return IST_OK;
+}
+
+// src[k] / src_pitch[k] belong to PART k: the device address (on the part's device) of ROW 0 of the part's image.  A slot
+// that holds only rows [sy0, sy1) passes the address of row sy0 minus sy0 * pitch.  dst: the canvas on the root's device,
+// rows contiguous.  Asynchronous; ist_group_sync waits for the canvas.
+int ist_group_job_launch(ist_group_job* job, const void* const* src, const size_t* src_pitch, int n_parts, void* dst, size_t dst_pitch) {
+  if (!job || !src || !dst) return fail(IST_E_INVALID, "ist_group_job_launch: NULL argument");
+  if (n_parts != static_cast<int>(job->parts.size())) return fail(IST_E_INVALID, "ist_group_job_launch: one source pointer per part is expected");
+  if (dst_pitch != static_cast<size_t>(job->cw) * 4) return fail(IST_E_INVALID, "ist_group_job_launch: the canvas rows must be contiguous (dst_pitch == canvas_w * 4)");
+  ist_group* g = job->g;
+  std::lock_guard<std::mutex> lock(g->mu);
+  const size_t ni = static_cast<size_t>(job->n_images);
+  std::vector<const void*> one(ni, nullptr);
+  std::vector<size_t> one_pitch(ni, 0);
+  bool any_remote = false;
+  // 1. every band on its owner's stream
+  for (size_t k = 0; k < job->parts.size(); ++k) {
+    auto& rt = job->parts[k];
+    const ist_part& p = rt.part;
+    if (p.slot == 0) continue;
+    if (!src[k]) return fail(IST_E_DECODE, "图片" + std::to_string(p.image) + "解码异常");
+    std::fill(one.begin(), one.end(), nullptr);
+    one[static_cast<size_t>(p.image)] = src[k];
+    one_pitch[static_cast<size_t>(p.image)] = src_pitch ? src_pitch[k] : 0;
+    int rc;
+    if (rt.local) {
+      rc = ist_job_launch(rt.band_job, one.data(), src_pitch ? one_pitch.data() : nullptr, job->n_images, dst, dst_pitch, g->ctx[0]->stream);
+    } else {
+      const size_t bp = static_cast<size_t>(p.X1 - p.X0) * 4;
+      const uintptr_t biased = reinterpret_cast<uintptr_t>(rt.band) - (static_cast<uintptr_t>(p.Y0) * bp + static_cast<uintptr_t>(p.X0) * 4);
+      rc = ist_job_launch(rt.band_job, one.data(), src_pitch ? one_pitch.data() : nullptr, job->n_images, reinterpret_cast<void*>(biased), bp,
+                          g->ctx[static_cast<size_t>(rt.rank)]->stream);
+      any_remote = true;
+    }
+    if (rc) return rc;
+  }
+  // 2. the root's own launch: slot 0's pointers, by image
+  std::fill(one.begin(), one.end(), nullptr);
+  for (size_t k = 0; k < job->parts.size(); ++k) {
+    const ist_part& p = job->parts[k].part;
+    if (p.slot != 0) continue;
+    if (!src[k]) return fail(IST_E_DECODE, "图片" + std::to_string(p.image) + "解码异常");
+    one[static_cast<size_t>(p.image)] = src[k];
+    one_pitch[static_cast<size_t>(p.image)] = src_pitch ? src_pitch[k] : 0;
+  }
+  int rc = ist_job_launch(job->root_job, one.data(), src_pitch ? one_pitch.data() : nullptr, job->n_images, dst, dst_pitch, g->ctx[0]->stream);
+  if (rc) return rc;
+  if (!any_remote) return IST_OK;
+  // 3. ONE grouped batch: every sender's bands to the root, the root's receives on their own stream
+  Rccl* R = rccl();
+  int nrc = R->GroupStart();
+  if (nrc) return nccl_fail("ncclGroupStart", nrc);
+  for (auto& rt : job->parts) {
+    if (rt.part.slot == 0 || rt.local) continue;
+    const size_t bytes = part_bytes(rt.part);
+    void* into = rt.part.in_place ? static_cast<void*>(static_cast<uint8_t*>(dst) + static_cast<size_t>(rt.part.Y0) * dst_pitch) : rt.staging;
+    nrc = R->Send(rt.band, bytes, kNcclUint8, 0, g->comm[static_cast<size_t>(rt.rank)], g->ctx[static_cast<size_t>(rt.rank)]->stream);
+    if (!nrc) nrc = R->Recv(into, bytes, kNcclUint8, rt.rank, g->comm[0], g->recv_stream);
+    if (nrc) { (void)R->GroupEnd(); return nccl_fail("ncclSend/ncclRecv", nrc); }
+  }
+  nrc = R->GroupEnd();
+  if (nrc) return nccl_fail("ncclGroupEnd", nrc);
+  // 4. staged bands: placed behind their receive (same stream)
+  for (auto& rt : job->parts) {
+    if (!rt.place_job) continue;
+    const void* band = rt.staging;
+    const size_t bp = static_cast<size_t>(rt.part.X1 - rt.part.X0) * 4;
+    rc = ist_job_launch(rt.place_job, &band, &bp, 1, dst, dst_pitch, g->recv_stream);
+    if (rc) return rc;
+  }
+  return IST_OK;
+}
+
+int ist_group_sync(ist_group* g) {
+  if (!g) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  for (size_t r = 0; r < g->devs.size(); ++r) {
+    DeviceGuard dg(g->devs[r]);
+    if (hipStreamSynchronize(g->ctx[r]->stream) != hipSuccess) return fail(IST_E_HIP, "hipStreamSynchronize failed");
+  }
+  DeviceGuard dg(g->devs[0]);
+  if (hipStreamSynchronize(g->recv_stream) != hipSuccess) return fail(IST_E_HIP, "hipStreamSynchronize failed");
+  return IST_OK;
+}
+
+// ---- host path: stitch(images, direction, {devices}) ------------------------------------------------------------------
+// plan -> parts -> every device uploads ONLY the source rows its parts sample (its own PCIe link, its own packing threads)
+// -> bands + gather -> the root's canvas comes back as one pooled pinned block.
+int ist_group_stitch_rgba8(ist_group* g, const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch, int n_images,
+                           int direction, int mode, double gap, const ist_limits* limits, int filter, int split, ist_plan* out_plan,
+                           uint8_t** out_pixels) {
+  if (!g) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (!out_plan || !out_pixels) return fail(IST_E_INVALID, "ist_group_stitch_rgba8: NULL output");
+  *out_pixels = nullptr;
+  ist_limits lim;
+  if (limits) lim = *limits; else ist_limits_unlimited(&lim);
+  int rc = ist_plan_compute(images, n_images, direction, mode, gap, &lim, out_plan);
+  if (rc != IST_OK) return rc;
+  struct PlanGuard { ist_plan* p; bool keep = false; ~PlanGuard() { if (!keep) ist_plan_free(p); } } pg{out_plan};
+  std::vector<ist_op> ops(static_cast<size_t>(out_plan->n_rects) + 1);
+  int n_ops = 0;
+  rc = ist_plan_ops(out_plan, images, n_images, ops.data(), &n_ops);
+  if (rc != IST_OK) return rc;
+  static const uint8_t transparent[4] = {0, 0, 0, 0};
+  ist_group_job* job = ist_group_job_create(g, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, images, n_images, filter, split);
+  if (!job) return g_last_code ? g_last_code : IST_E_INVALID;
+  struct JobFree { ist_group_job* j; ~JobFree() { ist_group_job_destroy(j); } } jf{job};
+
+  // holdings: per (device, image) the union of the rows its parts sample, + 16 readable bytes behind the last row
+  const size_t nd = g->devs.size();
+  struct Hold { int lo = 0, hi = 0; size_t off = 0; };
+  std::vector<std::map<int, Hold>> hold(nd);
+  for (const auto& rt : job->parts) {
+    if (!src || !src[rt.part.image]) return fail(IST_E_DECODE, "图片" + std::to_string(rt.part.image) + "解码异常");
+    auto it = hold[static_cast<size_t>(rt.rank)].find(rt.part.image);
+    if (it == hold[static_cast<size_t>(rt.rank)].end()) { Hold h; h.lo = rt.part.sy0; h.hi = rt.part.sy1; hold[static_cast<size_t>(rt.rank)][rt.part.image] = h; }
+    else { it->second.lo = std::min(it->second.lo, rt.part.sy0); it->second.hi = std::max(it->second.hi, rt.part.sy1); }
+  }
+  auto width_of = [&](int i) { return static_cast<size_t>(images[i].bmp_width > 0 ? images[i].bmp_width : images[i].width); };
+  std::vector<int> up_rc(nd, IST_OK);
+  std::vector<std::string> up_err(nd);
+  std::vector<std::unique_lock<std::mutex>> locks;
+  for (size_t r = 0; r < nd; ++r) locks.emplace_back(g->ctx[r]->mu);
+  {
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < nd; ++r) th.emplace_back([&, r]() {
+      ist_ctx* c = g->ctx[r];
+      DeviceGuard dg(c->device);
+      size_t total = 0;
+      for (auto& kv : hold[r]) { kv.second.off = total; total += ((width_of(kv.first) * 4 * static_cast<size_t>(kv.second.hi - kv.second.lo) + 16) + 255) & ~static_cast<size_t>(255); }
+      int rc2 = grow_device(&c->scratch_src, &c->scratch_src_bytes, total ? total : 256);
+      std::vector<RowsCopy> up;
+      for (auto& kv : hold[r]) {
+        const size_t row = width_of(kv.first) * 4, hp = src_pitch ? src_pitch[kv.first] : row;
+        if (hp < row) { rc2 = fail(IST_E_INVALID, "src_pitch too small"); break; }
+        up.push_back(RowsCopy{static_cast<uint8_t*>(c->scratch_src) + kv.second.off, src[kv.first] + static_cast<size_t>(kv.second.lo) * hp, nullptr, hp, row,
+                              static_cast<size_t>(kv.second.hi - kv.second.lo)});
+      }
+      if (rc2 == IST_OK) { if (!c->stager) c->stager.reset(new Stager(c->device)); rc2 = c->stager->upload(up, c->stream); }
+      up_rc[r] = rc2;
+      if (rc2) up_err[r] = g_last_error;
+    });
+    for (auto& t : th) t.join();
+  }
+  for (size_t r = 0; r < nd; ++r) if (up_rc[r]) return fail(up_rc[r], up_err[r]);
+  // canvas on the root, part pointers (row 0 of the image as seen from the holding)
+  ist_ctx* root = g->ctx[0];
+  const size_t canvas_bytes = static_cast<size_t>(out_plan->canvas_w) * 4 * static_cast<size_t>(out_plan->canvas_h);
+  {
+    DeviceGuard dg(root->device);
+    rc = grow_device(&root->scratch_dst, &root->scratch_dst_bytes, canvas_bytes);
+    if (rc) return rc;
+  }
+  std::vector<const void*> psrc(job->parts.size(), nullptr);
+  std::vector<size_t> ppitch(job->parts.size(), 0);
+  for (size_t k = 0; k < job->parts.size(); ++k) {
+    const auto& rt = job->parts[k];
+    const Hold& h = hold[static_cast<size_t>(rt.rank)][rt.part.image];
+    const size_t row = width_of(rt.part.image) * 4;
+    psrc[k] = reinterpret_cast<const void*>(reinterpret_cast<uintptr_t>(g->ctx[static_cast<size_t>(rt.rank)]->scratch_src) + h.off - static_cast<uintptr_t>(h.lo) * row);
+    ppitch[k] = row;
+  }
+  rc = ist_group_job_launch(job, psrc.data(), ppitch.data(), static_cast<int>(job->parts.size()), root->scratch_dst, static_cast<size_t>(out_plan->canvas_w) * 4);
+  if (rc) return rc;
+  rc = ist_group_sync(g);
+  if (rc) return rc;
+  {
+    DeviceGuard dg(root->device);
+    uint8_t* host = static_cast<uint8_t*>(pool_take(canvas_bytes));
+    if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
+    if (hipMemcpyAsync(host, root->scratch_dst, canvas_bytes, hipMemcpyDeviceToHost, root->stream) != hipSuccess || hipStreamSynchronize(root->stream) != hipSuccess) {
+      (void)hipGetLastError(); pool_give(host);
+      return fail(IST_E_HIP, "result readback failed");
+    }
+    *out_pixels = host;
+  }
+  pg.keep = true;
+  return IST_OK;
+}
+
+// stitch(images, direction, {devices: [...]}) in one call: groups are cached per device list
+int ist_stitch_rgba8_multi(const int* devices, int ndev, const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch,
+                           int n_images, int direction, int mode, double gap, const ist_limits* limits, int filter, int split,
+                           ist_plan* out_plan, uint8_t** out_pixels) {
+  if (!devices || ndev < 1) return fail(IST_E_INVALID, "ist_stitch_rgba8_multi: empty device list");
+  static std::mutex mu;
+  static std::map<std::vector<int>, ist_group*>* cache = new std::map<std::vector<int>, ist_group*>();   // never destroyed: no HIP calls at exit
+  ist_group* g = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    const std::vector<int> key(devices, devices + ndev);
+    auto it = cache->find(key);
+    if (it != cache->end()) g = it->second;
+    else {
+      g = ist_group_create(devices, ndev);
+      if (!g) return g_last_code ? g_last_code : IST_E_INVALID;
+      (*cache)[key] = g;
+    }
+  }
+  return ist_group_stitch_rgba8(g, images, src, src_pitch, n_images, direction, mode, gap, limits, filter, split, out_plan, out_pixels);
+}
+
+}  // extern "C"

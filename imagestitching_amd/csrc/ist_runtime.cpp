@@ -423,37 +423,42 @@ int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8
   return ist_png_decode_rgba8(file, len, out, out_pitch, out_rows);
 }
 
-// ---- the whole onStitch for files, device-resident: only file bytes go in and only PNG bytes come out over PCIe -------
-// decode (index.js:1441-1520) -> plan (1251-1386) -> one fused resample+blit launch (1532-1551) -> PNG export (1577-1579).
-// The serial part of decoding (Huffman / inflate) runs on host threads, one per image; JPEG reconstruction, the stitch
-// and the PNG encoder run on the GPU and hand buffers to each other in HBM.
-int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images, int direction, int mode,
-                         double gap, const ist_limits* limits, int filter, ist_plan* out_plan, uint8_t** out_png,
-                         int64_t* out_len) {
-  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
-  if (!out_plan || !out_png || !out_len) return fail(IST_E_INVALID, "ist_stitch_files_png: NULL output");
-  *out_png = nullptr; *out_len = 0;
-  std::memset(out_plan, 0, sizeof(*out_plan));
-  if (n_images <= 0) return IST_NOTHING_TO_DO;
-  if (!files || !lens) return fail(IST_E_INVALID, "ist_stitch_files_png: NULL input");
-  if (n_images > kMaxImages) return fail(IST_E_UNSUPPORTED, "more than 128 images in one launch");
-  const int n = n_images;
-  // IST_TIMING=1: phase times of this call on stderr (diagnostics; the phases end with a stream sync only when it is on)
-  static const bool timing = std::getenv("IST_TIMING") != nullptr;
-  auto now = []() { return std::chrono::steady_clock::now(); };
-  auto t_prev = now();
-  auto lap = [&](const char* what, hipStream_t st) {
-    if (!timing) return;
+// ---- files -> bitmaps in HBM: the decode stage shared by ist_stitch_files_png and ist_decode_files_device ------------
+extern "C++" {
+namespace {
+
+// one input file after the host stage: container parsed; for JPEG either the de-stuffed scan (GPU Huffman) or the
+// coefficients (host Huffman); for PNG / BMP / GIF the decoded pixels
+struct Dec { int rc = 0; std::string err; bool jpeg = false; JpegImage J; JpegGpuScan G; int w = 0, h = 0, orient = 0; std::vector<uint8_t> px; };
+
+// phase clock: stderr lines under IST_TIMING=1, numbers for ist_ctx_last_timing when the context asked for them.  Phases
+// end with a stream synchronisation only while one of the two is on.
+struct Phases {
+  ist_ctx* ctx; bool print, on;
+  std::chrono::steady_clock::time_point t_prev;
+  explicit Phases(ist_ctx* c) : ctx(c) {
+    static const bool env = std::getenv("IST_TIMING") != nullptr;
+    print = env; on = env || c->timing_on;
+    if (c->timing_on) for (double& v : c->last_ms) v = 0.0;
+    t_prev = std::chrono::steady_clock::now();
+  }
+  void lap(int phase, const char* what, hipStream_t st) {
+    if (!on) return;
     if (st) (void)hipStreamSynchronize(st);
-    const auto t = now();
-    std::fprintf(stderr, "[ist timing] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    const auto t = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(t - t_prev).count();
+    if (print) std::fprintf(stderr, "[ist timing] %-28s %8.2f ms\n", what, ms);
+    if (ctx->timing_on && phase >= 0 && phase < IST_PHASE_COUNT) ctx->last_ms[phase] += ms;
     t_prev = t;
-  };
-  // 1. host side of decoding, one thread per image
-  struct Dec { int rc = 0; std::string err; bool jpeg = false; JpegImage J; JpegGpuScan G; int w = 0, h = 0, orient = 0; std::vector<uint8_t> px; };
+  }
+};
+
+// 1. host side of decoding, one thread per image (index.js:1441-1520: the serial part of what the platform decoder does)
+int decode_host_stage(const uint8_t* const* files, const int64_t* lens, int n, std::vector<Dec>* out) {
   // baseline JPEGs: Huffman decoding on the GPU (ist_jpeg_gpu.hip); IST_JPEG_HOST_HUFFMAN=1 keeps it on the host threads
   static const bool gpu_huffman = std::getenv("IST_JPEG_HOST_HUFFMAN") == nullptr;
-  std::vector<Dec> dec(static_cast<size_t>(n));
+  std::vector<Dec>& dec = *out;
+  dec.clear(); dec.resize(static_cast<size_t>(n));
   {
     std::vector<std::thread> th;
     for (int i = 0; i < n; ++i) th.emplace_back([&, i]() {
@@ -475,47 +480,22 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   for (int i = 0; i < n; ++i)
     if (dec[static_cast<size_t>(i)].rc != IST_OK)
       return fail(dec[static_cast<size_t>(i)].rc, "图片" + std::to_string(i) + "解码异常: " + dec[static_cast<size_t>(i)].err);   // index.js:1512-1514
+  return IST_OK;
+}
 
-  lap("decode on host threads", nullptr);
-  // 2. plan (orientation from the file, like getImageInfo -> index.js:734)
-  std::vector<ist_image_desc> descs(static_cast<size_t>(n));
-  for (int i = 0; i < n; ++i) {
-    const Dec& D = dec[static_cast<size_t>(i)];
-    ist_image_desc& d = descs[static_cast<size_t>(i)];
-    std::memset(&d, 0, sizeof d);
-    d.width = D.w; d.height = D.h; d.orientation = D.orient ? D.orient : 1; d.opaque = D.jpeg ? 1 : 0; d.file_size = lens[i];
-  }
-  ist_limits lim;
-  if (limits) lim = *limits; else ist_limits_unlimited(&lim);
-  int rc = ist_plan_compute(descs.data(), n, direction, mode, gap, &lim, out_plan);
-  if (rc != IST_OK) return rc;
-  struct PlanGuard { ist_plan* p; bool keep = false; ~PlanGuard() { if (!keep) ist_plan_free(p); } } pg{out_plan};
-  std::vector<ist_op> ops(static_cast<size_t>(out_plan->n_rects) + 1);
-  int n_ops = 0;
-  rc = ist_plan_ops(out_plan, descs.data(), n, ops.data(), &n_ops);
-  if (rc != IST_OK) return rc;
+// device bytes the JPEG stages of the images need (coefficient planes, tables, sample planes), carved from *off
+void decode_layout(const std::vector<Dec>& dec, size_t* off, std::vector<JpegDevLayout>* jo) {
+  jo->assign(dec.size(), JpegDevLayout());
+  for (size_t i = 0; i < dec.size(); ++i) if (dec[i].jpeg) jpeg_layout(dec[i].J, off, &(*jo)[i]);
+}
 
-  std::lock_guard<std::mutex> lock(ctx->mu);
-  DeviceGuard g(ctx->device);
-  // 3. one device arena: bitmaps, JPEG coefficient planes + sample planes, canvas, PNG
-  size_t off = 0;
-  auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
-  std::vector<size_t> o_img(static_cast<size_t>(n));
-  std::vector<JpegDevLayout> jo(static_cast<size_t>(n));
-  for (int i = 0; i < n; ++i) {
-    const Dec& D = dec[static_cast<size_t>(i)];
-    o_img[static_cast<size_t>(i)] = take(static_cast<size_t>(D.w) * 4 * D.h);
-    if (D.jpeg) jpeg_layout(D.J, &off, &jo[static_cast<size_t>(i)]);
-  }
-  const size_t canvas_pitch = static_cast<size_t>(out_plan->canvas_w) * 4;
-  const size_t o_canvas = take(canvas_pitch * static_cast<size_t>(out_plan->canvas_h));
-  const int64_t png_cap = ist_png_bound(out_plan->canvas_w, out_plan->canvas_h);
-  const size_t o_png = take(static_cast<size_t>(png_cap));
-  uint8_t* d = nullptr;
-  IST_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
-  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
-  lap("plan + device arena", nullptr);
-  // entropy decoding of the eligible JPEGs on the GPU; an image that fails its validation goes back to the host decoder
+// 2. device side: entropy decoding of the eligible JPEGs on the GPU (an image that fails its validation goes back to the
+// host decoder), reconstruction of every JPEG into img[i] (pitch[i]), upload of the host-decoded bitmaps.  Everything is
+// enqueued on ctx->stream; `d` is the arena decode_layout was sized for.
+int decode_device_stage(ist_ctx* ctx, std::vector<Dec>& dec, const uint8_t* const* files, const int64_t* lens, uint8_t* d,
+                        const std::vector<JpegDevLayout>& jo, uint8_t* const* img, const size_t* pitch, Phases* ph) {
+  const int n = static_cast<int>(dec.size());
+  int rc;
   {
     std::vector<JpegGpuItem> items; std::vector<int> who;
     for (int i = 0; i < n; ++i) {
@@ -542,45 +522,167 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
       }
       D.G.eligible = true;          // (the planes are on the device now: enqueue skips the upload)
     }
-    if (timing) {
+    if (ph->print) {
       int good = 0;
       for (uint8_t v : okv) good += v ? 1 : 0;
       std::fprintf(stderr, "[ist timing] GPU Huffman: %d of %zu eligible JPEGs decoded on the GPU, %zu went back to the host decoder\n", good, okv.size(), okv.size() - static_cast<size_t>(good));
     }
-    lap("entropy decode (GPU)", ctx->stream);
+    ph->lap(IST_PHASE_ENTROPY_GPU, "entropy decode (GPU)", ctx->stream);
   }
-  std::vector<const void*> dsrc(static_cast<size_t>(n));
-  std::vector<size_t> dpitch(static_cast<size_t>(n));
   std::vector<RowsCopy> host_px;                  // PNG / BMP / GIF bitmaps decoded on the host
   for (int i = 0; i < n; ++i) {
     const Dec& D = dec[static_cast<size_t>(i)];
-    uint8_t* img = d + o_img[static_cast<size_t>(i)];
     const size_t row = static_cast<size_t>(D.w) * 4;
-    dsrc[static_cast<size_t>(i)] = img; dpitch[static_cast<size_t>(i)] = row;
-    if (!D.jpeg) { host_px.push_back(RowsCopy{img, D.px.data(), nullptr, row, row, static_cast<size_t>(D.h)}); continue; }
-    rc = jpeg_enqueue(D.J, d, jo[static_cast<size_t>(i)], img, row, ctx->stream, D.G.eligible);
+    if (!D.jpeg) {
+      if (pitch[i] != row) {                      // the staged copies land on contiguous device rows: copy row by row
+        for (int y = 0; y < D.h; ++y) host_px.push_back(RowsCopy{img[i] + static_cast<size_t>(y) * pitch[i], D.px.data() + static_cast<size_t>(y) * row, nullptr, row, row, 1});
+      } else host_px.push_back(RowsCopy{img[i], D.px.data(), nullptr, row, row, static_cast<size_t>(D.h)});
+      continue;
+    }
+    rc = jpeg_enqueue(D.J, d, jo[static_cast<size_t>(i)], img[i], pitch[i], ctx->stream, D.G.eligible);
     if (rc) return rc;
   }
   rc = stager_of(ctx).upload(host_px, ctx->stream);
   if (rc) return rc;
-  lap("H2D + JPEG reconstruct (GPU)", ctx->stream);
-  // 4. the stitch: one fused launch from the decoded bitmaps (HBM) into the canvas (HBM)
+  ph->lap(IST_PHASE_RECONSTRUCT, "H2D + JPEG reconstruct (GPU)", ctx->stream);
+  return IST_OK;
+}
+
+}  // namespace
+}  // extern "C++"
+
+int ist_ctx_set_timing(ist_ctx* ctx, int on) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  ctx->timing_on = on != 0;
+  return IST_OK;
+}
+
+int ist_ctx_last_timing(ist_ctx* ctx, double* ms, int n) {
+  if (!ctx || !ms || n < 0) return fail(IST_E_INVALID, "ist_ctx_last_timing: bad argument");
+  for (int k = 0; k < n; ++k) ms[k] = k < IST_PHASE_COUNT ? ctx->last_ms[k] : 0.0;
+  return IST_OK;
+}
+
+// files -> decoded bitmaps in caller-owned device memory (the Image.src step, utils/canvas.js:27-121, ending in HBM)
+int ist_decode_files_device(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images, void* const* dst,
+                            const size_t* dst_pitch, const int64_t* dst_rows, ist_image_desc* out_descs) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (n_images <= 0) return IST_NOTHING_TO_DO;
+  if (!files || !lens || !dst || !dst_pitch || !dst_rows) return fail(IST_E_INVALID, "ist_decode_files_device: NULL argument");
+  std::vector<Dec> dec;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  Phases ph(ctx);
+  int rc = decode_host_stage(files, lens, n_images, &dec);
+  if (rc) return rc;
+  ph.lap(IST_PHASE_HOST_DECODE, "decode on host threads", nullptr);
+  std::vector<uint8_t*> img(static_cast<size_t>(n_images));
+  for (int i = 0; i < n_images; ++i) {
+    const Dec& D = dec[static_cast<size_t>(i)];
+    // the file's own header is untrusted: the caller states what its buffer holds
+    if (!dst[i] || dst_pitch[i] < static_cast<size_t>(D.w) * 4 || (dst_pitch[i] & 3) || dst_rows[i] < D.h || (reinterpret_cast<uintptr_t>(dst[i]) & 3))
+      return fail(IST_E_INVALID, "ist_decode_files_device: the buffer of image " + std::to_string(i) + " is too small for " + std::to_string(D.w) + "x" + std::to_string(D.h));
+    img[static_cast<size_t>(i)] = static_cast<uint8_t*>(dst[i]);
+    if (out_descs) {
+      ist_image_desc& d = out_descs[i];
+      std::memset(&d, 0, sizeof d);
+      d.width = D.w; d.height = D.h; d.orientation = D.orient ? D.orient : 1; d.opaque = D.jpeg ? 1 : 0; d.file_size = lens[i];
+    }
+  }
+  size_t off = 0;
+  std::vector<JpegDevLayout> jo;
+  decode_layout(dec, &off, &jo);
+  rc = grow_device(&ctx->scratch_dec, &ctx->scratch_dec_bytes, off ? off : 256);
+  if (rc) return rc;
+  ph.lap(IST_PHASE_PLAN_ARENA, "device arena", nullptr);
+  rc = decode_device_stage(ctx, dec, files, lens, static_cast<uint8_t*>(ctx->scratch_dec), jo, img.data(), dst_pitch, &ph);
+  if (rc) return rc;
+  IST_HIP(hipStreamSynchronize(ctx->stream));      // the bitmaps are complete; `dec` (host coefficients in flight) may go
+  return IST_OK;
+}
+
+// ---- the whole onStitch for files, device-resident: only file bytes go in and only PNG bytes come out over PCIe -------
+// decode (index.js:1441-1520) -> plan (1251-1386) -> one fused resample+blit launch (1532-1551) -> PNG export (1577-1579).
+// The serial part of decoding (Huffman / inflate) runs on host threads, one per image; JPEG reconstruction, the stitch
+// and the PNG encoder run on the GPU and hand buffers to each other in HBM.
+int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images, int direction, int mode,
+                         double gap, const ist_limits* limits, int filter, ist_plan* out_plan, uint8_t** out_png,
+                         int64_t* out_len) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (!out_plan || !out_png || !out_len) return fail(IST_E_INVALID, "ist_stitch_files_png: NULL output");
+  *out_png = nullptr; *out_len = 0;
+  std::memset(out_plan, 0, sizeof(*out_plan));
+  if (n_images <= 0) return IST_NOTHING_TO_DO;
+  if (!files || !lens) return fail(IST_E_INVALID, "ist_stitch_files_png: NULL input");
+  if (n_images > kMaxImages) return fail(IST_E_UNSUPPORTED, "more than 128 images in one launch");
+  const int n = n_images;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  DeviceGuard g(ctx->device);
+  Phases ph(ctx);
+  std::vector<Dec> dec;
+  int rc = decode_host_stage(files, lens, n, &dec);
+  if (rc) return rc;
+  ph.lap(IST_PHASE_HOST_DECODE, "decode on host threads", nullptr);
+  // plan (orientation from the file, like getImageInfo -> index.js:734)
+  std::vector<ist_image_desc> descs(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) {
+    const Dec& D = dec[static_cast<size_t>(i)];
+    ist_image_desc& d = descs[static_cast<size_t>(i)];
+    std::memset(&d, 0, sizeof d);
+    d.width = D.w; d.height = D.h; d.orientation = D.orient ? D.orient : 1; d.opaque = D.jpeg ? 1 : 0; d.file_size = lens[i];
+  }
+  ist_limits lim;
+  if (limits) lim = *limits; else ist_limits_unlimited(&lim);
+  rc = ist_plan_compute(descs.data(), n, direction, mode, gap, &lim, out_plan);
+  if (rc != IST_OK) return rc;
+  struct PlanGuard { ist_plan* p; bool keep = false; ~PlanGuard() { if (!keep) ist_plan_free(p); } } pg{out_plan};
+  std::vector<ist_op> ops(static_cast<size_t>(out_plan->n_rects) + 1);
+  int n_ops = 0;
+  rc = ist_plan_ops(out_plan, descs.data(), n, ops.data(), &n_ops);
+  if (rc != IST_OK) return rc;
+
+  // one device arena: bitmaps, JPEG coefficient planes + sample planes, canvas, PNG
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
+  std::vector<size_t> o_img(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) o_img[static_cast<size_t>(i)] = take(static_cast<size_t>(dec[static_cast<size_t>(i)].w) * 4 * dec[static_cast<size_t>(i)].h);
+  std::vector<JpegDevLayout> jo;
+  decode_layout(dec, &off, &jo);
+  const size_t canvas_pitch = static_cast<size_t>(out_plan->canvas_w) * 4;
+  const size_t o_canvas = take(canvas_pitch * static_cast<size_t>(out_plan->canvas_h));
+  const int64_t png_cap = ist_png_bound(out_plan->canvas_w, out_plan->canvas_h);
+  const size_t o_png = take(static_cast<size_t>(png_cap));
+  uint8_t* d = nullptr;
+  IST_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
+  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
+  ph.lap(IST_PHASE_PLAN_ARENA, "plan + device arena", nullptr);
+  std::vector<uint8_t*> img(static_cast<size_t>(n));
+  std::vector<const void*> dsrc(static_cast<size_t>(n));
+  std::vector<size_t> dpitch(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) {
+    img[static_cast<size_t>(i)] = d + o_img[static_cast<size_t>(i)];
+    dsrc[static_cast<size_t>(i)] = img[static_cast<size_t>(i)];
+    dpitch[static_cast<size_t>(i)] = static_cast<size_t>(dec[static_cast<size_t>(i)].w) * 4;
+  }
+  rc = decode_device_stage(ctx, dec, files, lens, d, jo, img.data(), dpitch.data(), &ph);
+  if (rc) return rc;
+  // the stitch: one fused launch from the decoded bitmaps (HBM) into the canvas (HBM)
   static const uint8_t transparent[4] = {0, 0, 0, 0};
   ist_job* job = ist_job_create(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, descs.data(), n, filter, nullptr);
   if (!job) return g_last_code ? g_last_code : IST_E_INVALID;
   struct JobFree { ist_job* j; ~JobFree() { ist_job_destroy(j); } } jf{job};
   rc = ist_job_launch(job, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, ctx->stream);
   if (rc) return rc;
-  lap("compile + stitch launch", ctx->stream);
-  // 5. PNG export on the device, then the only D2H of the call
+  ph.lap(IST_PHASE_STITCH, "compile + stitch launch", ctx->stream);
+  // PNG export on the device, then the only D2H of the call
   int64_t len = 0;
   rc = ist_png_encode_device(ctx, d + o_canvas, canvas_pitch, out_plan->canvas_w, out_plan->canvas_h, d + o_png, png_cap, &len, ctx->stream);
   if (rc) return rc;
-  lap("PNG encode (GPU)", ctx->stream);
+  ph.lap(IST_PHASE_PNG, "PNG encode (GPU)", ctx->stream);
   uint8_t* host = nullptr;
   rc = read_back_pooled(d + o_png, static_cast<size_t>(len), ctx->stream, &host);
   if (rc) return rc;
-  lap("PNG D2H", nullptr);
+  ph.lap(IST_PHASE_D2H, "PNG D2H", nullptr);
   *out_png = host; *out_len = len;
   pg.keep = true;
   return IST_OK;

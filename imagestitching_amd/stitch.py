@@ -35,7 +35,11 @@ DEFAULT_OPTS = {
     "superSample": None,    # None: 1 when platform is None, reference rule (index.js:1363) otherwise
     "edgeAA": False,        # anti-alias fractional rectangle edges by area coverage (IST_FILTER_EDGE_AA)
     "pngLevel": None,       # PNG export form of the *_png / stitch_files calls: 0 stored, 1 compressed on the GPU; None = DEFAULT_PNG_LEVEL
+    "devices": None,        # list of GPU indices (devices[0] = root): shard the stitch over them from this one process (ist_stitch_rgba8_multi)
+    "split": "image",       # with devices: "image" (image i -> devices[i mod n], BASELINE configs[3]) or "band" (equal output rows per device)
 }
+
+_SPLITS = {"image": L.SPLIT_IMAGE, "band": L.SPLIT_BAND}
 
 DEFAULT_PNG_LEVEL = 1
 
@@ -180,8 +184,13 @@ def stitch(images, direction, opts=None, device=0):
     cplan = L.Plan()
     lim = _limits(o)
     out = C.POINTER(C.c_uint8)()
-    rc = L.check(L.lib.ist_stitch_rgba8(_ctx(device), descs, ptrs, pitches, n, _DIRECTIONS[direction], _MODES[o["mode"]],
-                                        float(o["gap"] or 0), C.byref(lim), _filter_of(o), C.byref(cplan), C.byref(out)))
+    if o.get("devices"):
+        devs = (C.c_int * len(o["devices"]))(*[int(d) for d in o["devices"]])
+        rc = L.check(L.lib.ist_stitch_rgba8_multi(devs, len(o["devices"]), descs, ptrs, pitches, n, _DIRECTIONS[direction], _MODES[o["mode"]],
+                                                  float(o["gap"] or 0), C.byref(lim), _filter_of(o), _SPLITS[o["split"]], C.byref(cplan), C.byref(out)))
+    else:
+        rc = L.check(L.lib.ist_stitch_rgba8(_ctx(device), descs, ptrs, pitches, n, _DIRECTIONS[direction], _MODES[o["mode"]],
+                                            float(o["gap"] or 0), C.byref(lim), _filter_of(o), C.byref(cplan), C.byref(out)))
     if rc == L.IST_NOTHING_TO_DO:
         return None
     w, h = int(cplan.canvas_w), int(cplan.canvas_h)
@@ -272,6 +281,41 @@ def decode_image(data, device=0):
     ctx = _ctx(device) if buf[:2] == b"\xff\xd8" else None          # only JPEG needs the GPU
     L.check(L.lib.ist_image_decode_rgba8(ctx, buf, len(buf), out.ctypes.data, out.strides[0], out.shape[0]))
     return out
+
+
+def decode_files_device(blobs, device=0, out=None):
+    """File bytes -> bitmaps in HBM (ist_decode_files_device): returns ([HxWx4 uint8 CUDA tensors], [image dicts for
+    plan/compile]).  Baseline JPEG: Huffman decoding + reconstruction on the GPU; only the file bytes cross PCIe.
+    out: optional list of preallocated tensors (one spare row behind each is the caller's business)."""
+    import torch
+    n = len(blobs)
+    sizes = [image_info(b) for b in blobs]
+    dev = torch.device("cuda", device)
+    if out is None:
+        out = [torch.empty((h + 1, w, 4), dtype=torch.uint8, device=dev)[:h] for (w, h, _) in sizes]
+    files = (C.c_char_p * n)(*blobs)
+    lens = (C.c_int64 * n)(*[len(b) for b in blobs])
+    dst, pitch, rows = (C.c_void_p * n)(), (C.c_size_t * n)(), (C.c_int64 * n)()
+    for i, t in enumerate(out):
+        dst[i], pitch[i], rows[i] = t.data_ptr(), t.stride(0), t.shape[0]
+    descs = (L.ImageDesc * n)()
+    L.check(L.lib.ist_decode_files_device(_ctx(device), files, lens, n, dst, pitch, rows, descs))
+    imgs = [{"width": d.width, "height": d.height, "orientation": d.orientation, "opaque": bool(d.opaque), "fileSize": d.file_size} for d in descs]
+    return out, imgs
+
+
+PHASES = ("host_decode", "plan_arena", "entropy_gpu", "reconstruct", "stitch", "png", "d2h")
+
+
+def last_phase_times(device=0):
+    """{phase: ms} of the last file-pipeline call on the device's context (enable with set_phase_timing)."""
+    ms = (C.c_double * 8)()
+    L.check(L.lib.ist_ctx_last_timing(_ctx(device), ms, 8))
+    return {k: ms[i] for i, k in enumerate(PHASES)}
+
+
+def set_phase_timing(on, device=0):
+    L.check(L.lib.ist_ctx_set_timing(_ctx(device), 1 if on else 0))
 
 
 def stitch_files(paths, direction, opts=None, out_path=None, device=0, copy=True):
@@ -437,3 +481,76 @@ class Stitcher:
             n_ops = len(sel)
         job = self.compile_ops(p.canvas_w, p.canvas_h, ops, n_ops, p._descs, len(images), _filter_of(o))
         return p, job
+
+
+class GroupJob:
+    """A stitch compiled for a device group (ist_group_job_*): parts[k] = {image, slot, device, box, rows} and one source
+    pointer per part at launch."""
+
+    def __init__(self, group, handle, plan):
+        self._g, self._h, self.plan = group, handle, plan
+        n = C.c_int(0)
+        L.check(L.lib.ist_group_job_parts(handle, None, 0, C.byref(n)))
+        arr = (L.Part * max(1, n.value))()
+        L.check(L.lib.ist_group_job_parts(handle, arr, n.value, C.byref(n)))
+        self.parts = [{"image": p.image, "slot": p.slot, "device": group.devices[p.slot], "box": (p.X0, p.Y0, p.X1, p.Y1),
+                       "rows": (p.sy0, p.sy1), "in_place": bool(p.in_place)} for p in arr[:n.value]]
+
+    def launch(self, part_srcs, out):
+        """part_srcs[k]: HxWx4 uint8 CUDA tensor on parts[k]['device'] holding the WHOLE image, or (tensor, first_row) for a
+        partial holding (rows first_row ... ; one spare row behind the last must be readable).  out: canvas on the root."""
+        n = len(self.parts)
+        ptrs, pitches = (C.c_void_p * n)(), (C.c_size_t * n)()
+        for k, s in enumerate(part_srcs):
+            t, first = (s if isinstance(s, tuple) else (s, 0))
+            ptrs[k] = t.data_ptr() - first * t.stride(0)
+            pitches[k] = t.stride(0)
+        L.check(L.lib.ist_group_job_launch(self._h, ptrs, pitches, n, C.c_void_p(out.data_ptr()), out.stride(0)))
+
+    def close(self):
+        if self._h:
+            L.lib.ist_group_job_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class StitchGroup:
+    """Several GPUs driven from this one process (the N-API host's layout; ist_group_*).  devices[0] is the root."""
+
+    def __init__(self, devices):
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        self._h = L.lib.ist_group_create(arr, len(self.devices))
+        if not self._h:
+            raise L.StitchError(-5, L.last_error())
+
+    def compile(self, images, direction, opts=None):
+        o = _merge(opts)
+        p = plan(images, direction, o)
+        if p is None:
+            return None
+        ops, n_ops = p.ops()
+        clr = (C.c_uint8 * 4)(0, 0, 0, 0)
+        h = L.lib.ist_group_job_create(self._h, p.canvas_w, p.canvas_h, clr, ops, n_ops, p._descs, len(images), _filter_of(o), _SPLITS[o["split"]])
+        if not h:
+            raise L.StitchError(-1, L.last_error())
+        return GroupJob(self, h, p)
+
+    def sync(self):
+        L.check(L.lib.ist_group_sync(self._h))
+
+    def close(self):
+        if self._h:
+            L.lib.ist_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -198,6 +198,42 @@ IST_API int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, c
 IST_API void ist_free(void* p);                /* any buffer the library returned through an out pointer */
 IST_API void ist_pool_trim(void);              /* release the idle pinned blocks ist_free is keeping for reuse */
 
+/* ---- device groups: one stitch on several GPUs from ONE process (stitch(images, direction, {devices})) ------ */
+/* onStitchVertical/Horizontal -> onStitch (index.js:771-788 -> :1186) with the per-image iterations (:1439-1554) dealt to
+ * the GPUs of `devices` (devices[0] = the root; a device may be listed more than once).  The job is cut by ist_shard_parts;
+ * parts render on their devices, finished bands reach the root's canvas through ONE grouped ncclSend/ncclRecv batch
+ * (RCCL over xGMI; librccl.so.1 is loaded on first use of a group with more than one device): full-width bands are
+ * received in place, others are staged and placed by a 1:1 launch behind their receive.  Parts whose device is the
+ * root's render straight into the canvas.  The one-process-per-GPU form of the same layout is imagestitching_amd/dist.py. */
+typedef struct ist_group ist_group;
+typedef struct ist_group_job ist_group_job;
+IST_API ist_group* ist_group_create(const int* devices, int ndev);
+IST_API void ist_group_destroy(ist_group* g);
+IST_API int ist_group_slots(const ist_group* g);
+IST_API int ist_group_device(const ist_group* g, int slot);            /* -1 when slot is out of range */
+/* device-resident: compile once, launch on new buffers.  split = IST_SPLIT_IMAGE / IST_SPLIT_BAND. */
+IST_API ist_group_job* ist_group_job_create(ist_group* g, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
+                                            const ist_op* ops, int n_ops, const ist_image_desc* images, int n_images, int filter,
+                                            int split);
+IST_API void ist_group_job_destroy(ist_group_job* job);
+/* the part table of the job (parts == NULL: only the count); part k's owner device = ist_group_device(g, parts[k].slot) */
+IST_API int ist_group_job_parts(const ist_group_job* job, ist_part* parts, int max_parts, int* n_parts);
+/* src[k] / src_pitch[k] belong to PART k: the address, on the part's device, of row 0 of the part's image (a holder of rows
+ * [sy0, sy1) only passes the address of row sy0 minus sy0 * pitch; 16 bytes behind its last row must be readable).
+ * dst: the canvas on the root's device, dst_pitch == canvas_w * 4.  Asynchronous: ist_group_sync waits for the canvas. */
+IST_API int ist_group_job_launch(ist_group_job* job, const void* const* src, const size_t* src_pitch, int n_parts, void* dst,
+                                 size_t dst_pitch);
+IST_API int ist_group_sync(ist_group* g);
+/* host buffers in, host buffer out (ist_stitch_rgba8 on a group): every device uploads only the source rows its parts
+ * sample, over its own PCIe link; *out_pixels is library-owned (ist_free). */
+IST_API int ist_group_stitch_rgba8(ist_group* g, const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch,
+                                   int n_images, int direction, int mode, double gap, const ist_limits* limits, int filter,
+                                   int split, ist_plan* out_plan, uint8_t** out_pixels);
+/* the same in one call; groups are cached per device list for the life of the process */
+IST_API int ist_stitch_rgba8_multi(const int* devices, int ndev, const ist_image_desc* images, const uint8_t* const* src,
+                                   const size_t* src_pitch, int n_images, int direction, int mode, double gap,
+                                   const ist_limits* limits, int filter, int split, ist_plan* out_plan, uint8_t** out_pixels);
+
 /* ---- decode: PNG file -> RGBA8 (host; the Image.src step, utils/canvas.js:27-121, for 'png' inputs, index.js:4) ---- */
 /* colour types 0/2/3/4/6, bit depths 1-16 (16-bit keeps the high byte), tRNS, plain or Adam7-interlaced.  JPEG / WebP /
  * HEIC return IST_E_UNSUPPORTED; damaged files IST_E_DECODE ('图片N解码异常' analogue).
@@ -214,6 +250,19 @@ IST_API int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len
  * WebP.  ctx may be NULL for everything except JPEG (whose reconstruction runs on the GPU). */
 IST_API int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation);
 IST_API int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch, int64_t out_rows);
+
+/* files -> decoded bitmaps in CALLER-OWNED DEVICE memory (the Image.src step ending in HBM): baseline JPEG entropy decoding
+ * and reconstruction on the GPU, progressive JPEG / PNG / BMP / GIF entropy stages on host threads.  dst[i] must hold
+ * dst_rows[i] rows of dst_pitch[i] bytes (sizes from ist_image_info); out_descs (optional) receives what the planner needs
+ * (size, EXIF orientation, opaque).  Returns when the bitmaps are complete. */
+IST_API int ist_decode_files_device(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images,
+                                    void* const* dst, const size_t* dst_pitch, const int64_t* dst_rows, ist_image_desc* out_descs);
+/* phase times of the last ist_stitch_files_png / ist_decode_files_device on this context, in milliseconds (measurement
+ * aid: while on, every phase ends with a stream synchronisation) */
+enum { IST_PHASE_HOST_DECODE = 0, IST_PHASE_PLAN_ARENA = 1, IST_PHASE_ENTROPY_GPU = 2, IST_PHASE_RECONSTRUCT = 3, IST_PHASE_STITCH = 4,
+       IST_PHASE_PNG = 5, IST_PHASE_D2H = 6, IST_PHASE_COUNT = 8 };
+IST_API int ist_ctx_set_timing(ist_ctx* ctx, int on);
+IST_API int ist_ctx_last_timing(ist_ctx* ctx, double* ms, int n);
 
 /* ---- files in, file out: the whole onStitch (decode -> plan -> resample+blit -> PNG export; index.js:1441-1581) ---- */
 /* files[i] = PNG or JPEG file bytes.  Huffman / inflate on host threads (one per image), everything else on the GPU;

@@ -6,7 +6,9 @@
  * function marshals arguments and calls libimagestitch.so.
  *
  *   plan(images, direction, mode, gap, limits)                         -> plan object        (pure CPU)
- *   stitch(images, direction, mode, gap, limits, filter)              -> Promise<{width,height,data}>  (napi_async_work)
+ *   stitch(images, direction, mode, gap, limits, filter, asPng?, devices?, split?) -> Promise<{width,height,data}>  (napi_async_work)
+ *       devices: number[] (devices[0] = root) shards the stitch over several GPUs from this process (ist_stitch_rgba8_multi:
+ *       RCCL gather over xGMI); split 0 = by image (round robin), 1 = by band (equal output rows)
  *   stitchSync(...same...)                                             -> {width,height,data}
  *   render(canvasW, canvasH, clearRGBA, ops, images, filter, region, asPng?) -> Buffer (region pixels, or the PNG file)
  *   encodePng(data, width, height) -> Buffer;  stitch(..., filter, true) resolves {width,height,png}
@@ -206,6 +208,7 @@ typedef struct {
   images_t im;
   int direction, mode, filter; double gap; ist_limits lim;
   int want_png; int64_t png_len;          /* stitchPng: `pixels` holds the PNG file bytes */
+  int devices[64]; int ndev, split;       /* opts.devices / opts.split: ndev 0 = the process-wide single context */
   ist_plan plan; uint8_t* pixels; int rc; char err[256];
   napi_deferred deferred; napi_async_work work;
 } stitch_job;
@@ -232,7 +235,10 @@ static void stitch_execute(napi_env env, void* data) {
   if (!ctx) { j->rc = IST_E_NO_DEVICE; snprintf(j->err, sizeof j->err, "%s", g_ctx_err); return; }
   for (int i = 0; i < j->im.n; i++)
     if (!j->im.data[i]) { j->rc = IST_E_DECODE; snprintf(j->err, sizeof j->err, "\xe5\x9b\xbe\xe7\x89\x87%d\xe8\xa7\xa3\xe7\xa0\x81\xe5\xbc\x82\xe5\xb8\xb8", i); return; }
-  if (j->want_png)
+  if (j->ndev > 0 && !j->want_png)
+    j->rc = ist_stitch_rgba8_multi(j->devices, j->ndev, j->im.descs, j->im.data, j->im.pitch, j->im.n, j->direction, j->mode, j->gap, &j->lim,
+                                   j->filter, j->split, &j->plan, &j->pixels);
+  else if (j->want_png)
     j->rc = ist_stitch_png(ctx, j->im.descs, j->im.data, j->im.pitch, j->im.n, j->direction, j->mode, j->gap, &j->lim,
                            j->filter, &j->plan, &j->pixels, &j->png_len);
   else
@@ -269,7 +275,7 @@ static void stitch_complete(napi_env env, napi_status status, void* data) {
 }
 
 static stitch_job* stitch_parse(napi_env env, napi_callback_info info, int want_refs) {
-  size_t argc = 7; napi_value argv[7];
+  size_t argc = 9; napi_value argv[9];
   if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < 6) {
     napi_throw_type_error(env, NULL, "stitch(images, direction, mode, gap, limits, filter)");
     return NULL;
@@ -283,6 +289,16 @@ static stitch_job* stitch_parse(napi_env env, napi_callback_info info, int want_
   limits_parse(env, argv[4], &j->lim);
   napi_get_value_int32(env, argv[5], &v); j->filter = v;
   if (argc > 6) { bool b = false; napi_get_value_bool(env, argv[6], &b); j->want_png = b ? 1 : 0; }
+  if (argc > 7) {                                       /* devices: number[] */
+    bool is_arr = false; uint32_t n = 0;
+    if (napi_is_array(env, argv[7], &is_arr) == napi_ok && is_arr) {
+      napi_get_array_length(env, argv[7], &n);
+      if (n > 64) { napi_throw_range_error(env, NULL, "devices: at most 64 entries"); images_free(env, &j->im); free(j); return NULL; }
+      for (uint32_t i = 0; i < n; i++) { napi_value e; int32_t d = -1; napi_get_element(env, argv[7], i, &e); napi_get_value_int32(env, e, &d); j->devices[i] = d; }
+      j->ndev = (int)n;
+    }
+  }
+  if (argc > 8) { napi_get_value_int32(env, argv[8], &v); j->split = v; }
   return j;
 }
 

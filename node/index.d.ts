@@ -18,6 +18,8 @@ export interface StitchOptions {
   edgeAA?: boolean;                         // anti-alias fractional rectangle edges (ctx.scale(superSample), unrounded cursor)
   onProgress?: (percent: number) => void;   // stitchProgress checkpoints (index.js:1193-1611)
   pngLevel?: 0 | 1;                         // PNG export form: 0 stored, 1 compressed on the GPU (process-wide once set)
+  devices?: number[];                       // GPUs to shard the stitch over from this process; devices[0] is the root (RCCL gather over xGMI)
+  split?: 'image' | 'band';                 // with devices: image i -> devices[i mod n] (default) | equal output rows per GPU
 }
 export interface PlanRect { image: number; orientation: number; dx: number; dy: number; dw: number; dh: number; }
 export interface StitchPlan {

@@ -14,7 +14,10 @@
  *              (reproduces the phone caps, index.js:1323-1336; default: caps lifted, superSample 1),
  *              maxSide, maxPixels (deviceMaxCanvasSize/Pixels), superSample (MAX_SUPER_SAMPLE, index.js:1363),
  *              onProgress: (percent) => void  (the stitchProgress checkpoints of index.js:1193-1611),
- *              edgeAA: anti-alias fractional rectangle edges by area coverage (default false: pixel-centre rule)}
+ *              edgeAA: anti-alias fractional rectangle edges by area coverage (default false: pixel-centre rule),
+ *              devices: number[] - shard the stitch over these GPUs from this one process (devices[0] = root; parts render
+ *              on their GPUs, one grouped RCCL send/recv batch over xGMI gathers the bands into the root's canvas),
+ *              split: 'image' (image i -> devices[i mod n], the BASELINE layout) | 'band' (equal output rows per GPU)}
  * Errors reject with Error('拼图失败：' + reason) like the reference's catch (index.js:1618-1624); err.code is the
  * C-ABI code.  No pixel arithmetic happens in JavaScript; there is no CPU fallback.
  */
@@ -25,7 +28,8 @@ const DIRECTION = { vertical: 0, horizontal: 1 };
 const MODE = { min: 0, max: 1, original: 2 };
 const FILTER = { nearest: 0, bilinear: 1 };
 const PLATFORM = { other: 0, devtools: 0, windows: 0, mac: 0, ios: 1, android: 2 };
-const KNOWN = ['mode', 'gap', 'filter', 'platform', 'maxSide', 'maxPixels', 'superSample', 'onProgress', 'edgeAA', 'pngLevel'];
+const KNOWN = ['mode', 'gap', 'filter', 'platform', 'maxSide', 'maxPixels', 'superSample', 'onProgress', 'edgeAA', 'pngLevel', 'devices', 'split'];
+const SPLIT = { image: 0, band: 1 };
 const FILTER_EDGE_AA = 0x100;    // IST_FILTER_EDGE_AA: anti-alias fractional rectangle edges by area coverage
 
 function limitsOf(opts) {
@@ -63,13 +67,22 @@ function withProgress(opts, run) {
   return run().then((r) => { cb(90); cb(96); cb(100); return r; }, (e) => { cb(0); throw e; });       // failure resets to 0 (:1622)
 }
 
+// opts.devices -> the trailing (asPng, devices, split) arguments of the native call
+function groupArgs(opts) {
+  const o = opts || {};
+  if (o.devices === undefined || o.devices === null) return [];
+  if (!Array.isArray(o.devices) || !o.devices.length || !o.devices.every((d) => Number.isInteger(d) && d >= 0)) throw new TypeError('devices must be a non-empty array of GPU indices');
+  const split = o.split || 'image';
+  if (!(split in SPLIT)) throw new TypeError('unknown split ' + split);
+  return [false, o.devices, SPLIT[split]];
+}
 function stitch(images, direction, opts) {
   let a;
-  try { a = args(images, direction, opts); } catch (e) { return Promise.reject(e); }
+  try { a = args(images, direction, opts).concat(groupArgs(opts)); } catch (e) { return Promise.reject(e); }
   if (!a[0].length) return Promise.resolve(null);      // `if (!originalImages.length) return;` (index.js:1189): no progress, no error
   return withProgress(opts, () => native.stitch(...a));
 }
-function stitchSync(images, direction, opts) { const a = args(images, direction, opts); return a[0].length ? native.stitchSync(...a) : null; }
+function stitchSync(images, direction, opts) { const a = args(images, direction, opts).concat(groupArgs(opts)); return a[0].length ? native.stitchSync(...a) : null; }
 /** stitch + the reference's export step: resolves {width, height, png: Buffer (a lossless PNG file), plan}. The canvas
  *  never leaves the GPU; only the PNG bytes cross PCIe (utils/canvas.js:205-242, index.js:1577-1579). */
 function stitchPng(images, direction, opts) {
@@ -108,4 +121,4 @@ function plan(images, direction, opts) {
   return native.plan(a[0], a[1], a[2], a[3], a[4]);
 }
 
-module.exports = { stitch, stitchSync, stitchPng, stitchFiles, encodePng, setPngLevel, decodePng, decodeImage, plan, native, DIRECTION, MODE, FILTER, PLATFORM };
+module.exports = { stitch, stitchSync, stitchPng, stitchFiles, encodePng, setPngLevel, decodePng, decodeImage, plan, native, DIRECTION, MODE, FILTER, PLATFORM, SPLIT };

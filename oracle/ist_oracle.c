@@ -388,8 +388,18 @@ static int cv_draw_image(orc_canvas* cv, const uint8_t* img, int img_w, int img_
   /* identity fast path (what BASELINE's uniform configs reduce to): 1:1, no swap, integer offset */
   int identity = !R.swap && R.kx == 1.0 && R.ky == 1.0 && R.ox == floor(R.ox) && R.oy == floor(R.oy);
 
+  /* ... whose rows are contiguous source bytes when no index was clamped: an all-opaque row is then one memcpy (what a
+   * Canvas backend's identity blit does; same bytes as the per-pixel loop below, which is kept for every other row) */
+  const int row_copy = identity && !cv->aa && nX > 0 && xi0[nX - 1] - xi0[0] == nX - 1;
+
   for (int j = 0; j < nY; j++) {
     uint8_t* drow = cv->px + (size_t)(Y0 + j) * cv->pitch + 4 * (size_t)R.X0;
+    if (row_copy) {
+      const uint8_t* srow = img + (size_t)yi0[j] * img_pitch + 4 * (size_t)xi0[0];
+      uint32_t all = 0xFFFFFFFFu;
+      for (int i = 0; i < nX; i++) { uint32_t px; memcpy(&px, srow + 4 * (size_t)i, 4); all &= px; }
+      if ((all >> 24) == 255u) { memcpy(drow, srow, 4 * (size_t)nX); continue; }
+    }
     if (identity || !cv->smoothing) {
       for (int i = 0; i < nX; i++) {
         int ix = !R.swap ? xi0[i] : yi0[j], iy = !R.swap ? yi0[j] : xi0[i];

@@ -53,6 +53,11 @@ def main():
             machine.setdefault(name, {})[cname + "_bytes"] = scale * mean * 1024
     print("\n".join(out))
     if len(sys.argv) > 5:
+        # which kernel + tiling these numbers belong to: bench.py quotes roofline.traffic only when this matches its own hash
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        machine["kernel_source_sha"] = bench.kernel_source_sha()
         json.dump(machine, open(sys.argv[5], "w"), indent=1)
 
 

@@ -102,3 +102,37 @@ def test_job_and_render_need_a_context():
     assert "绘图上下文" in L.last_error()                                                              # index.js:1412
     out, n = C.POINTER(C.c_uint8)(), C.c_int64(0)
     assert L.lib.ist_png_encode_rgba8(None, None, 0, 1, 1, C.byref(out), C.byref(n)) == -4
+
+
+def test_group_entry_points_reject_bad_lists_without_a_device():
+    """ist_group_create / ist_stitch_rgba8_multi (SURVEY 8b `devices`): argument errors come first, then - on a box
+    without a GPU - IST_E_NO_DEVICE; never a crash, never a CPU fallback"""
+    from imagestitching_amd import _lib as L
+    assert not L.lib.ist_group_create(None, 0) and "device list" in L.last_error()
+    devs = (C.c_int * 2)(0, 1)
+    assert not L.lib.ist_group_create(devs, 0)
+    assert not L.lib.ist_group_create(devs, 65)
+    if L.lib.ist_device_count() == 0:
+        assert not L.lib.ist_group_create(devs, 2) and "no HIP device" in L.last_error()
+    assert L.lib.ist_group_slots(None) == 0 and L.lib.ist_group_device(None, 0) == -1
+    plan, out = L.Plan(), C.POINTER(C.c_uint8)()
+    descs = (L.ImageDesc * 1)(L.ImageDesc(4, 4, 1, 0, 0, 0, 0))
+    rc = L.lib.ist_stitch_rgba8_multi(None, 0, descs, None, None, 1, 0, 0, 0.0, None, 1, 0, C.byref(plan), C.byref(out))
+    assert rc == -1
+
+
+def test_shard_parts_is_pure_cpu_and_checks_its_arguments():
+    import imagestitching_amd as ist
+    from imagestitching_amd import _lib as L
+    p = ist.plan([{"width": 40, "height": 30}] * 3, "vertical")
+    ops, n = p.ops()
+    arr, cnt = (L.Part * 16)(), C.c_int(0)
+    assert L.lib.ist_shard_parts(ops, n, p.canvas_w, p.canvas_h, p._descs, 3, 1, 2, 0, arr, 16, C.byref(cnt)) == 0 and cnt.value == 3
+    assert [arr[k].slot for k in range(3)] == [0, 1, 0]
+    assert L.lib.ist_shard_parts(ops, n, p.canvas_w, p.canvas_h, p._descs, 3, 1, 0, 0, arr, 16, C.byref(cnt)) == -1      # no slots
+    assert L.lib.ist_shard_parts(ops, n, p.canvas_w, p.canvas_h, p._descs, 3, 1, 2, 7, arr, 16, C.byref(cnt)) == -1      # unknown split
+    assert L.lib.ist_shard_parts(ops, n, p.canvas_w, p.canvas_h, p._descs, 3, 1, 2, 0, arr, 2, C.byref(cnt)) == -1       # table too small
+    assert L.lib.ist_shard_parts(ops, n, p.canvas_w, p.canvas_h, p._descs, 3, 1, 3, 1, arr, 16, C.byref(cnt)) == 0
+    rows = sorted((arr[k].Y0, arr[k].Y1, arr[k].slot) for k in range(cnt.value))
+    assert rows[0][0] == 0 and rows[-1][1] == 90 and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    assert [r[2] for r in rows] == sorted(r[2] for r in rows)            # canvas order = slot order

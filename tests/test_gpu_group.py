@@ -1,0 +1,118 @@
+"""The single-process device group (ist_group_*, include/imagestitch.h): stitch(images, direction, {devices}) from one
+process - what the N-API host binds (`devices`).  A one-GPU box exercises everything but the
+cross-device transfer: a device listed several times serves several slots (their bands render straight into the
+canvas), and the tuning knob IST_GROUP_SELF_SEND=1 routes those bands through ncclSend/ncclRecv to the same rank, so
+the RCCL binding itself (dlopen, communicator, grouped batch, in-place and staged receives) runs here too."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import imagestitching_amd as ist
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(403, 302), (302, 403), (400, 300), (192, 108), (640, 480)]
+
+
+@pytest.mark.parametrize("devices,split", [([0], "image"), ([0, 0], "image"), ([0, 0], "band"), ([0, 0, 0, 0, 0], "band"), ([0] * 8, "image")])
+@pytest.mark.parametrize("direction,opts", [
+    ("vertical", {"filter": "bilinear", "mode": "max", "gap": 3}),
+    ("horizontal", {"filter": "nearest", "mode": "min", "gap": 0}),
+    ("vertical", {"filter": "bilinear", "mode": "original", "gap": 5}),
+])
+def test_host_path_on_a_device_list_matches_the_single_device_result(devices, split, direction, opts):
+    px = [U.rand_image(800 + i, h, w, opaque=(i != 1)) for i, (w, h) in enumerate(SIZES)]
+    one = ist.stitch(px, direction, opts)
+    many = ist.stitch(px, direction, dict(opts, devices=devices, split=split))
+    assert (many["width"], many["height"]) == (one["width"], one["height"])
+    assert np.array_equal(many["data"], one["data"])           # same kernels, same arithmetic: bit-identical
+    ref, _, _ = U.oracle_stitch(px, direction, opts)
+    assert U.max_abs_diff(many["data"], ref) <= (0 if opts["filter"] == "nearest" else 1)
+
+
+def test_device_resident_group_job_with_partial_holdings():
+    """ist_group_job_launch: one pointer per part; a slot holds only the source rows its band samples"""
+    import torch
+    px = [U.rand_image(820 + i, h, w) for i, (w, h) in enumerate(SIZES)]
+    g = ist.StitchGroup([0, 0, 0])
+    job = g.compile(U.hip_images(px), "vertical", {"filter": "bilinear", "mode": "max", "split": "band"})
+    assert {p["slot"] for p in job.parts} == {0, 1, 2} and all(p["device"] == 0 for p in job.parts)
+    full = [torch.from_numpy(a).cuda() for a in px]
+    srcs = []
+    for p in job.parts:
+        a, b = p["rows"]
+        t = full[p["image"]]
+        hold = torch.empty((b - a + 1, t.shape[1], 4), dtype=torch.uint8, device="cuda")[:b - a]
+        hold.copy_(t[a:b])
+        srcs.append((hold, a))
+    out = torch.full((job.plan.canvas_h, job.plan.canvas_w, 4), 0x5A, dtype=torch.uint8, device="cuda")
+    job.launch(srcs, out)
+    g.sync()
+    ref, _, _ = U.oracle_stitch(px, "vertical", {"filter": "bilinear", "mode": "max"})
+    assert U.max_abs_diff(out.cpu().numpy(), ref) <= 1
+
+
+def test_full_size_nine_photos_on_eight_slots_of_one_gpu():
+    """BASELINE configs[3] geometry through the C-ABI group: 9 x 4032x3024, devices = [0]*8, both splits, both directions"""
+    import torch
+    srcs = [torch.empty((3024, 4032, 4), dtype=torch.uint8, device="cuda").random_(0, 256) for _ in range(9)]
+    for t in srcs:
+        t[..., 3] = 255
+    g = ist.StitchGroup([0] * 8)
+    imgs = [{"width": 4032, "height": 3024, "opaque": True}] * 9
+    for direction, dim in (("vertical", 0), ("horizontal", 1)):
+        for split in ("image", "band"):
+            job = g.compile(imgs, direction, {"filter": "bilinear", "split": split})
+            out = torch.full((job.plan.canvas_h, job.plan.canvas_w, 4), 0x5A, dtype=torch.uint8, device="cuda")
+            job.launch([srcs[p["image"]] for p in job.parts], out)
+            g.sync()
+            assert torch.equal(out, torch.cat(srcs, dim)), (direction, split)
+            job.close()
+
+
+def test_bad_device_lists_are_refused():
+    with pytest.raises(ist.StitchError):
+        ist.StitchGroup([0, 99])
+    with pytest.raises(ist.StitchError):
+        ist.StitchGroup([-1])
+    px = [U.rand_image(830, 8, 8)]
+    with pytest.raises(ist.StitchError):
+        ist.stitch(px, "vertical", {"devices": [0, 4096]})
+
+
+def test_edge_antialiased_plans_are_refused_by_a_group_and_fine_on_one_device():
+    px = [U.rand_image(840 + i, 48, 64) for i in range(3)]
+    opts = {"platform": "ios", "edgeAA": True}                  # superSample 2.2: fractional seams
+    ist.stitch(px, "vertical", opts)
+    with pytest.raises(ist.StitchError) as e:
+        ist.stitch(px, "vertical", dict(opts, devices=[0, 0]))
+    assert e.value.code == -7
+
+
+def test_rccl_binding_through_self_send():
+    """IST_TUNING=1 IST_GROUP_SELF_SEND=1: bands of same-device slots are rendered into band buffers and travel through
+    ncclSend / ncclRecv (rank 0 -> rank 0) inside one ncclGroupStart/End: in-place receives (vertical) and staged
+    receives + placement launches (horizontal).  Run in a child process (knobs are read only by a process started in
+    tuning mode)."""
+    code = """
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import imagestitching_amd as ist
+from tests import util as U
+px = [U.rand_image(850 + i, h, w) for i, (w, h) in enumerate(%r)]
+for direction in ("vertical", "horizontal"):
+    for split in ("image", "band"):
+        opts = {"filter": "bilinear", "mode": "max", "gap": 2}
+        one = ist.stitch(px, direction, opts)
+        many = ist.stitch(px, direction, dict(opts, devices=[0, 0, 0], split=split))
+        assert np.array_equal(many["data"], one["data"]), (direction, split)
+print("self send ok")
+""" % (U.ROOT, SIZES)
+    env = dict(os.environ, IST_TUNING="1", IST_GROUP_SELF_SEND="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "self send ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -41,12 +41,19 @@ def test_tall_narrow_png_encode_from_a_heap_block():
 
 
 def test_rows_longer_than_one_staging_chunk_and_sizes_around_the_chunk_boundaries():
-    """a staging chunk is 4 MiB: rows of 4 MiB + 4 bytes are carried in column segments; totals of chunk +- one row
-    exercise the piece arithmetic on both sides"""
-    for w, h in ((1048577, 2), (1024, 1023), (1024, 1024), (1024, 1025), (1024, 4097)):
+    """a staging chunk is 4 MiB: totals of chunk +- one row exercise the piece arithmetic on both sides; a row of exactly
+    one chunk (1048576 px, the widest canvas the lifted limits plan) is one piece per row; rows LONGER than a chunk are
+    carried in column segments (only reachable through the PNG encoder: the planner caps canvases at 1048576 px)"""
+    from PIL import Image
+    for w, h in ((1048576, 2), (1024, 1023), (1024, 1024), (1024, 1025), (1024, 4097)):
         px = [U.rand_image(520 + h % 7, h, w), U.rand_image(530, 1, w)]
         got = ist.stitch(px, "vertical", {"filter": "nearest"})
         assert np.array_equal(got["data"], np.concatenate(px, 0)), (w, h)
+    a = U.rand_image(531, 2, 1048577 + 300, opaque=False)
+    Image.MAX_IMAGE_PIXELS = None
+    for src in (a, a[:, 150:150 + 1048577]):                         # contiguous and pitched
+        png = ist.encode_png(src, level=0)
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(png)).convert("RGBA")), src)
 
 
 def test_region_readback_is_compact_and_exact():

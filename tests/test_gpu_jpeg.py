@@ -279,3 +279,43 @@ def test_sixty_four_files_in_one_call(tmp_path):
         paths.append(str(p)); bitmaps.append(_pil(p.read_bytes()))
     res = ist.stitch_files(paths, "vertical", {"filter": "nearest"})
     assert np.array_equal(ist.decode_png(res["png"]), np.concatenate(bitmaps, 0))
+
+
+def test_decode_files_into_device_memory_matches_pil_and_reports_phases(tmp_path):
+    """ist_decode_files_device: files -> bitmaps in caller-owned HBM (baseline JPEG on the GPU, progressive JPEG / PNG / BMP
+    on host threads), bit-exact vs PIL; the context reports the phase times of the call"""
+    import torch
+    rng = np.random.default_rng(31)
+    blobs, want = [], []
+    for k, (fmt, kw, size) in enumerate([("JPEG", {"quality": 88, "subsampling": 2}, (203, 317)), ("JPEG", {"quality": 75, "subsampling": 0}, (64, 64)),
+                                         ("JPEG", {"progressive": True, "subsampling": 1}, (131, 97)), ("PNG", {}, (50, 77)), ("BMP", {}, (33, 18))]):
+        h, w = size
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = np.stack([(xx * 3 + yy + 10 * k) % 256, (yy * 2 + 5 * k) % 256, (xx + yy * 2) % 256], -1) + rng.integers(-15, 15, (h, w, 3))
+        im = Image.fromarray(a.clip(0, 255).astype(np.uint8), "RGB")
+        b = io.BytesIO()
+        im.save(b, fmt, **kw)
+        blobs.append(b.getvalue())
+        want.append(np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGBA")))
+    ist.set_phase_timing(True)
+    try:
+        out, imgs = ist.decode_files_device(blobs)
+        times = ist.last_phase_times()
+    finally:
+        ist.set_phase_timing(False)
+    assert [(i["width"], i["height"]) for i in imgs] == [(a.shape[1], a.shape[0]) for a in want]
+    assert [i["opaque"] for i in imgs] == [True, True, True, False, False]
+    for t, a in zip(out, want):
+        assert np.array_equal(t.cpu().numpy(), a)
+    assert times["host_decode"] > 0 and times["entropy_gpu"] > 0 and times["reconstruct"] > 0 and times["png"] == 0
+    # into pitched, caller-allocated buffers
+    wide = [torch.zeros((a.shape[0] + 2, a.shape[1] + 5, 4), dtype=torch.uint8, device="cuda") for a in want]
+    views = [t[1:1 + a.shape[0], 2:2 + a.shape[1]] for t, a in zip(wide, want)]
+    ist.decode_files_device(blobs, out=views)
+    for t, v, a in zip(wide, views, want):
+        assert np.array_equal(v.cpu().numpy(), a)
+        assert int(t[0].max()) == 0 and int(t[-1].max()) == 0 and int(t[:, :2].max()) == 0
+    # a buffer that is too small for what the file's header announces is refused
+    small = [torch.zeros((a.shape[0] - 1, a.shape[1], 4), dtype=torch.uint8, device="cuda") for a in want]
+    with pytest.raises(ist.StitchError):
+        ist.decode_files_device(blobs, out=small)

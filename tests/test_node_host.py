@@ -169,6 +169,36 @@ def test_node_png_export(tmp_path):
 
 
 @needs_node
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,split", [([0], "image"), ([0, 0, 0], "image"), ([0, 0], "band")])
+def test_node_stitch_on_a_device_list(devices, split, tmp_path):
+    """opts.devices: the Node host shards the stitch over a device list through ist_stitch_rgba8_multi; on a
+    one-GPU box the listed device serves every slot and the result is the single-device result, bit for bit"""
+    px = [U.rand_image(160, 48, 64), U.smooth_image(161, 80, 50), U.rand_image(162, 33, 77, opaque=False), U.rand_image(163, 40, 64)]
+    imgs = _write_images(px, tmp_path)
+    opts = {"filter": "bilinear", "mode": "max", "gap": 3}
+    for direction in ("vertical", "horizontal"):
+        rc, out, err = _cli({"mode": "stitch", "direction": direction, "opts": dict(opts, devices=devices, split=split), "images": imgs, "out": str(tmp_path / "m.rgba")}, tmp_path)
+        assert rc == 0, err
+        rc, one, err = _cli({"mode": "stitch", "direction": direction, "opts": opts, "images": imgs, "out": str(tmp_path / "o.rgba")}, tmp_path)
+        assert rc == 0, err
+        assert (out["width"], out["height"]) == (one["width"], one["height"])
+        assert np.array_equal(np.fromfile(tmp_path / "m.rgba", np.uint8), np.fromfile(tmp_path / "o.rgba", np.uint8))
+        ref, _, _ = U.oracle_stitch(px, direction, opts)
+        assert U.max_abs_diff(np.fromfile(tmp_path / "m.rgba", np.uint8).reshape(ref.shape), ref) <= 1
+
+
+@needs_node
+def test_node_device_list_validation():
+    code = ("const api=require('%s/node/index.js'); let bad=0;"
+            "for (const o of [{devices:[]},{devices:'0'},{devices:[0.5]},{devices:[-1]},{devices:[0],split:'diagonal'}])"
+            "{ try{api.stitchSync([{width:1,height:1,data:new Uint8Array(4)}],'vertical',o)}catch(e){ if (e instanceof TypeError) bad++ } }"
+            "console.log(JSON.stringify({bad}));") % ROOT
+    out = subprocess.run([NODE, "-e", code], capture_output=True, text=True, timeout=60)
+    assert json.loads(out.stdout.strip().splitlines()[-1])["bad"] == 5, out.stdout + out.stderr
+
+
+@needs_node
 def test_node_progress_checkpoints_and_option_validation():
     code = ("const api=require('%s/node/index.js'); const seen=[];"
             "let bad=0; try{api.plan([],'diagonal')}catch(e){bad++} try{api.plan([],'vertical',{bogus:1})}catch(e){bad++}"
