@@ -120,11 +120,12 @@ static int64_t distinct_taps(double k, double o, int lo, int hi, int clo, int ch
 // Shape of a compiled job.  Production compiles use the constants below (the measured optima on MI355X) and touch
 // neither the environment nor any mutable global, so jobs can be compiled concurrently on any number of threads.  A
 // process started with IST_TUNING=1 (tools/sweep_*.py, tools/exp_*.py: single-threaded benchmarks) re-reads the knobs at
-// every compile: IST_COPY_TILE=WxH (W = 256, 512, ...), IST_LDS_BUDGET (bytes), IST_LDS_RUN, IST_NO_LDS, IST_NO_BANDS,
+// every compile: IST_COPY_TILE=WxH (W = 256, 512, ...), IST_LDS_BUDGET (bytes), IST_LDS_RUN, IST_LDS_TILE_W, IST_NO_LDS, IST_NO_BANDS,
 // IST_NO_TILE_TABLE.
 struct CompileKnobs {
   int tile_w = 256, tile_h = 8;        // FILL / COPY: ~64 KB of loads in flight per CU
   int lds_run = 2;                     // pipeline stages per workgroup on the SAMPLE_LDS path
+  int lds_tile_w = 0;                  // 0: pick 256 / 128 / 64 per cell; IST_LDS_TILE_W pins one width
   int64_t lds_budget_words = 6144;     // 24 KiB footprint budget per workgroup
   bool no_lds = false, no_bands = false, no_tile_table = false;
 };
@@ -140,6 +141,7 @@ static CompileKnobs read_knobs() {
   if (e && std::sscanf(e, "%dx%d", &w, &h) == 2 && w >= 256 && (w & (w - 1)) == 0 && h >= 1 && h <= 4096) { k.tile_w = w; k.tile_h = h; }
   if ((e = std::getenv("IST_LDS_BUDGET")) != nullptr) k.lds_budget_words = std::max<int64_t>(256, std::atoll(e) / 4);
   if ((e = std::getenv("IST_LDS_RUN")) != nullptr) k.lds_run = std::min(16, std::max(1, std::atoi(e)));
+  if ((e = std::getenv("IST_LDS_TILE_W")) != nullptr) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) k.lds_tile_w = v; }
   k.no_lds = std::getenv("IST_NO_LDS") != nullptr;
   k.no_bands = std::getenv("IST_NO_BANDS") != nullptr;
   k.no_tile_table = std::getenv("IST_NO_TILE_TABLE") != nullptr;
@@ -318,17 +320,24 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
       const double akx = std::fabs(r.kx), aky = std::fabs(r.ky);
       const int64_t budget = knobs.lds_budget_words;
       if (r.cx1 > r.cx0 && r.cy1 > r.cy0 && akx <= 4.0 && aky <= 8.0) {
-        const int64_t wl = (static_cast<int64_t>(std::floor(255.0 * akx)) + 3 + 3) & ~3LL;      // pixels per LDS row
-        int th = 0; int64_t need = 0;
-        for (int t = 32; t >= 4; t -= 4) {
-          const int64_t fh = static_cast<int64_t>(std::floor((t - 1) * aky)) + 3;
-          if (wl * fh <= budget) { th = t; need = wl * fh; break; }
+        // tile shape: 64 * NP pixels wide (NP = 4, 2, 1 per lane and row) x th rows per stage, whichever carries the most
+        // output pixels in one footprint of `budget` words; ties go to the wider tile (longer contiguous row segments)
+        int best_w = 0, best_h = 0; int64_t best_need = 0;
+        const int w_lo = knobs.lds_tile_w ? knobs.lds_tile_w : 64, w_hi = knobs.lds_tile_w ? knobs.lds_tile_w : 256;
+        for (int tw = w_hi; tw >= w_lo; tw >>= 1) {
+          const int64_t wl = (static_cast<int64_t>(std::floor((tw - 1) * akx)) + 3 + 3) & ~3LL;    // pixels per LDS row
+          for (int t = 32; t >= 4; t -= 4) {
+            const int64_t fh = static_cast<int64_t>(std::floor((t - 1) * aky)) + 3;
+            if (wl * fh > budget) continue;
+            if (static_cast<int64_t>(tw) * t > static_cast<int64_t>(best_w) * best_h) { best_w = tw; best_h = t; best_need = wl * fh; }
+            break;                                  // the tallest stage of this width
+          }
         }
-        if (th) {
-          // a workgroup walks `run` stages down its 256-pixel column (see tile_sample_lds)
+        if (best_h) {
+          // a workgroup walks `run` stages down its column (see tile_sample_lds)
           const int run = knobs.lds_run;
-          cell.path = PATH_SAMPLE_LDS; cell.tile_w = 256; cell.sub_h = th; cell.tile_h = th * run;
-          out->lds_half = std::max<int32_t>(out->lds_half, static_cast<int32_t>(need));
+          cell.path = PATH_SAMPLE_LDS; cell.tile_w = best_w; cell.sub_h = best_h; cell.tile_h = best_h * run;
+          out->lds_half = std::max<int32_t>(out->lds_half, static_cast<int32_t>(best_need));
           out->lds_words = std::max<int32_t>(out->lds_words, out->lds_half);
         }
       }

@@ -90,6 +90,31 @@ IST_DEV void bilerp4_opaque(const uint32_t p00[4], const uint32_t p01[4], const 
   }
 }
 
+// the same for the narrower SAMPLE_LDS tiles (NP = 1 or 2 pixels per lane and row): identical IEEE operations per channel
+template <int NP>
+IST_DEV void bilerpN_opaque(const uint32_t p00[NP], const uint32_t p01[NP], const uint32_t p10[NP], const uint32_t p11[NP],
+                            const float tx[NP], float ty, uint32_t o[NP]) {
+  if constexpr (NP == 4) { bilerp4_opaque(p00, p01, p10, p11, tx, ty, o); return; }
+  const f32x2 ty2 = {ty, ty}, half = {0.5f, 0.5f};
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {                  // red + green of pixel p
+    const f32x2 t = {tx[p], tx[p]};
+    const f32x2 v = lerp2(lerp2(rg(p00[p]), rg(p01[p]), t), lerp2(rg(p10[p]), rg(p11[p]), t), ty2) + half;
+    o[p] = 0xFF000000u | static_cast<uint32_t>(v.x) | (static_cast<uint32_t>(v.y) << 8);
+  }
+  if constexpr (NP == 2) {                        // blue of both pixels in one packed chain
+    const f32x2 t = {tx[0], tx[1]};
+    const f32x2 v = lerp2(lerp2(chan2(p00[0], p00[1], 2), chan2(p01[0], p01[1], 2), t),
+                          lerp2(chan2(p10[0], p10[1], 2), chan2(p11[0], p11[1], 2), t), ty2) + half;
+    o[0] |= static_cast<uint32_t>(v.x) << 16;
+    o[1] |= static_cast<uint32_t>(v.y) << 16;
+  } else {
+    const float top = lerpf(static_cast<float>(ch(p00[0], 2)), static_cast<float>(ch(p01[0], 2)), tx[0]);
+    const float bot = lerpf(static_cast<float>(ch(p10[0], 2)), static_cast<float>(ch(p11[0], 2)), tx[0]);
+    o[0] |= to_u8(lerpf(top, bot, ty)) << 16;
+  }
+}
+
 // bilinear blend of four straight-alpha taps, composited over a premultiplied destination pixel
 // `opaque` (wave-uniform, the caller's hint for JPEG-decoded bitmaps) skips the per-pixel alpha test
 IST_DEV uint32_t bilerp_over(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, float tx, float ty, uint32_t d, bool opaque = false) {
@@ -320,7 +345,12 @@ IST_DEV Tap row_tap(const RowTaps& r, int j) {
 // The footprint buffer is dynamic LDS sized by the host (LaunchArgs.lds_half words = the largest footprint any stage
 // of any cell needs).
 
-IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int X0, int Y0, int X1, int Y1, int sub_h, uint32_t* lds) {
+// NP = pixels per lane and row: the tile is 64 * NP pixels wide.  The host picks the width per cell (ist_compile.cpp): a
+// strong shrink has a tall footprint per output row, and a narrower, taller tile then carries more output pixels per
+// 24 KiB of footprint (kx = ky = 1.87: 128 x 12 instead of 256 x 4) and re-reads fewer halo rows.
+// fresh: the workgroup has not touched LDS yet (one tile per workgroup), so the first stage needs no leading barrier.
+template <int NP>
+IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int X0, int Y0, int X1, int Y1, int sub_h, uint32_t* lds, bool fresh) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   // The tile is a column of stages of sub_h rows, each loaded (LDS-DMA, no VGPRs) and then resampled: the per-tile
@@ -387,9 +417,9 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
   // last column) and only skip their stores: the row taps below are exchanged with v_readlane and the barriers of
   // later stages need every wave.
   const int Xl = X0 + lane;
-  int lx[4]; float wx[4];
+  int lx[NP]; float wx[NP];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const Tap t = bilinear_tap(op.kx, op.ox, min(Xl + 64 * p, X1 - 1), op.cx0, op.cx1);
     lx[p] = t.base - fx0; wx[p] = t.t;
   }
@@ -398,7 +428,7 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
   int fy0, fh;
   foot(0, &fy0, &fh);
   for (int s = 0; s < nsub; ++s) {
-    __syncthreads();                                      // every wave is done reading the previous stage (or tile)
+    if (s > 0 || !fresh) __syncthreads();                 // every wave is done reading the previous stage (or tile)
     stage(fy0, fh, lds);
     int ny0 = 0, nh = 0;
     if (s + 1 < nsub) foot(s + 1, &ny0, &nh);             // (tap arithmetic under the loads)
@@ -411,21 +441,21 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
       const Tap ty = row_tap(rows, Y - Ya);
       const uint32_t* r0 = buf + (ty.base - fy0) * wl;
       const uint32_t* r1 = r0 + wl;
-      uint32_t o[4];
-      uint32_t p00[4], p01[4], p10[4], p11[4];
+      uint32_t o[NP];
+      uint32_t p00[NP], p01[NP], p10[NP], p11[NP];
 #pragma unroll
-      for (int p = 0; p < 4; ++p) { p00[p] = r0[lx[p]]; p01[p] = r0[lx[p] + 1]; p10[p] = r1[lx[p]]; p11[p] = r1[lx[p] + 1]; }
+      for (int p = 0; p < NP; ++p) { p00[p] = r0[lx[p]]; p01[p] = r0[lx[p] + 1]; p10[p] = r1[lx[p]]; p11[p] = r1[lx[p] + 1]; }
       uint32_t all = 0xFFFFFFFFu;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) all &= p00[p] & p01[p] & p10[p] & p11[p];
-      if (opaque || (all >> 24) == 255u) bilerp4_opaque(p00, p01, p10, p11, wx, ty.t, o);
+      for (int p = 0; p < NP; ++p) all &= p00[p] & p01[p] & p10[p] & p11[p];
+      if (opaque || (all >> 24) == 255u) bilerpN_opaque<NP>(p00, p01, p10, p11, wx, ty.t, o);
       else {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) o[p] = bilerp_over(p00[p], p01[p], p10[p], p11[p], wx[p], ty.t, bg, false);
+        for (int p = 0; p < NP; ++p) o[p] = bilerp_over(p00[p], p01[p], p10[p], p11[p], wx[p], ty.t, bg, false);
       }
       uint8_t* dp = d + static_cast<size_t>(Y) * A.dst_pitch;
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int p = 0; p < NP; ++p)
         if (Xl + 64 * p < X1) st4(dp + 256 * p, o[p]);
     }
     fy0 = ny0; fh = nh;
@@ -604,7 +634,7 @@ IST_DEV void tile_general(const LaunchArgs& A, const DevCell c, int X0, int Y0, 
 enum : int { HAS_FILL = 1, HAS_COPY = 2, HAS_SAMPLE = 4, HAS_GENERAL = 8 };
 
 template <int PATHS, int V>
-IST_DEV void run_tile(const LaunchArgs& A, int64_t tile) {
+IST_DEV void run_tile(const LaunchArgs& A, int64_t tile, bool fresh) {
   int ci, oi, X0, Y0;
   if (A.tiles) {                       // one 16-byte scalar load; the cell and the op are then fetched side by side
     const DevTile t = A.tiles[tile];
@@ -633,7 +663,7 @@ IST_DEV void run_tile(const LaunchArgs& A, int64_t tile) {
   DevOp op_;                           // fetched together with the cell (both indices come from the tile entry)
   if (oi >= 0) op_ = A.ops[oi]; else __builtin_memset(&op_, 0, sizeof(op_));
   const int X1 = min(X0 + c.tile_w, c.X1), Y1 = min(Y0 + c.tile_h, c.Y1);
-  const int lg = 31 - __builtin_clz(c.tile_w >> 8);
+  const int lg = c.tile_w >= 256 ? 31 - __builtin_clz(c.tile_w >> 8) : 0;       // FILL / COPY tiles are 256 << lg wide
   const int path = c.path;
   if ((PATHS & HAS_COPY) && path == PATH_COPY) {
     const DevOp op = op_;
@@ -646,7 +676,9 @@ IST_DEV void run_tile(const LaunchArgs& A, int64_t tile) {
     tile_fill(A, c.bg, lg, X0, Y0, X1, Y1);
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE_LDS) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    tile_sample_lds(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds);
+    if (c.tile_w == 256) tile_sample_lds<4>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
+    else if (c.tile_w == 128) tile_sample_lds<2>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
+    else tile_sample_lds<1>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SWAP_LDS) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (!tile_swap_lds(A, op_, c.bg, X0, Y0, X1, Y1, lds)) tile_general(A, c, X0, Y0, X1, Y1);
@@ -663,9 +695,9 @@ IST_DEV void run_tile(const LaunchArgs& A, int64_t tile) {
 template <int PATHS, int V, bool PERSIST>
 __global__ __launch_bounds__(256) void ist_stitch_kernel(const LaunchArgs A, const int64_t n_tiles) {
   if (PERSIST) {
-    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) run_tile<PATHS, V>(A, t);
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) run_tile<PATHS, V>(A, t, false);
   } else {
-    run_tile<PATHS, V>(A, static_cast<int64_t>(blockIdx.x));
+    run_tile<PATHS, V>(A, static_cast<int64_t>(blockIdx.x), true);
   }
 }
 

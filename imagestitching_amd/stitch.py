@@ -498,7 +498,12 @@ class GroupJob:
 
     def launch(self, part_srcs, out):
         """part_srcs[k]: HxWx4 uint8 CUDA tensor on parts[k]['device'] holding the WHOLE image, or (tensor, first_row) for a
-        partial holding (rows first_row ... ; one spare row behind the last must be readable).  out: canvas on the root."""
+        partial holding (rows first_row ... ; one spare row behind the last must be readable).  out: canvas on the root.
+        The group's streams do not synchronise with the caller's: work the caller queued on these buffers (uploads, fills) is
+        waited for here, on each tensor's current torch stream."""
+        import torch
+        for dev in {(s[0] if isinstance(s, tuple) else s).device for s in part_srcs} | {out.device}:
+            torch.cuda.current_stream(dev).synchronize()
         n = len(self.parts)
         ptrs, pitches = (C.c_void_p * n)(), (C.c_size_t * n)()
         for k, s in enumerate(part_srcs):

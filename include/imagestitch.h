@@ -220,7 +220,8 @@ IST_API void ist_group_job_destroy(ist_group_job* job);
 IST_API int ist_group_job_parts(const ist_group_job* job, ist_part* parts, int max_parts, int* n_parts);
 /* src[k] / src_pitch[k] belong to PART k: the address, on the part's device, of row 0 of the part's image (a holder of rows
  * [sy0, sy1) only passes the address of row sy0 minus sy0 * pitch; 16 bytes behind its last row must be readable).
- * dst: the canvas on the root's device, dst_pitch == canvas_w * 4.  Asynchronous: ist_group_sync waits for the canvas. */
+ * dst: the canvas on the root's device, dst_pitch == canvas_w * 4.  Asynchronous: ist_group_sync waits for the canvas.
+ * The group runs on its own streams: whatever the caller queued on these buffers must have completed before the call. */
 IST_API int ist_group_job_launch(ist_group_job* job, const void* const* src, const size_t* src_pitch, int n_parts, void* dst,
                                  size_t dst_pitch);
 IST_API int ist_group_sync(ist_group* g);
