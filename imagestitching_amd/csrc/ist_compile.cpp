@@ -120,14 +120,14 @@ static int64_t distinct_taps(double k, double o, int lo, int hi, int clo, int ch
 // Shape of a compiled job.  Production compiles use the constants below (the measured optima on MI355X) and touch
 // neither the environment nor any mutable global, so jobs can be compiled concurrently on any number of threads.  A
 // process started with IST_TUNING=1 (tools/sweep_*.py, tools/exp_*.py: single-threaded benchmarks) re-reads the knobs at
-// every compile: IST_COPY_TILE=WxH (W = 256, 512, ...), IST_LDS_BUDGET (bytes), IST_LDS_RUN, IST_LDS_TILE_W, IST_NO_LDS, IST_NO_BANDS,
+// every compile: IST_COPY_TILE=WxH (W = 256, 512, ...), IST_LDS_BUDGET (bytes), IST_LDS_RUN, IST_LDS_TILE_W, IST_NO_LDS, IST_NO_BANDS, IST_NO_SORT,
 // IST_NO_TILE_TABLE.
 struct CompileKnobs {
   int tile_w = 256, tile_h = 8;        // FILL / COPY: ~64 KB of loads in flight per CU
   int lds_run = 2;                     // pipeline stages per workgroup on the SAMPLE_LDS path
   int lds_tile_w = 0;                  // 0: pick 256 / 128 / 64 per cell; IST_LDS_TILE_W pins one width
   int64_t lds_budget_words = 6144;     // 24 KiB footprint budget per workgroup
-  bool no_lds = false, no_bands = false, no_tile_table = false;
+  bool no_lds = false, no_bands = false, no_tile_table = false, no_sort = false;
 };
 bool tuning_mode() {
   static const bool on = [] { const char* e = std::getenv("IST_TUNING"); return e && *e && std::strcmp(e, "0") != 0; }();
@@ -145,6 +145,7 @@ static CompileKnobs read_knobs() {
   k.no_lds = std::getenv("IST_NO_LDS") != nullptr;
   k.no_bands = std::getenv("IST_NO_BANDS") != nullptr;
   k.no_tile_table = std::getenv("IST_NO_TILE_TABLE") != nullptr;
+  k.no_sort = std::getenv("IST_NO_SORT") != nullptr;
   return k;
 }
 
@@ -159,7 +160,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
   const CompileKnobs knobs = read_knobs();
   out->canvas_w = canvas_w; out->canvas_h = canvas_h; out->filter = filter | (aa ? IST_FILTER_EDGE_AA : 0);
   out->ops.clear(); out->cells.clear(); out->stacks.clear(); out->bands.clear(); out->tiles.clear();
-  out->lds_words = 0; out->lds_half = 0;
+  out->lds_words = 0; out->lds_half = 0; out->kernel_kind = 0;
   out->img_w.assign(static_cast<size_t>(n_images), 0);
   out->img_h.assign(static_cast<size_t>(n_images), 0);
   for (int i = 0; i < n_images; ++i) {
@@ -320,16 +321,18 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
       const double akx = std::fabs(r.kx), aky = std::fabs(r.ky);
       const int64_t budget = knobs.lds_budget_words;
       if (r.cx1 > r.cx0 && r.cy1 > r.cy0 && akx <= 4.0 && aky <= 8.0) {
-        // tile shape: 64 * NP pixels wide (NP = 4, 2, 1 per lane and row) x th rows per stage, whichever carries the most
-        // output pixels in one footprint of `budget` words; ties go to the wider tile (longer contiguous row segments)
+        // tile shape: 256 pixels wide (4 per lane and row) whenever a stage of at least 4 rows fits the budget: measured on
+        // MI355X (tools/sweep_resample.py) the wide tile wins even where a 128-wide one would carry more output pixels per
+        // footprint (mixed horizontal strip, kx = ky = 1.87: 125 us against 137 us).  Narrower tiles (2 or 1 pixel per lane)
+        // only take the scales where the wide one does not fit at all (|k| from about 2.3 to 4).
         int best_w = 0, best_h = 0; int64_t best_need = 0;
         const int w_lo = knobs.lds_tile_w ? knobs.lds_tile_w : 64, w_hi = knobs.lds_tile_w ? knobs.lds_tile_w : 256;
-        for (int tw = w_hi; tw >= w_lo; tw >>= 1) {
+        for (int tw = w_hi; tw >= w_lo && !best_h; tw >>= 1) {
           const int64_t wl = (static_cast<int64_t>(std::floor((tw - 1) * akx)) + 3 + 3) & ~3LL;    // pixels per LDS row
           for (int t = 32; t >= 4; t -= 4) {
             const int64_t fh = static_cast<int64_t>(std::floor((t - 1) * aky)) + 3;
             if (wl * fh > budget) continue;
-            if (static_cast<int64_t>(tw) * t > static_cast<int64_t>(best_w) * best_h) { best_w = tw; best_h = t; best_need = wl * fh; }
+            best_w = tw; best_h = t; best_need = wl * fh;
             break;                                  // the tallest stage of this width
           }
         }
@@ -367,6 +370,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     cell.tile_begin = tiles;
     tiles += nt;
     info.out_pixels += w * h;
+    out->kernel_kind = std::max<int32_t>(out->kernel_kind, (cell.path == PATH_FILL || cell.path == PATH_COPY) ? 0 : (cell.path == PATH_SAMPLE || cell.path == PATH_SAMPLE_LDS) ? 1 : 2);
     switch (cell.path) {
       case PATH_FILL: info.tiles_fill += nt; break;
       case PATH_COPY: info.tiles_copy += nt; break;
@@ -384,6 +388,25 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     }
   }
   if (tiles > 2147483647LL) return fail(IST_E_OUTPUT_SIZE, "canvas needs more than 2^31 tiles");
+  // launch order of the bands: the expensive tiles (resampling) first, copies next, fills last, so that the workgroups
+  // that finish the launch are the short ones (a strip of mixed scales otherwise ends on whatever its last image needs).
+  // Stable: bands of one kind keep their canvas order.
+  if (!knobs.no_sort && out->bands.size() > 1) {
+    auto weight = [&](const DevBand& b) {
+      const int32_t path = out->cells[b.first_cell].path;
+      return path == PATH_FILL ? 0 : path == PATH_COPY ? 1 : 2;
+    };
+    std::stable_sort(out->bands.begin(), out->bands.end(), [&](const DevBand& a, const DevBand& b) { return weight(a) > weight(b); });
+    int64_t at = 0;
+    for (DevBand& b : out->bands) {
+      b.tile_begin = at;
+      const DevCell& f = out->cells[b.first_cell];
+      const int64_t rows = (f.Y1 - f.Y0 + f.tile_h - 1) / f.tile_h;
+      int64_t cell_at = at;
+      for (int32_t k = 0; k < b.n_cells; ++k) { DevCell& c = out->cells[b.first_cell + k]; c.tile_begin = cell_at; cell_at += static_cast<int64_t>(c.tiles_x) * rows; }
+      at += static_cast<int64_t>(b.tiles_per_row) * rows;
+    }
+  }
   // the table pays when tiles have a long set-up (resample paths: -3..5 % measured); pure fill/copy jobs keep the
   // prefix search, whose few cache lines stay hot in the scalar cache (a per-tile entry is a cold miss: +3 % measured)
   const bool resamples = info.tiles_sample + info.tiles_general > 0;

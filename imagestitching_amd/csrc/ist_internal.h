@@ -88,6 +88,7 @@ struct Compiled {
   int filter = IST_FILTER_BILINEAR;
   int32_t lds_words = 0;               // dynamic LDS per workgroup (32-bit words): max(SWAP_LDS patch, lds_half)
   int32_t lds_half = 0;                // the SAMPLE_LDS footprint buffer (the largest footprint any stage needs)
+  int32_t kernel_kind = 0;             // 0: fill/copy cells only; 1: + SAMPLE / SAMPLE_LDS; 2: + SWAP_LDS / GENERAL
   std::vector<DevOp> ops;
   std::vector<DevCell> cells;
   std::vector<DevBand> bands;

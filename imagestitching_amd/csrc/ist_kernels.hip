@@ -34,6 +34,12 @@ typedef u32x4 u32x4_a4 __attribute__((aligned(4)));   // RGBA rows are only pixe
 typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
 
 #define IST_DEV static __device__ __forceinline__
+#ifndef IST_X_EARLY
+#define IST_X_EARLY 1     // experiment switches (tools/ab_build.sh builds the alternatives)
+#endif
+#ifndef IST_X_SU
+#define IST_X_SU 8
+#endif
 
 IST_DEV u32x4 ld16(const uint8_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(p)); }
 IST_DEV void st16(uint8_t* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a4*>(p)); }
@@ -411,12 +417,21 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
       }
     }
   };
+  // The first stage's loads go out BEFORE the per-lane set-up below (four fp64 column taps per lane, ~0.4 us): a
+  // workgroup that has just started then already has its footprint in flight while it computes them.
+  int fy0, fh;
+  foot(0, &fy0, &fh);
+#if IST_X_EARLY
+  if (!fresh) __syncthreads();                            // every wave is done reading the previous tile's footprint
+  stage(fy0, fh, lds);
+#endif
   // Lane l owns pixels X0 + l + 64 p (p = 0..3), NOT 4 neighbours: consecutive lanes then read LDS words |kx| apart
   // instead of 4|kx| apart (measured: 77 % of the LDS cycles were bank conflicts with the neighbour mapping), and each
   // of the 4 stores of a wave is still 256 contiguous bytes.  Lanes past a ragged right edge keep computing (on the
   // last column) and only skip their stores: the row taps below are exchanged with v_readlane and the barriers of
   // later stages need every wave.
-  const int Xl = X0 + lane;
+  int Xl = X0 + lane;
+  asm volatile("" : "+v"(Xl));                            // (keeps the tap arithmetic below the loads issued above)
   int lx[NP]; float wx[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
@@ -425,21 +440,12 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
   }
   uint8_t* d = A.dst + static_cast<size_t>(Xl) * 4;
   const bool opaque = (op.flags & OPF_OPAQUE) != 0;
-  int fy0, fh;
-  foot(0, &fy0, &fh);
-  for (int s = 0; s < nsub; ++s) {
-    if (s > 0 || !fresh) __syncthreads();                 // every wave is done reading the previous stage (or tile)
-    stage(fy0, fh, lds);
-    int ny0 = 0, nh = 0;
-    if (s + 1 < nsub) foot(s + 1, &ny0, &nh);             // (tap arithmetic under the loads)
+  // one stage's arithmetic: LDS taps -> blend -> 256-B-per-wave stores
+  auto compute = [&](int s, int sfy0, const RowTaps& rows, const uint32_t* buf) {
     const int Ya = Y0 + s * sub_h, Yb = min(Ya + sub_h, Y1);
-    const RowTaps rows = row_taps(op.ky, op.oy, Ya, Yb, op.cy0, op.cy1);   // all 64 lanes active (readlane source)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA is tracked by vmcnt only
-    __syncthreads();
-    const uint32_t* buf = lds;
     for (int Y = Ya + wave; Y < Yb; Y += 4) {
       const Tap ty = row_tap(rows, Y - Ya);
-      const uint32_t* r0 = buf + (ty.base - fy0) * wl;
+      const uint32_t* r0 = buf + (ty.base - sfy0) * wl;
       const uint32_t* r1 = r0 + wl;
       uint32_t o[NP];
       uint32_t p00[NP], p01[NP], p10[NP], p11[NP];
@@ -458,6 +464,24 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
       for (int p = 0; p < NP; ++p)
         if (Xl + 64 * p < X1) st4(dp + 256 * p, o[p]);
     }
+  };
+  for (int s = 0; s < nsub; ++s) {
+#if IST_X_EARLY
+    if (s > 0) {
+      __syncthreads();                                    // every wave is done reading the previous stage
+      stage(fy0, fh, lds);
+    }
+#else
+    if (s > 0 || !fresh) __syncthreads();
+    stage(fy0, fh, lds);
+#endif
+    int ny0 = 0, nh = 0;
+    if (s + 1 < nsub) foot(s + 1, &ny0, &nh);             // (tap arithmetic under the loads)
+    const int Ya = Y0 + s * sub_h, Yb = min(Ya + sub_h, Y1);
+    const RowTaps rows = row_taps(op.ky, op.oy, Ya, Yb, op.cy0, op.cy1);   // all 64 lanes active (readlane source)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA is tracked by vmcnt only
+    __syncthreads();
+    compute(s, fy0, rows, lds);
     fy0 = ny0; fh = nh;
   }
 }
@@ -485,10 +509,11 @@ IST_DEV bool tile_swap_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int
   // ---- stage transposed: work item = (source row r, 4-pixel chunk c)
   const int chunks = (fw + 3) >> 2;
   const int total = chunks * fh;
-  for (int i0 = 0; i0 < total; i0 += 256 * 4) {
-    u32x4 v[4];
+  constexpr int SU = IST_X_SU;                  // 16-B loads in flight per lane: a 64 x 64 tile's patch (<= 2048 chunks) is ONE round
+  for (int i0 = 0; i0 < total; i0 += 256 * SU) {
+    u32x4 v[SU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < SU; ++u) {
       const int i = i0 + u * 256 + tid;
       if (i < total) {
         const int r = i / chunks, c = i - r * chunks;
@@ -504,7 +529,7 @@ IST_DEV bool tile_swap_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < SU; ++u) {
       const int i = i0 + u * 256 + tid;
       if (i < total) {
         const int r = i / chunks, c = i - r * chunks;
@@ -537,13 +562,33 @@ IST_DEV bool tile_swap_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int
     }
     return true;
   }
-  for (int Y = Y0 + wave; Y < Y1; Y += 4) {
+  // two canvas rows per step (Y and Y + 4): they share the row weight tr.t, so the packed blend of the SAMPLE_LDS path
+  // applies (two pixels per v_pk_fma_f32 chain instead of one)
+  int Y = Y0 + wave;
+  for (; Y + 4 < Y1; Y += 8) {
+    const Tap tc0 = row_tap(cols, Y - Y0), tc1 = row_tap(cols, Y + 4 - Y0);
+    const uint32_t* a0 = col0 + (tc0.base - fx0) * pitch;   // T[sx][sy], T[sx][sy+1]
+    const uint32_t* b0 = a0 + pitch;                         // T[sx+1][...]
+    const uint32_t* a1 = col0 + (tc1.base - fx0) * pitch;
+    const uint32_t* b1 = a1 + pitch;
+    // (p00, p01, p10, p11): p01 = next source column, p10 = next source row
+    const uint32_t p00[2] = {a0[0], a1[0]}, p01[2] = {b0[0], b1[0]}, p10[2] = {a0[1], a1[1]}, p11[2] = {b0[1], b1[1]};
+    uint32_t o[2];
+    if (opaque || ((p00[0] & p01[0] & p10[0] & p11[0] & p00[1] & p01[1] & p10[1] & p11[1]) >> 24) == 255u) {
+      const float tx[2] = {tc0.t, tc1.t};
+      bilerpN_opaque<2>(p00, p01, p10, p11, tx, tr.t, o);
+    } else {
+      o[0] = bilerp_over(p00[0], p01[0], p10[0], p11[0], tc0.t, tr.t, bg, false);
+      o[1] = bilerp_over(p00[1], p01[1], p10[1], p11[1], tc1.t, tr.t, bg, false);
+    }
+    st4(dcol + static_cast<size_t>(Y) * A.dst_pitch, o[0]);
+    st4(dcol + static_cast<size_t>(Y + 4) * A.dst_pitch, o[1]);
+  }
+  for (; Y < Y1; Y += 4) {
     const Tap tc = row_tap(cols, Y - Y0);
-    const uint32_t* a = col0 + (tc.base - fx0) * pitch;     // T[sx][sy], T[sx][sy+1]
-    const uint32_t* b = a + pitch;                           // T[sx+1][...]
-    // bilerp_over(p00, p01, p10, p11, tx, ty): p01 = next source column, p10 = next source row
-    const uint32_t o = bilerp_over(a[0], b[0], a[1], b[1], tc.t, tr.t, bg, opaque);
-    st4(A.dst + static_cast<size_t>(Y) * A.dst_pitch + static_cast<size_t>(X) * 4, o);
+    const uint32_t* a = col0 + (tc.base - fx0) * pitch;
+    const uint32_t* b = a + pitch;
+    st4(dcol + static_cast<size_t>(Y) * A.dst_pitch, bilerp_over(a[0], b[0], a[1], b[1], tc.t, tr.t, bg, opaque));
   }
   return true;
 }
@@ -631,7 +676,7 @@ IST_DEV void tile_general(const LaunchArgs& A, const DevCell c, int X0, int Y0, 
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
-enum : int { HAS_FILL = 1, HAS_COPY = 2, HAS_SAMPLE = 4, HAS_GENERAL = 8 };
+enum : int { HAS_FILL = 1, HAS_COPY = 2, HAS_SAMPLE = 4, HAS_GENERAL = 8, HAS_SWAP = 16 };
 
 template <int PATHS, int V>
 IST_DEV void run_tile(const LaunchArgs& A, int64_t tile, bool fresh) {
@@ -679,7 +724,7 @@ IST_DEV void run_tile(const LaunchArgs& A, int64_t tile, bool fresh) {
     if (c.tile_w == 256) tile_sample_lds<4>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
     else if (c.tile_w == 128) tile_sample_lds<2>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
     else tile_sample_lds<1>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
-  } else if ((PATHS & HAS_SAMPLE) && path == PATH_SWAP_LDS) {
+  } else if ((PATHS & HAS_SWAP) && path == PATH_SWAP_LDS) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (!tile_swap_lds(A, op_, c.bg, X0, Y0, X1, Y1, lds)) tile_general(A, c, X0, Y0, X1, Y1);
   } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE) {
@@ -720,7 +765,7 @@ static void launch_variant(int v, bool persist, const LaunchArgs& a, int64_t n, 
   }
 }
 
-int launch_stitch(const LaunchArgs& args, int64_t n_tiles, bool lean, void* stream) {
+int launch_stitch(const LaunchArgs& args, int64_t n_tiles, int kind, void* stream) {
   if (n_tiles <= 0) return IST_OK;
   // tuning knobs, read only when the process was started with IST_TUNING=1 (tools/sweep_*.py): IST_VARIANT = copy variant
   // + 100 * persistent; IST_PERSIST_BLOCKS; IST_FULL_KERNEL; IST_DYN_LDS.  Production launches touch no environment.
@@ -732,8 +777,11 @@ int launch_stitch(const LaunchArgs& args, int64_t n_tiles, bool lean, void* stre
   const int v = knob % 100;
   const bool persist = knob >= 100;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (lean && !full) launch_variant<HAS_FILL | HAS_COPY>(v, persist, args, n_tiles, s, pb, dl);
-  else launch_variant<HAS_FILL | HAS_COPY | HAS_SAMPLE | HAS_GENERAL>(v, persist, args, n_tiles, s, pb, dl);
+  // three instantiations of one template, by what the job's cells need: the fewer paths, the fewer registers and the
+  // more workgroups per CU (fill/copy: 28 VGPRs; + axis-aligned resampling; + quarter turns and the per-pixel stack)
+  if (kind == 0 && !full) launch_variant<HAS_FILL | HAS_COPY>(v, persist, args, n_tiles, s, pb, dl);
+  else if (kind == 1 && !full) launch_variant<HAS_FILL | HAS_COPY | HAS_SAMPLE>(v, persist, args, n_tiles, s, pb, dl);
+  else launch_variant<HAS_FILL | HAS_COPY | HAS_SAMPLE | HAS_SWAP | HAS_GENERAL>(v, persist, args, n_tiles, s, pb, dl);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(IST_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));
   return IST_OK;

@@ -29,8 +29,9 @@ struct LaunchArgs {
   size_t pitch[kMaxImages];
 };
 
-// lean = the job has only FILL / COPY cells (the instantiation without the resample paths is launched)
-int launch_stitch(const LaunchArgs& args, int64_t n_tiles, bool lean, void* stream);
+// kind: 0 = the job has only FILL / COPY cells, 1 = + axis-aligned resampling (SAMPLE, SAMPLE_LDS), 2 = anything
+// (quarter turns, paint stacks): the instantiation with just those paths is launched
+int launch_stitch(const LaunchArgs& args, int64_t n_tiles, int kind, void* stream);
 
 }  // namespace ist
 

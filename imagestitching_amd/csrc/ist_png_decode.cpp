@@ -37,7 +37,7 @@ int parse(const uint8_t* f, int64_t n, Header* H, std::vector<Span>* idat, std::
   if (!f || n < 8 + 25 + 12) return fail(IST_E_DECODE, "not a PNG file (too short)");
   if (std::memcmp(f, sig, 8) != 0) {
     if (f[0] == 0xFF && f[1] == 0xD8) return fail(IST_E_UNSUPPORTED, "this is a JPEG file: use ist_image_decode_rgba8");
-    if (n >= 12 && !std::memcmp(f, "RIFF", 4) && !std::memcmp(f + 8, "WEBP", 4)) return fail(IST_E_UNSUPPORTED, "WebP decode is not built (PNG, JPEG, BMP and GIF inputs are)");
+    if (n >= 12 && !std::memcmp(f, "RIFF", 4) && !std::memcmp(f + 8, "WEBP", 4)) return fail(IST_E_UNSUPPORTED, "this is a WebP file: use ist_image_decode_rgba8");
     return fail(IST_E_DECODE, "not a PNG file");
   }
   int64_t pos = 8;

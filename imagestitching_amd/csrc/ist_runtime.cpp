@@ -18,6 +18,7 @@
 #include "ist_internal.h"
 #include "ist_jpeg.h"
 #include "ist_launch.h"
+#include "ist_webp.h"
 
 using namespace ist;
 
@@ -182,7 +183,7 @@ int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch
   if ((reinterpret_cast<uintptr_t>(dst) & 3) != 0) return fail(IST_E_INVALID, "dst must be 4-byte aligned");
   DeviceGuard g(job->ctx->device);
   if (!g.ok) return fail(IST_E_NO_DEVICE, "hipSetDevice failed");
-  return launch_stitch(a, h.info.n_tiles, h.info.tiles_sample == 0 && h.info.tiles_general == 0, stream);
+  return launch_stitch(a, h.info.n_tiles, h.kernel_kind, stream);
 }
 
 void ist_job_destroy(ist_job* job) {
@@ -412,6 +413,7 @@ static bool is_misc(const uint8_t* f, int64_t n) { return f && n >= 4 && ((f[0] 
 
 int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation) {
   if (is_jpeg(file, len)) return ist_jpeg_info(file, len, width, height, orientation);
+  if (is_webp(file, len)) return webp_info(file, len, width, height, orientation);      // EXIF chunk of the container
   if (orientation) *orientation = 0;
   if (is_misc(file, len)) return ist_misc_info(file, len, width, height);
   return ist_png_info(file, len, width, height);
@@ -420,6 +422,7 @@ int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* he
 int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch, int64_t out_rows) {
   if (is_jpeg(file, len)) return ist_jpeg_decode_rgba8(ctx, file, len, out, out_pitch, out_rows);
   if (is_misc(file, len)) return ist_misc_decode_rgba8(file, len, out, out_pitch, out_rows);
+  if (is_webp(file, len)) return webp_decode_rgba8(file, len, out, out_pitch, out_rows);
   return ist_png_decode_rgba8(file, len, out, out_pitch, out_rows);
 }
 
@@ -471,6 +474,7 @@ int decode_host_stage(const uint8_t* const* files, const int64_t* lens, int n, s
       } else {                 // PNG, BMP, GIF: host decoders
         int32_t w = 0, h = 0, o = 0;
         D.rc = ist_image_info(f, len, &w, &h, &o);
+        D.orient = o;                                     // WebP carries EXIF in its container
         if (D.rc == IST_OK) { D.w = w; D.h = h; D.px.resize(static_cast<size_t>(w) * h * 4); D.rc = ist_image_decode_rgba8(nullptr, f, len, D.px.data(), static_cast<size_t>(w) * 4, h); }
       }
       if (D.rc != IST_OK) D.err = g_last_error;        // thread-local in the worker: carry it out

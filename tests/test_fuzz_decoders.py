@@ -27,7 +27,10 @@ def _seeds(d):
             ("prog.jpg", im, "JPEG", {"progressive": True, "subsampling": 2}), ("prog444.jpg", im, "JPEG", {"progressive": True, "subsampling": 0}),
             ("24.bmp", im, "BMP", {}), ("8.bmp", im.convert("P"), "BMP", {}), ("1.bmp", im.convert("1"), "BMP", {}),
             ("a.gif", im.convert("P"), "GIF", {}), ("i.gif", im.convert("P"), "GIF", {"interlace": True}),
-            ("t.gif", im.convert("P"), "GIF", {"transparency": 3})]
+            ("t.gif", im.convert("P"), "GIF", {"transparency": 3}),
+            ("ll.webp", im, "WEBP", {"lossless": True}), ("lla.webp", im.convert("RGBA"), "WEBP", {"lossless": True, "quality": 100, "method": 6}),
+            ("llp.webp", im.convert("P").convert("RGB"), "WEBP", {"lossless": True}), ("lossy.webp", im, "WEBP", {"quality": 80}),
+            ("lossya.webp", im.convert("RGBA"), "WEBP", {"quality": 60})]
     out = []
     from test_png_decode import _adam7_png
     with open(os.path.join(d, "adam7.png"), "wb") as f:

@@ -1,0 +1,115 @@
+"""WebP decode ('webp' is in SUPPORTED_IMAGE_TYPES, pages/index/index.js:4, and among the
+chooser's extensions, index.js:1030).  Host decoders, so this runs without a GPU.  Lossless (VP8L) is pinned bit for bit
+by libwebp through PIL; lossy (VP8 key frames) is compared with PIL's own decode of the same file."""
+import ctypes as C
+import io
+import struct
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from imagestitching_amd import _lib as L
+
+
+def _webp(a, mode, **kw):
+    b = io.BytesIO()
+    Image.fromarray(a, mode).save(b, "WEBP", **kw)
+    return b.getvalue()
+
+
+def _decode(buf):
+    w, h, o = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = L.lib.ist_image_info(buf, len(buf), C.byref(w), C.byref(h), C.byref(o))
+    if rc:
+        return rc, None, 0
+    out = np.full((h.value + 1, w.value, 4), 0xA5, np.uint8)
+    rc = L.lib.ist_image_decode_rgba8(None, buf, len(buf), out.ctypes.data, w.value * 4, h.value)
+    assert (out[h.value] == 0xA5).all(), "decoder wrote past the declared capacity"
+    return rc, out[:h.value], o.value
+
+
+def _pil(buf):
+    return np.asarray(Image.open(io.BytesIO(buf)).convert("RGBA"))
+
+
+def _pictures():
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:120, 0:173]
+    smooth = np.stack([(xx * 2 + yy) % 256, (yy * 3) % 256, (xx + yy * 2) % 256, 255 - (xx % 256)], -1).astype(np.uint8)
+    noise = rng.integers(0, 256, (64, 97, 4), dtype=np.uint8)
+    pal = (rng.integers(0, 5, (50, 70)) * 50).astype(np.uint8)
+    photo = (128 + 90 * np.sin(xx / 17.0 + yy / 31.0))[..., None] * np.ones(3) + rng.normal(0, 4, (120, 173, 3))
+    return {"smooth": smooth, "noise": noise, "palette5": np.stack([pal, pal // 2, 255 - pal], -1), "two": (np.stack([pal > 100] * 3, -1) * 255).astype(np.uint8),
+            "photo": photo.clip(0, 255).astype(np.uint8), "one": np.zeros((1, 1, 3), np.uint8), "wide": np.full((3, 5000, 3), 7, np.uint8),
+            "tall": rng.integers(0, 3, (3000, 2, 3), dtype=np.uint8) * 100}
+
+
+@pytest.mark.parametrize("name", ["smooth", "noise", "palette5", "two", "photo", "one", "wide", "tall"])
+@pytest.mark.parametrize("quality,method", [(0, 0), (50, 3), (100, 6)])
+def test_lossless_webp_is_bit_exact(name, quality, method):
+    a = _pictures()[name]
+    mode = "RGBA" if a.shape[2] == 4 else "RGB"
+    buf = _webp(a, mode, lossless=True, quality=quality, method=method)
+    assert buf[12:16] in (b"VP8L", b"VP8X")
+    rc, got, o = _decode(buf)
+    assert rc == 0, L.last_error()
+    assert np.array_equal(got, _pil(buf))
+    if mode == "RGB":
+        assert np.array_equal(got[..., :3], a) and (got[..., 3] == 255).all()
+
+
+def test_webp_exif_orientation_is_read_from_the_container():
+    a = _pictures()["photo"]
+    ex = Image.Exif()
+    ex[0x0112] = 6
+    buf = _webp(a, "RGB", lossless=True, exif=ex.tobytes())
+    assert buf[12:16] == b"VP8X" and b"EXIF" in buf
+    rc, got, o = _decode(buf)
+    assert rc == 0 and o == 6 and np.array_equal(got[..., :3], a)       # the bitmap is returned as stored; the stitch turns it
+
+
+def _riff(chunks):
+    body = b"WEBP" + b"".join(t + struct.pack("<I", len(d)) + d + (b"\x00" if len(d) & 1 else b"") for t, d in chunks)
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def test_webp_container_errors():
+    a = _pictures()["smooth"]
+    buf = _webp(a, "RGBA", lossless=True)
+    payload = buf[20:20 + struct.unpack("<I", buf[16:20])[0]]
+    # animated: unsupported, named
+    anim = _riff([(b"VP8X", bytes([0x02, 0, 0, 0]) + struct.pack("<I", a.shape[1] - 1)[:3] + struct.pack("<I", a.shape[0] - 1)[:3]), (b"ANIM", bytes(6)), (b"VP8L", payload)])
+    rc, _, _ = _decode(anim)
+    assert rc == -7 and "animated" in L.last_error()
+    # canvas size in VP8X disagrees with the frame
+    lie = _riff([(b"VP8X", bytes([0, 0, 0, 0]) + struct.pack("<I", 9)[:3] + struct.pack("<I", 9)[:3]), (b"VP8L", payload)])
+    assert _decode(lie)[0] == -6
+    # no image chunk; truncated chunk; truncated bitstream at every 97th byte; bad signature
+    assert _decode(_riff([(b"EXIF", b"II*\x00")]))[0] == -6
+    assert _decode(buf[:30])[0] == -6
+    for cut in range(21, len(payload), 97):
+        rc, _, _ = _decode(_riff([(b"VP8L", payload[:cut])]))
+        assert rc == -6, cut
+    assert _decode(_riff([(b"VP8L", b"\x2e" + payload[1:])]))[0] == -6
+    assert _decode(_riff([(b"VP8L", payload[:4] + bytes([payload[4] | 0x20]) + payload[5:])]))[0] == -6       # version != 0
+
+
+def test_webp_capacity_is_checked_against_the_files_own_header():
+    a = _pictures()["noise"]
+    buf = _webp(a, "RGBA", lossless=True)
+    out = np.zeros((10, a.shape[1], 4), np.uint8)
+    assert L.lib.ist_image_decode_rgba8(None, buf, len(buf), out.ctypes.data, a.shape[1] * 4, 10) == -1
+
+
+def test_lossless_webp_survives_bit_flips():
+    """every single-byte corruption of a small file comes back as pixels or as an error code (the library stays up)"""
+    a = _pictures()["smooth"][:40, :60]
+    buf = bytearray(_webp(a, "RGBA", lossless=True))
+    rng = np.random.default_rng(5)
+    for _ in range(400):
+        b = bytearray(buf)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(20, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        rc, got, _ = _decode(bytes(b))
+        assert rc in (0, -6, -7, -1)

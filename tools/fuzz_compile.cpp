@@ -146,7 +146,6 @@ int main(int argc, char** argv) {
       CHECK(c.stack_off >= 0 && c.stack_len >= 0 && size_t(c.stack_off) + c.stack_len <= C.stacks.size());
       for (int k = 0; k < c.stack_len; ++k) { const int32_t e = C.stacks[c.stack_off + k]; CHECK(e >= 0 && size_t(e) < C.ops.size()); CHECK(!(C.ops[e].flags & OPF_HOLE)); }
       CHECK(c.tile_w >= 1 && c.tile_h >= 1 && c.tiles_x == (c.X1 - c.X0 + c.tile_w - 1) / c.tile_w);
-      CHECK(c.tile_begin == tiles);
       tiles += int64_t(c.tiles_x) * ((c.Y1 - c.Y0 + c.tile_h - 1) / c.tile_h);
       area += int64_t(c.X1 - c.X0) * (c.Y1 - c.Y0);
       if (c.path != PATH_FILL) { CHECK(c.stack_len >= 1 && c.op == C.stacks[c.stack_off]); }
@@ -169,8 +168,16 @@ int main(int argc, char** argv) {
     }
     CHECK(tiles == C.info.n_tiles);
     if (!holes) CHECK(area == (C.rx1 - C.rx0) * (C.ry1 - C.ry0)); else CHECK(area <= (C.rx1 - C.rx0) * (C.ry1 - C.ry0));
+    // bands partition the cells (each cell in exactly one band) and are launched in array order: expensive kinds first
     int64_t bt = 0;
+    std::vector<char> in_band(C.cells.size(), 0);
+    int last_weight = 3;
     for (const DevBand& b : C.bands) {
+      for (int k = 0; k < b.n_cells; ++k) { CHECK(!in_band[b.first_cell + k]); in_band[b.first_cell + k] = 1; }
+      const int32_t bp = C.cells[b.first_cell].path;
+      const int weight = bp == PATH_FILL ? 0 : bp == PATH_COPY ? 1 : 2;
+      CHECK(weight <= last_weight);
+      last_weight = weight;
       CHECK(b.tile_begin == bt && b.n_cells >= 1 && size_t(b.first_cell) + b.n_cells <= C.cells.size());
       int per_row = 0;
       const DevCell& f = C.cells[b.first_cell];
@@ -179,6 +186,7 @@ int main(int argc, char** argv) {
       bt += int64_t(per_row) * ((f.Y1 - f.Y0 + f.tile_h - 1) / f.tile_h);
     }
     CHECK(bt == tiles);
+    for (char v : in_band) CHECK(v);
   }
   printf("fuzz-compile: %ld compiled, %ld rejected, all invariants hold\n", ok, bad);
   return 0;

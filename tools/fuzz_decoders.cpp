@@ -10,6 +10,7 @@
 
 #include "imagestitch.h"
 #include "ist_jpeg.h"
+#include "ist_webp.h"
 
 extern "C" int ist_misc_info(const uint8_t*, int64_t, int32_t*, int32_t*);
 extern "C" int ist_misc_decode_rgba8(const uint8_t*, int64_t, uint8_t*, size_t, int64_t);
@@ -28,6 +29,12 @@ static void one(const std::vector<uint8_t>& f, long* ok, long* bad) {
       ist::JpegImage J2; ist::JpegGpuScan G;
       (void)ist::jpeg_parse_and_entropy_decode(p, n, &J2, false, &G);
       if (G.eligible && (G.slots < 1 || G.slots > 10 || G.bits < 0 || G.stream.size() < size_t(G.bits / 8) + 16)) abort();
+    }
+  } else if (ist::is_webp(p, n)) {
+    rc = ist::webp_info(p, n, &w, &h, &o);
+    if (rc == IST_OK && int64_t(w) * h <= (1 << 22)) {
+      std::vector<uint8_t> out(size_t(w) * h * 4);
+      rc = ist::webp_decode_rgba8(p, n, out.data(), size_t(w) * 4, h);
     }
   } else {
     const bool misc = n >= 4 && ((p[0] == 'B' && p[1] == 'M') || !memcmp(p, "GIF8", 4));

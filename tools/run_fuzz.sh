@@ -1,6 +1,6 @@
 #!/bin/bash
 # Sanitizer (ASan + UBSan, CPU only) fuzzing of the host-side code that faces untrusted input.
-#   tools/run_fuzz.sh ITERS seed1 [seed2 ...]     mutation-fuzz the file parsers (PNG / JPEG / BMP / GIF) from seed files
+#   tools/run_fuzz.sh ITERS seed1 [seed2 ...]     mutation-fuzz the file parsers (PNG / JPEG / BMP / GIF / WebP) from seed files
 #   tools/run_fuzz.sh compile ITERS               random + hostile op lists through the op-list compiler, invariants checked
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(dirname "$HERE"); C=$ROOT/imagestitching_amd/csrc
@@ -11,6 +11,6 @@ if [ "$1" = compile ]; then
   shift
   g++ $FLAGS "$HERE/fuzz_compile.cpp" "$C/ist_compile.cpp" "$C/ist_plan.cpp" -o "$OUT"
 else
-  g++ $FLAGS "$HERE/fuzz_decoders.cpp" "$C/ist_png_decode.cpp" "$C/ist_image_misc.cpp" "$C/ist_jpeg.cpp" "$C/ist_plan.cpp" -lz -o "$OUT"
+  g++ $FLAGS "$HERE/fuzz_decoders.cpp" "$C/ist_png_decode.cpp" "$C/ist_image_misc.cpp" "$C/ist_jpeg.cpp" "$C/ist_webp.cpp" "$C/ist_webp_vp8.cpp" "$C/ist_plan.cpp" -lz -o "$OUT"
 fi
 "$OUT" "$@"
