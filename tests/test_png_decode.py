@@ -227,7 +227,10 @@ def test_gif_first_frame_matches_pil():
 
 def test_webp_and_garbage_are_named():
     with pytest.raises(ist.StitchError) as e:
-        ist.decode_image(b"RIFF\x00\x00\x00\x00WEBPVP8 " + b"\x00" * 64)
+        ist.decode_image(b"RIFF\x00\x00\x00\x00WEBPVP8 " + b"\x00" * 64)            # a RIFF/WEBP header with no chunk inside
+    assert e.value.code == -6 and "WebP" in str(e.value)
+    with pytest.raises(ist.StitchError) as e:
+        ist.decode_png(b"RIFF\x00\x00\x00\x00WEBPVP8 " + b"\x00" * 64)              # the PNG-only entry point names the format
     assert e.value.code == -7 and "WebP" in str(e.value)
     with pytest.raises(ist.StitchError):
         ist.decode_image(b"GIF89a" + b"\x00" * 3)
