@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libimagestitch.so")
 VERTICAL, HORIZONTAL = 0, 1
 MODE_MIN, MODE_MAX, MODE_ORIGINAL = 0, 1, 2
 PLATFORM_OTHER, PLATFORM_IOS, PLATFORM_ANDROID = 0, 1, 2
-FILTER_NEAREST, FILTER_BILINEAR = 0, 1
+FILTER_NEAREST, FILTER_BILINEAR, FILTER_AREA = 0, 1, 2
 SPLIT_IMAGE, SPLIT_BAND = 0, 1
 
 IST_OK, IST_NOTHING_TO_DO = 0, 1

@@ -97,6 +97,14 @@ int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, 
 // number of distinct source indices one axis of a draw touches over canvas coordinates [lo, hi)
 static int64_t distinct_taps(double k, double o, int lo, int hi, int clo, int chi, int filter) {
   if (hi <= lo) return 0;
+  if (filter == IST_FILTER_AREA && std::fabs(k) > 1.0) {     // a box of width |k| per canvas pixel: contiguous boxes tile the whole span
+    const double a = k * static_cast<double>(lo) + o, b = k * static_cast<double>(hi) + o;
+    const double s0 = std::min(a, b), s1 = std::max(a, b);
+    const int64_t i0 = static_cast<int64_t>(std::min(std::max(std::floor(s0), -4.0e9), 4.0e9)), i1 = static_cast<int64_t>(std::min(std::max(std::ceil(s1), -4.0e9), 4.0e9)) - 1;
+    const int64_t c0 = std::min<int64_t>(std::max<int64_t>(i0, clo), chi), c1 = std::min<int64_t>(std::max<int64_t>(i1, clo), chi);
+    return c1 - c0 + 1;
+  }
+  if (filter == IST_FILTER_AREA) filter = IST_FILTER_BILINEAR;
   std::vector<int32_t> idx;
   idx.reserve(static_cast<size_t>(hi - lo) * 2);
   for (int w = lo; w < hi; ++w) {
@@ -156,9 +164,13 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
   if (n_ops < 0 || (n_ops > 0 && !ops)) return fail(IST_E_INVALID, "compile_ops: bad op list");
   const bool aa = (filter & IST_FILTER_EDGE_AA) != 0;
   filter &= 0xFF;
-  if (filter != IST_FILTER_NEAREST && filter != IST_FILTER_BILINEAR) return fail(IST_E_INVALID, "unknown filter");
+  if (filter != IST_FILTER_NEAREST && filter != IST_FILTER_BILINEAR && filter != IST_FILTER_AREA) return fail(IST_E_INVALID, "unknown filter");
+  // AREA: minifying draws are averaged per pixel on the general path; everything else about the job is bilinear
+  const bool area = filter == IST_FILTER_AREA;
+  const int job_filter = filter;
+  if (area) filter = IST_FILTER_BILINEAR;
   const CompileKnobs knobs = read_knobs();
-  out->canvas_w = canvas_w; out->canvas_h = canvas_h; out->filter = filter | (aa ? IST_FILTER_EDGE_AA : 0);
+  out->canvas_w = canvas_w; out->canvas_h = canvas_h; out->filter = job_filter | (aa ? IST_FILTER_EDGE_AA : 0);
   out->ops.clear(); out->cells.clear(); out->stacks.clear(); out->bands.clear(); out->tiles.clear();
   out->lds_words = 0; out->lds_half = 0; out->kernel_kind = 0;
   out->img_w.assign(static_cast<size_t>(n_images), 0);
@@ -276,8 +288,14 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     const bool bg_opaque = (cell.bg >> 24) == 255u;
     const bool partial = cell.tiles_x < 0;
     cell.tiles_x = 0;
-    if (partial) {
-      cell.path = PATH_GENERAL;                   // fractional edge strip: per-pixel coverage
+    bool minified = false;                        // IST_FILTER_AREA: a draw of the stack shrinks on some axis
+    if (area)
+      for (int k = 0; k < cell.stack_len; ++k) {
+        const DevOp& r = out->ops[out->stacks[cell.stack_off + k]];
+        minified |= !(r.flags & OPF_FILL) && (std::fabs(r.kx) > 1.0 || std::fabs(r.ky) > 1.0);
+      }
+    if (partial || minified) {
+      cell.path = PATH_GENERAL;                   // fractional edge strip: per-pixel coverage; box-averaged draw: per-pixel footprint
     } else if (cell.stack_len == 0) {
       cell.path = PATH_FILL;
       if (!bg_opaque) cell.bg = clear_back;       // reads back un-premultiplied
@@ -382,8 +400,9 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
       if (r.flags & OPF_FILL) continue;
       const bool sw = (r.flags & OPF_SWAP) != 0;
       // source x is driven by canvas X (or Y when turned); source y by the other axis
-      const int64_t nx = distinct_taps(r.kx, r.ox, sw ? cell.Y0 : cell.X0, sw ? cell.Y1 : cell.X1, r.cx0, r.cx1, filter);
-      const int64_t ny = distinct_taps(r.ky, r.oy, sw ? cell.X0 : cell.Y0, sw ? cell.X1 : cell.Y1, r.cy0, r.cy1, filter);
+      const int tf = (area && (std::fabs(r.kx) > 1.0 || std::fabs(r.ky) > 1.0)) ? IST_FILTER_AREA : filter;
+      const int64_t nx = distinct_taps(r.kx, r.ox, sw ? cell.Y0 : cell.X0, sw ? cell.Y1 : cell.X1, r.cx0, r.cx1, tf);
+      const int64_t ny = distinct_taps(r.ky, r.oy, sw ? cell.X0 : cell.Y0, sw ? cell.X1 : cell.Y1, r.cy0, r.cy1, tf);
       info.src_pixels_touched += nx * ny;
     }
   }

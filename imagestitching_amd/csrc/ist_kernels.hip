@@ -599,6 +599,7 @@ IST_DEV bool tile_swap_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int
 IST_DEV uint32_t pixel_general(const LaunchArgs& A, const DevCell c, int X, int Y) {
   uint32_t d = c.bg;
   const bool nearest = (A.filter & 0xFF) == IST_FILTER_NEAREST;
+  const bool area = (A.filter & 0xFF) == IST_FILTER_AREA;
   const bool edge_aa = (A.filter & IST_FILTER_EDGE_AA) != 0;
   for (int k = 0; k < c.stack_len; ++k) {
     const DevOp op = A.ops[A.stacks[c.stack_off + k]];
@@ -630,6 +631,43 @@ IST_DEV uint32_t pixel_general(const LaunchArgs& A, const DevCell c, int X, int 
         o |= static_cast<uint32_t>(fmin(fmax(v, 0.0), 255.0)) << (8 * ch_);
       }
       const double va = floor(static_cast<double>(a) * cov + static_cast<double>(d >> 24) * keep + 0.5);
+      d = o | (static_cast<uint32_t>(fmin(fmax(va, 0.0), 255.0)) << 24);
+    } else if (area && (fabs(op.kx) > 1.0 || fabs(op.ky) > 1.0)) {
+      // IST_FILTER_AREA on a minifying draw: a box of width max(1, |k|) per axis around the sample position, source pixels
+      // weighted by their overlap (fp32 sums of premultiplied taps; the oracle does the same sums in fp64)
+      const double sxc = op.kx * (static_cast<double>(wx) + 0.5) + op.ox, syc = op.ky * (static_cast<double>(wy) + 0.5) + op.oy;
+      const double bw = fmax(fabs(op.kx), 1.0), bh = fmax(fabs(op.ky), 1.0);
+      const double xlo = sxc - 0.5 * bw, xhi = sxc + 0.5 * bw, ylo = syc - 0.5 * bh, yhi = syc + 0.5 * bh;
+      const int ix0 = static_cast<int>(fmin(fmax(floor(xlo), -2.0e9), 2.0e9)), ix1 = static_cast<int>(fmin(fmax(ceil(xhi), -2.0e9), 2.0e9)) - 1;
+      const int iy0 = static_cast<int>(fmin(fmax(floor(ylo), -2.0e9), 2.0e9)), iy1 = static_cast<int>(fmin(fmax(ceil(yhi), -2.0e9), 2.0e9)) - 1;
+      float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+      for (int yy = iy0; yy <= iy1; ++yy) {
+        const float oyw = static_cast<float>(fmin(static_cast<double>(yy) + 1.0, yhi) - fmax(static_cast<double>(yy), ylo));
+        if (oyw <= 0.f) continue;
+        const uint8_t* srow = src + static_cast<size_t>(min(max(yy, op.cy0), op.cy1)) * sp;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+        for (int xx = ix0; xx <= ix1; ++xx) {
+          const float oxw = static_cast<float>(fmin(static_cast<double>(xx) + 1.0, xhi) - fmax(static_cast<double>(xx), xlo));
+          if (oxw <= 0.f) continue;
+          const uint32_t s = ld4(srow + 4 * static_cast<size_t>(min(max(xx, op.cx0), op.cx1)));
+          const float a = static_cast<float>(s >> 24);
+          r0 += oxw * (static_cast<float>(ch(s, 0)) * a); r1 += oxw * (static_cast<float>(ch(s, 1)) * a);
+          r2 += oxw * (static_cast<float>(ch(s, 2)) * a); r3 += oxw * a;
+        }
+        acc0 += oyw * r0; acc1 += oyw * r1; acc2 += oyw * r2; acc3 += oyw * r3;
+      }
+      const double norm = 1.0 / (bw * bh);
+      const double Aa = static_cast<double>(acc3) * norm;
+      const double keep = 1.0 - cov * (Aa / 255.0);
+      const float accs[3] = {acc0, acc1, acc2};
+      uint32_t o = 0;
+#pragma unroll
+      for (int ch_ = 0; ch_ < 3; ++ch_) {
+        const double P = static_cast<double>(accs[ch_]) * norm / 255.0;
+        const double v = floor(P * cov + static_cast<double>(ch(d, ch_)) * keep + 0.5);
+        o |= static_cast<uint32_t>(fmin(fmax(v, 0.0), 255.0)) << (8 * ch_);
+      }
+      const double va = floor(Aa * cov + static_cast<double>(d >> 24) * keep + 0.5);
       d = o | (static_cast<uint32_t>(fmin(fmax(va, 0.0), 255.0)) << 24);
     } else {
       const Tap tx = bilinear_tap(op.kx, op.ox, wx, op.cx0, op.cx1);

@@ -22,6 +22,16 @@ namespace {
 
 // source index range one axis of a draw touches over canvas coordinates [lo, hi) (inclusive result, clamped)
 void tap_range(double k, double o, int lo, int hi, int clo, int chi, int filter, int* a, int* b) {
+  if (filter == IST_FILTER_AREA && std::fabs(k) > 1.0) {      // a box of width |k| around every sample position
+    const double half = 0.5 * std::fabs(k);
+    const double c0 = k * (static_cast<double>(lo) + 0.5) + o, c1 = k * (static_cast<double>(hi - 1) + 0.5) + o;
+    const double s0 = std::min(c0, c1) - half, s1 = std::max(c0, c1) + half;
+    const int64_t i0 = static_cast<int64_t>(std::min(std::max(std::floor(s0), -4.0e9), 4.0e9)), i1 = static_cast<int64_t>(std::min(std::max(std::ceil(s1), -4.0e9), 4.0e9)) - 1;
+    *a = static_cast<int>(std::min<int64_t>(std::max<int64_t>(i0, clo), chi));
+    *b = static_cast<int>(std::min<int64_t>(std::max<int64_t>(i1, clo), chi));
+    return;
+  }
+  if (filter == IST_FILTER_AREA) filter = IST_FILTER_BILINEAR;
   auto first_tap = [&](int w) {
     const double s = k * (static_cast<double>(w) + 0.5) + o;
     double fl = std::floor(filter == IST_FILTER_BILINEAR ? s - 0.5 : s);
@@ -49,7 +59,7 @@ extern "C" int ist_shard_parts(const ist_op* ops, int n_ops, int64_t canvas_w, i
   if (canvas_w < 1 || canvas_h < 1 || canvas_w > (1 << 29) || canvas_h > 2147483647LL) return fail(IST_E_OUTPUT_SIZE, "输出尺寸计算失败: canvas size out of range");
   const bool aa = (filter & IST_FILTER_EDGE_AA) != 0;
   const int f = filter & 0xFF;
-  if (f != IST_FILTER_NEAREST && f != IST_FILTER_BILINEAR) return fail(IST_E_INVALID, "unknown filter");
+  if (f != IST_FILTER_NEAREST && f != IST_FILTER_BILINEAR && f != IST_FILTER_AREA) return fail(IST_E_INVALID, "unknown filter");
   *n_parts = 0;
   struct Draw { int op; DevOp r; };
   std::vector<Draw> draws;

@@ -16,24 +16,34 @@ from . import _lib as L
 
 _DIRECTIONS = {"vertical": L.VERTICAL, "horizontal": L.HORIZONTAL}
 _MODES = {"min": L.MODE_MIN, "max": L.MODE_MAX, "original": L.MODE_ORIGINAL}
-_FILTERS = {"nearest": L.FILTER_NEAREST, "bilinear": L.FILTER_BILINEAR}
+_FILTERS = {"nearest": L.FILTER_NEAREST, "bilinear": L.FILTER_BILINEAR, "area": L.FILTER_AREA}
 FILTER_EDGE_AA = 0x100
 
 
+def edge_aa_of(o):
+    """Coverage rule for fractional rectangle edges.  Unset: ON whenever a reference platform's plan is requested
+    (opts.platform: the reference's own default behaviour scales the canvas by superSample 2.2 / 2.6 for fewer than 7
+    images, index.js:1363,1426-1428, and leaves the cursor unrounded when gap > 0 and scaleDown < 1, :1432, so fractional
+    edges are the normal case there and a Canvas raster anti-aliases them); OFF for the lifted MI355X default, whose
+    plans have integer edges unless a gap meets a shrink, so that every output pixel is owned by exactly one image."""
+    v = o.get("edgeAA")
+    return (o.get("platform") is not None) if v is None else bool(v)
+
+
 def _filter_of(o):
-    return _FILTERS[o["filter"]] | (FILTER_EDGE_AA if o.get("edgeAA") else 0)
+    return _FILTERS[o["filter"]] | (FILTER_EDGE_AA if edge_aa_of(o) else 0)
 _PLATFORMS = {"ios": L.PLATFORM_IOS, "android": L.PLATFORM_ANDROID, "devtools": L.PLATFORM_OTHER,
               "windows": L.PLATFORM_OTHER, "mac": L.PLATFORM_OTHER, "other": L.PLATFORM_OTHER}
 
 DEFAULT_OPTS = {
     "mode": "min",          # data.verticalStitchMode / horizontalStitchMode default (index.js:19-20)
     "gap": 0,               # data.gap default (index.js:17)
-    "filter": "bilinear",   # imageSmoothingEnabled = true (index.js:1416-1418)
+    "filter": "bilinear",   # imageSmoothingEnabled = true (index.js:1416-1418); 'nearest' = false; 'area' = opt-in box average of minified axes (IST_FILTER_AREA)
     "platform": None,       # None: MI355X default = caps lifted; 'ios' / 'android' / 'devtools' reproduce the phone caps
     "maxSide": None,        # deviceMaxCanvasSize override
     "maxPixels": None,      # deviceMaxCanvasPixels override
     "superSample": None,    # None: 1 when platform is None, reference rule (index.js:1363) otherwise
-    "edgeAA": False,        # anti-alias fractional rectangle edges by area coverage (IST_FILTER_EDGE_AA)
+    "edgeAA": None,         # anti-alias fractional rectangle edges by area coverage (IST_FILTER_EDGE_AA); None: on iff `platform` is given (edge_aa_of)
     "pngLevel": None,       # PNG export form of the *_png / stitch_files calls: 0 stored, 1 compressed on the GPU; None = DEFAULT_PNG_LEVEL
     "devices": None,        # list of GPU indices (devices[0] = root): shard the stitch over them from this one process (ist_stitch_rgba8_multi)
     "split": "image",       # with devices: "image" (image i -> devices[i mod n], BASELINE configs[3]) or "band" (equal output rows per device)

@@ -12,10 +12,10 @@ export interface StitchImage {
   bmpWidth?: number; bmpHeight?: number;
 }
 export interface StitchOptions {
-  mode?: StitchMode; gap?: number; filter?: 'bilinear' | 'nearest';
+  mode?: StitchMode; gap?: number; filter?: 'bilinear' | 'nearest' | 'area';      // 'area': box-average minified axes (one reading of imageSmoothingQuality 'high'); default bilinear
   platform?: 'ios' | 'android' | 'devtools' | 'windows' | 'mac' | 'other';
   maxSide?: number; maxPixels?: number; superSample?: number;
-  edgeAA?: boolean;                         // anti-alias fractional rectangle edges (ctx.scale(superSample), unrounded cursor)
+  edgeAA?: boolean;                         // anti-alias fractional rectangle edges (ctx.scale(superSample), unrounded cursor); default: true iff `platform` is given
   onProgress?: (percent: number) => void;   // stitchProgress checkpoints (index.js:1193-1611)
   pngLevel?: 0 | 1;                         // PNG export form: 0 stored, 1 compressed on the GPU (process-wide once set)
   devices?: number[];                       // GPUs to shard the stitch over from this process; devices[0] is the root (RCCL gather over xGMI)

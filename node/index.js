@@ -14,7 +14,8 @@
  *              (reproduces the phone caps, index.js:1323-1336; default: caps lifted, superSample 1),
  *              maxSide, maxPixels (deviceMaxCanvasSize/Pixels), superSample (MAX_SUPER_SAMPLE, index.js:1363),
  *              onProgress: (percent) => void  (the stitchProgress checkpoints of index.js:1193-1611),
- *              edgeAA: anti-alias fractional rectangle edges by area coverage (default false: pixel-centre rule),
+ *              edgeAA: anti-alias fractional rectangle edges by area coverage (default: true when `platform` is given - a
+ *              reference plan has fractional edges as a rule - false otherwise: pixel-centre rule),
  *              devices: number[] - shard the stitch over these GPUs from this one process (devices[0] = root; parts render
  *              on their GPUs, one grouped RCCL send/recv batch over xGMI gathers the bands into the root's canvas),
  *              split: 'image' (image i -> devices[i mod n], the BASELINE layout) | 'band' (equal output rows per GPU)}
@@ -26,7 +27,7 @@ const native = require(path.join(__dirname, 'imagestitch.node'));
 
 const DIRECTION = { vertical: 0, horizontal: 1 };
 const MODE = { min: 0, max: 1, original: 2 };
-const FILTER = { nearest: 0, bilinear: 1 };
+const FILTER = { nearest: 0, bilinear: 1, area: 2 };
 const PLATFORM = { other: 0, devtools: 0, windows: 0, mac: 0, ios: 1, android: 2 };
 const KNOWN = ['mode', 'gap', 'filter', 'platform', 'maxSide', 'maxPixels', 'superSample', 'onProgress', 'edgeAA', 'pngLevel', 'devices', 'split'];
 const SPLIT = { image: 0, band: 1 };
@@ -45,6 +46,12 @@ function limitsOf(opts) {
   return Object.keys(lim).length ? lim : null;
 }
 
+// Coverage rule for fractional rectangle edges.  Unset: ON whenever a reference platform's plan is requested (the
+// reference's default plans scale the canvas by superSample 2.2 / 2.6 for fewer than 7 images, index.js:1363,1426-1428, and
+// keep an unrounded cursor when gap > 0 and scaleDown < 1, :1432, so fractional edges are normal there and a Canvas raster
+// anti-aliases them); OFF for the lifted MI355X default (every output pixel owned by exactly one image).
+function edgeAA(o) { return (o.edgeAA === undefined || o.edgeAA === null) ? (o.platform !== undefined && o.platform !== null) : !!o.edgeAA; }
+
 function args(images, direction, opts) {
   const o = opts || {};
   for (const k of Object.keys(o)) if (!KNOWN.includes(k)) throw new TypeError('unknown stitch option ' + k);
@@ -53,7 +60,7 @@ function args(images, direction, opts) {
   if (!(mode in MODE)) throw new TypeError('unknown mode ' + mode);
   const filter = o.filter || 'bilinear';
   if (!(filter in FILTER)) throw new TypeError('unknown filter ' + filter);
-  return [images || [], DIRECTION[direction], MODE[mode], Number(o.gap) || 0, limitsOf(o), FILTER[filter] | (o.edgeAA ? FILTER_EDGE_AA : 0)];
+  return [images || [], DIRECTION[direction], MODE[mode], Number(o.gap) || 0, limitsOf(o), FILTER[filter] | (edgeAA(o) ? FILTER_EDGE_AA : 0)];
 }
 
 // The reference reports progress through setData({stitchProgress}): 1 at the start (index.js:1193), 25 when every image

@@ -48,7 +48,7 @@
 enum { ORC_VERTICAL = 0, ORC_HORIZONTAL = 1 };
 enum { ORC_MODE_MIN = 0, ORC_MODE_MAX = 1, ORC_MODE_ORIGINAL = 2 };
 enum { ORC_PLATFORM_OTHER = 0, ORC_PLATFORM_IOS = 1, ORC_PLATFORM_ANDROID = 2 };
-enum { ORC_NEAREST = 0, ORC_BILINEAR = 1, ORC_EDGE_AA = 0x100 };   /* filter | ORC_EDGE_AA: coverage anti-aliasing of fractional edges */
+enum { ORC_NEAREST = 0, ORC_BILINEAR = 1, ORC_AREA = 2, ORC_EDGE_AA = 0x100 };   /* filter | ORC_EDGE_AA: coverage anti-aliasing of fractional edges */
 
 typedef struct {
   int32_t width, height;     /* naturalWidth / naturalHeight (index.js:724-739) */
@@ -249,12 +249,13 @@ typedef struct {
   orc_mat stack[16];
   int sp;
   int smoothing;        /* imageSmoothingEnabled */
+  int area;             /* ORC_AREA: minified axes average the source over the output pixel's footprint (box), others stay bilinear */
   int aa;               /* anti-alias fractional rectangle edges by area coverage (off: pixel-centre rule) */
   int y0, y1;           /* raster band [y0,y1) for the multithreaded baseline */
 } orc_canvas;
 
 static void cv_init(orc_canvas* cv, int w, int h, uint8_t* px, size_t pitch, int smoothing, int y0, int y1) {
-  cv->w = w; cv->h = h; cv->px = px; cv->pitch = pitch; cv->sp = 0; cv->smoothing = smoothing & 1; cv->aa = (smoothing & ORC_EDGE_AA) != 0;
+  cv->w = w; cv->h = h; cv->px = px; cv->pitch = pitch; cv->sp = 0; cv->smoothing = (smoothing & 3) != 0; cv->area = (smoothing & 3) == ORC_AREA; cv->aa = (smoothing & ORC_EDGE_AA) != 0;
   cv->m.a = 1; cv->m.b = 0; cv->m.c = 0; cv->m.d = 1; cv->m.e = 0; cv->m.f = 0;
   cv->y0 = y0 < 0 ? 0 : y0; cv->y1 = y1 > h ? h : y1;
 }
@@ -385,6 +386,54 @@ static int cv_draw_image(orc_canvas* cv, const uint8_t* img, int img_w, int img_
     double c = cv->aa ? dmin(Y + 1.0, R.yh) - dmax(Y, R.yl) : 1.0;
     covy[j] = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
   }
+  /* ORC_AREA ("imageSmoothingQuality = 'high'" read as area averaging, index.js:1419; an OPTION, the contract's default stays
+   * bilinear): per source axis the weight function is a box of width max(1, |k|) centred on the sample position; at |k| <= 1
+   * that is exactly the bilinear pair, beyond it every source pixel under the output pixel contributes by its overlap.
+   * Separable; taps outside the source rectangle clamp to its edge (their weight lands on the edge pixel). */
+  if (cv->area && (fabs(R.kx) > 1.0 || fabs(R.ky) > 1.0)) {
+    for (int j = 0; j < nY; j++) {
+      uint8_t* drow = cv->px + (size_t)(Y0 + j) * cv->pitch + 4 * (size_t)R.X0;
+      for (int i = 0; i < nX; i++) {
+        const double cov = covx[i] * covy[j];
+        if (cov <= 0.0) continue;
+        /* canvas X drives source x (or source y when swapped) */
+        const double Xc = (double)(R.X0 + i) + 0.5, Yc = (double)(Y0 + j) + 0.5;
+        const double sxc = !R.swap ? R.kx * Xc + R.ox : R.kx * Yc + R.ox;
+        const double syc = !R.swap ? R.ky * Yc + R.oy : R.ky * Xc + R.oy;
+        const double wxw = fabs(R.kx) > 1.0 ? fabs(R.kx) : 1.0, wyw = fabs(R.ky) > 1.0 ? fabs(R.ky) : 1.0;
+        const double xlo = sxc - 0.5 * wxw, xhi = sxc + 0.5 * wxw, ylo = syc - 0.5 * wyw, yhi = syc + 0.5 * wyw;
+        const int ix0 = (int)floor(xlo), ix1 = (int)ceil(xhi) - 1, iy0 = (int)floor(ylo), iy1 = (int)ceil(yhi) - 1;
+        double acc[4] = {0, 0, 0, 0};
+        for (int yy = iy0; yy <= iy1; yy++) {
+          const double oy = dmin((double)yy + 1.0, yhi) - dmax((double)yy, ylo);
+          if (oy <= 0.0) continue;
+          const uint8_t* srow = img + (size_t)iclamp(yy, R.cy0, R.cy1) * img_pitch;
+          double racc[4] = {0, 0, 0, 0};
+          for (int xx = ix0; xx <= ix1; xx++) {
+            const double ox = dmin((double)xx + 1.0, xhi) - dmax((double)xx, xlo);
+            if (ox <= 0.0) continue;
+            const uint8_t* s = srow + 4 * (size_t)iclamp(xx, R.cx0, R.cx1);
+            const double a = (double)s[3];
+            racc[0] += ox * (s[0] * a); racc[1] += ox * (s[1] * a); racc[2] += ox * (s[2] * a); racc[3] += ox * a;
+          }
+          acc[0] += oy * racc[0]; acc[1] += oy * racc[1]; acc[2] += oy * racc[2]; acc[3] += oy * racc[3];
+        }
+        const double norm = 1.0 / (wxw * wyw);
+        const double A = acc[3] * norm;
+        uint8_t* d = drow + 4 * (size_t)i;
+        const double keep = 1.0 - cov * (A / 255.0);
+        for (int c = 0; c < 3; c++) {
+          const double P = acc[c] * norm / 255.0;
+          double v = floor(P * cov + d[c] * keep + 0.5);
+          d[c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+        double va = floor(A * cov + d[3] * keep + 0.5);
+        d[3] = (uint8_t)(va < 0 ? 0 : (va > 255 ? 255 : va));
+      }
+    }
+    free(xi0); free(xt); free(covx);
+    return 0;
+  }
   /* identity fast path (what BASELINE's uniform configs reduce to): 1:1, no swap, integer offset */
   int identity = !R.swap && R.kx == 1.0 && R.ky == 1.0 && R.ox == floor(R.ox) && R.oy == floor(R.oy);
 
@@ -494,7 +543,7 @@ static int render_band(int cw, int ch, double ss, const orc_rect* rects, int n,
                        const uint8_t* const* src, const orc_image* imgs, const size_t* pitch,
                        int filter, uint8_t* dst, size_t dst_pitch, int y0, int y1) {
   orc_canvas cv;
-  cv_init(&cv, cw, ch, dst, dst_pitch, ((filter & 0xFF) == ORC_BILINEAR) | (filter & ORC_EDGE_AA), y0, y1);
+  cv_init(&cv, cw, ch, dst, dst_pitch, (filter & 3) | (filter & ORC_EDGE_AA), y0, y1);
   const uint8_t white[4] = {255, 255, 255, 255};
   cv_fill_rect_opaque(&cv, 0, 0, cw, ch, white);
   if (ss != 1.0) cv_scale(&cv, ss, ss);
@@ -575,7 +624,7 @@ ORC_API int orc_render_ops(int canvas_w, int canvas_h, const uint8_t clear_rgba[
                            const orc_image* imgs, const uint8_t* const* src, const size_t* src_pitch,
                            int filter, uint8_t* dst, size_t dst_pitch) {
   orc_canvas cv;
-  cv_init(&cv, canvas_w, canvas_h, dst, dst_pitch, ((filter & 0xFF) == ORC_BILINEAR) | (filter & ORC_EDGE_AA), 0, canvas_h);
+  cv_init(&cv, canvas_w, canvas_h, dst, dst_pitch, (filter & 3) | (filter & ORC_EDGE_AA), 0, canvas_h);
   /* initial canvas colour (premultiplied storage) */
   uint8_t pm[4];
   for (int c = 0; c < 3; c++) pm[c] = (uint8_t)((clear_rgba[c] * clear_rgba[3] + 127) / 255);

@@ -16,7 +16,7 @@ _LIB_PATH = os.environ.get("IST_ORACLE_LIB") or os.path.join(_HERE, "libist_orac
 VERTICAL, HORIZONTAL = 0, 1
 MODE = {"min": 0, "max": 1, "original": 2}
 PLATFORM = {"other": 0, "devtools": 0, "windows": 0, "mac": 0, "ios": 1, "android": 2}
-NEAREST, BILINEAR = 0, 1
+NEAREST, BILINEAR, AREA = 0, 1, 2
 EDGE_AA = 0x100     # OR-ed into a filter: coverage anti-aliasing of fractional rectangle edges
 
 
@@ -125,7 +125,7 @@ def plan(descs, direction, mode="min", gap=0.0, limits=None):
 
 
 def _filter(filter, edge_aa=False):
-    f = {"nearest": 0, "bilinear": 1}[filter] if isinstance(filter, str) else int(filter)
+    f = {"nearest": 0, "bilinear": 1, "area": 2}[filter] if isinstance(filter, str) else int(filter)
     return f | (EDGE_AA if edge_aa else 0)
 
 

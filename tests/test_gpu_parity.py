@@ -387,6 +387,25 @@ def test_edge_antialiasing_known_answer():
         assert (out[..., 3] == 255).all()
 
 
+@pytest.mark.parametrize("direction", ["vertical", "horizontal"])
+def test_area_filter_matches_the_oracle(direction):
+    """IST_FILTER_AREA: minified draws are box-averaged (fp32 sums on the GPU, fp64 in the oracle: +-1 LSB); draws that do not
+    shrink take the bilinear fast paths and are identical to filter 'bilinear'."""
+    px = [U.rand_image(900, 300, 400), U.smooth_image(901, 130, 120), U.rand_image(902, 90, 700, opaque=False), U.rand_image(903, 66, 120)]
+    for opts, ori in (({"filter": "area", "mode": "min"}, None), ({"filter": "area", "mode": "min", "gap": 3}, [6, 1, 3, 8]),
+                      ({"filter": "area", "platform": "android", "maxSide": 256, "maxPixels": 65536}, None),          # ~6x shrink, edge AA on
+                      ({"filter": "area", "platform": "ios", "superSample": 1, "maxSide": 200}, [2, 5, 1, 7])):
+        out, ref = _check(px, direction, opts, orientations=ori)
+    up = [U.rand_image(904, 40, 60), U.rand_image(905, 90, 120)]
+    a = ist.stitch(U.hip_images(up), direction, {"filter": "area", "mode": "max"})["data"]
+    b = ist.stitch(U.hip_images(up), direction, {"filter": "bilinear", "mode": "max"})["data"]
+    assert np.array_equal(a, b)
+    big = [U.smooth_image(906, 3024 // 4, 4032 // 4) for _ in range(3)]                 # integer 3x shrink: the block mean
+    got = ist.stitch(U.hip_images(big), direction, {"filter": "area", "maxSide": 1008 // 3 if direction == "vertical" else 1008, "platform": "ios", "superSample": 1, "edgeAA": False})
+    ref, _, _ = U.oracle_stitch(big, direction, {"filter": "area", "maxSide": 1008 // 3 if direction == "vertical" else 1008, "platform": "ios", "superSample": 1, "edgeAA": False})
+    assert U.max_abs_diff(got["data"], ref) <= 1
+
+
 def test_random_op_lists_against_oracle():
     """Differential test of the op-list surface (what the Canvas shim records): fills, draws under all eight
     axis-aligned transforms at random scales, source rectangles that leave the bitmap, overlapping and translucent

@@ -104,3 +104,35 @@ def test_gap_and_rounding_slack_stay_white():
     out, pd, rl = O.stitch(px, "vertical", "min", 6, filter="nearest")
     assert out.shape == (102, 40, 4)
     assert (out[30:36] == 255).all() and (out[66:72] == 255).all() and (out[0:30, :, :3] == 0).all()
+
+
+def test_area_filter_is_the_exact_block_mean_at_integer_ratios_and_bilinear_when_nothing_shrinks():
+    """IST_FILTER_AREA (opt-in reading of imageSmoothingQuality 'high', index.js:1419): per minified axis a box of width |k|;
+    at integer shrink factors that is the mean of k x k blocks (an independent closed form), PIL's BOX resize agrees within 1."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for k in (2, 3, 5):
+        a = rng.integers(0, 256, (60 * k, 80 * k, 4), dtype=np.uint8)
+        a[..., 3] = 255
+        b = rng.integers(0, 256, (10, 80, 4), dtype=np.uint8)
+        b[..., 3] = 255
+        out, pd, rl = O.stitch([a, b], "vertical", "min", 0, O.lifted_limits(1.0), "area")
+        ref = np.floor(a.reshape(60, k, 80, k, 4).astype(np.float64).mean((1, 3)) + 0.5)
+        assert np.array_equal(out[:60], ref.astype(np.uint8))
+        assert np.array_equal(out[60:], b)                                   # the 1:1 image is untouched
+        box = np.asarray(Image.fromarray(a).resize((80, 60), Image.BOX))
+        assert np.abs(out[:60].astype(int) - box.astype(int)).max() <= 1
+    a = rng.integers(0, 256, (30, 40, 4), dtype=np.uint8)
+    b = rng.integers(0, 256, (45, 60, 4), dtype=np.uint8)
+    up_area, _, _ = O.stitch([a, b], "vertical", "max", 3, O.lifted_limits(1.0), "area")
+    up_bil, _, _ = O.stitch([a, b], "vertical", "max", 3, O.lifted_limits(1.0), "bilinear")
+    assert np.array_equal(up_area, up_bil)
+
+
+def test_hosts_turn_edge_antialiasing_on_for_reference_platform_plans():
+    from imagestitching_amd.stitch import _filter_of, _merge, edge_aa_of
+    assert not edge_aa_of(_merge(None)) and not edge_aa_of(_merge({"gap": 3}))
+    assert edge_aa_of(_merge({"platform": "ios"})) and edge_aa_of(_merge({"platform": "devtools"}))
+    assert not edge_aa_of(_merge({"platform": "ios", "edgeAA": False})) and edge_aa_of(_merge({"edgeAA": True}))
+    assert _filter_of(_merge({"platform": "android", "filter": "area"})) == (2 | 0x100)
+    assert _filter_of(_merge({"filter": "nearest"})) == 0

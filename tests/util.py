@@ -46,13 +46,20 @@ def oracle_limits(opts):
     return lim
 
 
+def edge_aa_of(opts):
+    """the hosts' default (imagestitching_amd.stitch.edge_aa_of, node/index.js edgeAA): on iff a reference platform's plan
+    is requested, unless the caller says otherwise"""
+    v = (opts or {}).get("edgeAA")
+    return ((opts or {}).get("platform") is not None) if v is None else bool(v)
+
+
 def oracle_stitch(pixels, direction, opts=None, orientations=None, threads=4):
     opts = opts or {}
     descs = [{"width": a.shape[1], "height": a.shape[0], "orientation": (orientations[i] if orientations else 1)}
              for i, a in enumerate(pixels)]
     rc, pd, rl = O.plan(descs, direction, opts.get("mode", "min"), opts.get("gap", 0), oracle_limits(opts))
     assert rc == 0, rc
-    img = O.render(pd, rl, descs, pixels, opts.get("filter", "bilinear"), threads, edge_aa=bool(opts.get("edgeAA")))
+    img = O.render(pd, rl, descs, pixels, opts.get("filter", "bilinear"), threads, edge_aa=edge_aa_of(opts))
     return img, pd, rl
 
 
