@@ -113,3 +113,63 @@ def test_lossless_webp_survives_bit_flips():
             b[int(rng.integers(20, len(b)))] ^= 1 << int(rng.integers(0, 8))
         rc, got, _ = _decode(bytes(b))
         assert rc in (0, -6, -7, -1)
+
+
+@pytest.mark.parametrize("size", [(1, 1), (2, 3), (15, 17), (16, 16), (17, 15), (31, 33), (100, 1), (1, 100), (255, 257)])
+@pytest.mark.parametrize("quality,method", [(5, 0), (40, 2), (80, 4), (99, 6)])
+def test_lossy_webp_equals_libwebp(size, quality, method):
+    """VP8 key frames: boolean-coded modes and tokens, intra prediction, inverse WHT/DCT, the loop filter (simple and normal,
+    with segments at method >= 4), then libwebp's fancy chroma upsampling and fixed-point YUV -> RGB: the bytes PIL returns"""
+    h, w = size
+    rng = np.random.default_rng(h * 1000 + w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = ((128 + 90 * np.sin(xx / 37.0 + yy / 91.0))[..., None] * np.array([1, .8, .6]) + 40 * np.sin(xx * yy / 900.)[..., None] + rng.normal(0, 8, (h, w, 3))).clip(0, 255).astype(np.uint8)
+    buf = _webp(a, "RGB", quality=quality, method=method)
+    assert buf[12:16] == b"VP8 "
+    rc, got, o = _decode(buf)
+    assert rc == 0, L.last_error()
+    assert np.array_equal(got, _pil(buf))
+
+
+def test_lossy_webp_with_alpha_sharp_edges_and_a_photo_sized_frame():
+    rng = np.random.default_rng(21)
+    yy, xx = np.mgrid[0:200, 0:300]
+    base = ((128 + 90 * np.sin(xx / 17.0 + yy / 31.0))[..., None] * np.ones(3) + rng.normal(0, 6, (200, 300, 3))).clip(0, 255).astype(np.uint8)
+    for aq in (0, 50, 100):                                        # ALPH chunk: raw, or a VP8L stream, with its predictive filters
+        a = np.dstack([base, ((xx * 3) % 256).astype(np.uint8)])
+        buf = _webp(a, "RGBA", quality=70, alpha_quality=aq, method=4)
+        assert buf[12:16] == b"VP8X" and b"ALPH" in buf
+        rc, got, _ = _decode(buf)
+        assert rc == 0 and np.array_equal(got, _pil(buf)), aq
+    hard = np.dstack([base, np.where(xx % 50 < 25, 0, 255).astype(np.uint8)])
+    for kw in ({}, {"exact": True}):
+        buf = _webp(hard, "RGBA", quality=80, **kw)
+        rc, got, _ = _decode(buf)
+        assert rc == 0 and np.array_equal(got, _pil(buf))
+    sharp = np.zeros((128, 160, 3), np.uint8)
+    sharp[::7] = 255
+    sharp[:, ::5, 0] = 255
+    sharp[40:80, 60:100] = (255, 0, 0)
+    for q in (20, 75, 100):
+        buf = _webp(sharp, "RGB", quality=q)
+        rc, got, _ = _decode(buf)
+        assert rc == 0 and np.array_equal(got, _pil(buf)), q
+    big = np.asarray(Image.fromarray(base).resize((1008, 756)))     # 63 x 48 macroblocks (ragged right column)
+    buf = _webp(big, "RGB", quality=85)
+    rc, got, _ = _decode(buf)
+    assert rc == 0 and np.array_equal(got, _pil(buf))
+
+
+def test_lossy_webp_truncations_and_bit_flips_are_survived():
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:48, 0:64]
+    a = np.stack([(xx * 4) % 256, (yy * 5) % 256, ((xx + yy) * 3) % 256], -1).astype(np.uint8)
+    buf = bytearray(_webp(a, "RGB", quality=60))
+    for cut in range(12, len(buf), 23):
+        rc, _, _ = _decode(bytes(buf[:cut]))
+        assert rc in (0, -6)                                    # a truncated token partition decodes zeros: pixels or an error, never a fault
+    for _ in range(300):
+        b = bytearray(buf)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(20, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        assert _decode(bytes(b))[0] in (0, -6, -7, -1)
