@@ -15,6 +15,9 @@
  * drawImage / fillRect only RECORD an op (with the CTM of that moment); an export or getImageData triggers ONE fused
  * launch over the recorded list through native.render().  getImageData renders just the requested region and keeps
  * the list (the reference calls getImageData(0,0,1,1) after every image purely as a flush, index.js:1559-1566).
+ * Fractional rectangle edges are anti-aliased by area coverage, as a Canvas raster does (IST_FILTER_EDGE_AA): the page's
+ * default plans scale the canvas by superSample 2.2 / 2.6 (index.js:1363,1426-1428), so its edges are fractional as a rule.
+ * makeEnvironment({edgeAA: false}) selects the pixel-centre rule instead.
  */
 const path = require('path');
 const native = require(path.join(__dirname, 'imagestitch.node'));
@@ -133,7 +136,7 @@ class ShimCanvas {
                                 bitmaps: bitmaps.map((b) => [b.width, b.height]) });
       return Buffer.alloc(Math.min((reg ? reg.w * reg.h : this._w * this._h) * 4, 1 << 16));   // placeholder pixels
     }
-    return native.render(this._w, this._h, new Uint8Array([0, 0, 0, 0]), packed, bitmaps, smoothing ? 1 : 0, reg, !!asPng);
+    return native.render(this._w, this._h, new Uint8Array([0, 0, 0, 0]), packed, bitmaps, (smoothing ? 1 : 0) | (this._env.edgeAA === false ? 0 : 0x100), reg, !!asPng);
   }
 }
 
@@ -141,8 +144,8 @@ class ShimCanvas {
  * A `wx` + canvas-node environment for running the reference page.  files: {path: {width, height, data, opaque?,
  * orientation?}} are the "decoded bitmaps" (decode is outside the path: SURVEY.md section 8f rank 3).
  */
-function makeEnvironment({ platform = 'devtools', files = {}, storage = {}, recordOnly = false, outDir = null } = {}) {
-  const env = { platform, files, storage, exports: {}, toasts: [], nextExport: 0, recordOnly, recorded: [], outDir };
+function makeEnvironment({ platform = 'devtools', files = {}, storage = {}, recordOnly = false, outDir = null, edgeAA = true } = {}) {
+  const env = { platform, files, storage, exports: {}, toasts: [], nextExport: 0, recordOnly, recorded: [], outDir, edgeAA };
   env.exportCanvas = (canvas, o) => {
     const w = Math.max(1, Math.floor(o.width || canvas.width)), h = Math.max(1, Math.floor(o.height || canvas.height));
     if ((o.destWidth && o.destWidth !== w) || (o.destHeight && o.destHeight !== h)) throw new Error('export rescale is outside the stitch path');

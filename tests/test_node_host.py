@@ -132,7 +132,7 @@ def test_canvas_shim_pixels_match_oracle(tmp_path):
     for opts in ({"filter": "nearest"}, {"filter": "bilinear", "platform": "devtools"}, {"filter": "bilinear", "mode": "original", "gap": 9}):
         rc, out, err = _cli({"mode": "shim", "direction": "vertical", "opts": opts, "images": imgs, "out": str(tmp_path / "o.rgba")}, tmp_path)
         assert rc == 0, err
-        ref, pd, _ = U.oracle_stitch(px, "vertical", opts)
+        ref, pd, _ = U.oracle_stitch(px, "vertical", dict(opts, edgeAA=True))      # the shim is a Canvas: fractional edges are anti-aliased
         got = np.fromfile(tmp_path / "o.rgba", np.uint8).reshape(out["height"], out["width"], 4)
         assert got.shape == ref.shape
         assert U.max_abs_diff(got, ref) <= (0 if opts["filter"] == "nearest" else 1)
