@@ -18,6 +18,7 @@ struct ist_ctx {
   void* scratch_src = nullptr; size_t scratch_src_bytes = 0;
   void* scratch_dst = nullptr; size_t scratch_dst_bytes = 0;
   void* scratch_dec = nullptr; size_t scratch_dec_bytes = 0;   // JPEG coefficient / sample planes of ist_decode_files_device
+  void* scratch_huff = nullptr; size_t scratch_huff_bytes = 0; // GPU Huffman decoder: scans, tables, per-subsequence state
   std::mutex mu;                         // one host-path stitch in flight per context (index.js:772 isStitching)
   int png_level = 1;                     // 1: Paeth + run-length + Huffman; 0: stored deflate blocks (ist_ctx_set_png_level)
   std::unique_ptr<ist::Stager> stager;   // pinned staging ring, built on first use

@@ -96,7 +96,8 @@ std::vector<int16_t> jpeg_dense_coefficients(const JpegComp& c);
 // dense device planes (blocks_x*blocks_y*64 int16 each) the reconstruction kernels read.  ok[i] = 0 when image i failed
 // the end-of-scan validation: the caller then decodes that image on the host.  Synchronises `stream`.
 struct JpegGpuItem { const JpegImage* J; const JpegGpuScan* S; int16_t* d_coef[3]; };
-int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<uint8_t>* ok, void* stream);
+// scratch / scratch_bytes (optional): a grow-only device buffer the caller keeps across calls
+int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<uint8_t>* ok, void* stream, void** scratch = nullptr, size_t* scratch_bytes = nullptr);
 
 }  // namespace ist
 

@@ -14,6 +14,8 @@
 //     and because of self-synchronisation almost all others are too.  When a pass changes no exit state the states are
 //     a fixed point, hence (by induction from subsequence 0) all exact; a subsequence whose start state did not change
 //     since it was last decoded keeps its result, so the later passes touch only the few that are still settling;
+//   * the passes of one workgroup (256 neighbouring subsequences) run INSIDE one launch, exit states exchanged through
+//     LDS; only the hand-over between workgroups needs another launch (ist_jpeg_sync_kernel);
 //   * an exclusive scan of the per-subsequence block counts gives every thread the index of its first block; a last
 //     pass decodes once more and writes the coefficients straight into the dense planes in HBM; the DC differences
 //     are integrated per component in decoding order by a block-wide scan.
@@ -141,25 +143,59 @@ struct SyncArgs {
   uint32_t* changed; int32_t n_sub_total; int32_t pass; int32_t sub_bits;
 };
 
+// One LAUNCH = as many synchronisation passes as its workgroup needs: the 256 subsequences of a workgroup exchange exit
+// states through LDS and iterate (re-decode whoever's start state changed, barrier) until none of them changes, so a
+// chain of out-of-phase subsequences is chased to its end inside one launch instead of one subsequence per
+// host-synchronised pass.  Across workgroups the first thread starts from the exit state its left neighbour reached in
+// the PREVIOUS launch; a launch in which no workgroup's last exit state changed is the global fixed point.  (The
+// "overflow" idea of the published scheme, restated for a barrier-synchronised workgroup.)  Measured on nine 12 MP
+// photos: fixed point after 2-3 launches instead of 7.
+constexpr int kInnerPasses = 48;
+
 __global__ __launch_bounds__(256) void ist_jpeg_sync_kernel(const SyncArgs A) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= A.n_sub_total) return;
-  const DevImg& I = A.imgs[A.sub_img[g]];
-  const uint32_t i = static_cast<uint32_t>(g - I.first_sub);
-  State S;
-  if (i == 0) { S.p = 0; S.c = 0; S.z = 0; }
-  else if (A.pass == 0) { S.p = i * static_cast<uint32_t>(A.sub_bits); S.c = 0; S.z = 0; }
-  else { S.p = A.in_p[g - 1]; S.c = A.in_cz[g - 1] >> 8; S.z = A.in_cz[g - 1] & 255u; }
-  // a subsequence whose start state is the one it was decoded from last time keeps its result (most of them, from the
-  // second pass on): start states are remembered in start_p / start_cz
-  if (A.pass > 0 && A.start_p[g] == S.p && A.start_cz[g] == ((S.c << 8) | S.z)) { A.out_p[g] = A.in_p[g]; A.out_cz[g] = A.in_cz[g]; return; }
-  A.start_p[g] = S.p; A.start_cz[g] = (S.c << 8) | S.z;
-  const uint64_t end = static_cast<uint64_t>(i + 1) * static_cast<uint64_t>(A.sub_bits);
-  const uint32_t limit = static_cast<uint32_t>(end < static_cast<uint64_t>(I.bits) ? end : static_cast<uint64_t>(I.bits));
-  const uint32_t done = run<false>(I, S, limit, 0);
-  const uint32_t cz = (S.c << 8) | S.z;
-  if (A.pass > 0 && (A.in_p[g] != S.p || A.in_cz[g] != cz)) *A.changed = 1u;
-  A.out_p[g] = S.p; A.out_cz[g] = cz; A.nblk[g] = done;
+  __shared__ uint32_t ex_p[256], ex_cz[256];
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x * blockDim.x + tid;
+  const bool live = g < A.n_sub_total;
+  const DevImg* Ip = live ? &A.imgs[A.sub_img[g]] : &A.imgs[0];
+  const uint32_t i = live ? static_cast<uint32_t>(g - Ip->first_sub) : 0u;
+  uint32_t limit = 0;
+  if (live) {
+    const uint64_t end = static_cast<uint64_t>(i + 1) * static_cast<uint64_t>(A.sub_bits);
+    limit = static_cast<uint32_t>(end < static_cast<uint64_t>(Ip->bits) ? end : static_cast<uint64_t>(Ip->bits));
+  }
+  // what this subsequence last decoded from, and to (carried across launches in start_* / in_*)
+  bool have = live && A.pass > 0;
+  uint32_t st_p = have ? A.start_p[g] : 0u, st_cz = have ? A.start_cz[g] : 0u;
+  uint32_t my_p = have ? A.in_p[g] : 0u, my_cz = have ? A.in_cz[g] : 0u, nb = have ? A.nblk[g] : 0u;
+  bool settled = false;
+  for (int it = 0; it < kInnerPasses; ++it) {
+    uint32_t sp = 0, scz = 0;
+    if (live && i != 0) {                            // (the first subsequence of an image starts from the true state 0, 0, 0)
+      if (it == 0 || tid == 0) {                     // from the previous launch (or, in the very first pass, a guess: a block starts here)
+        if (A.pass == 0) { sp = i * static_cast<uint32_t>(A.sub_bits); scz = 0; }
+        else { sp = A.in_p[g - 1]; scz = A.in_cz[g - 1]; }
+      } else { sp = ex_p[tid - 1]; scz = ex_cz[tid - 1]; }      // from the left neighbour, this launch
+    }
+    const bool redo = live && !(have && st_p == sp && st_cz == scz);
+    if (redo) {
+      State S; S.p = sp; S.c = scz >> 8; S.z = scz & 255u;
+      nb = run<false>(*Ip, S, limit, 0);
+      my_p = S.p; my_cz = (S.c << 8) | S.z;
+      st_p = sp; st_cz = scz; have = true;
+    }
+    __syncthreads();                                 // every thread has read its neighbour's previous exit state
+    ex_p[tid] = my_p; ex_cz[tid] = my_cz;
+    if (!__syncthreads_or(redo ? 1 : 0)) { settled = true; break; }
+  }
+  if (!live) return;
+  // the launch changed something the NEXT workgroup depends on (or ran out of inner passes): not the fixed point yet
+  const bool last = tid == 255 || g == A.n_sub_total - 1;
+  if (A.pass == 0 || !settled || (last && (A.in_p[g] != my_p || A.in_cz[g] != my_cz))) {
+    if (A.pass == 0 ? (tid == 0) : true) *A.changed = 1u;
+  }
+  A.out_p[g] = my_p; A.out_cz[g] = my_cz; A.nblk[g] = nb;
+  A.start_p[g] = st_p; A.start_cz[g] = st_cz;
 }
 
 struct WriteArgs { const DevImg* imgs; const uint16_t* sub_img; const uint32_t* p; const uint32_t* cz; const uint32_t* blk_excl; int32_t n_sub_total; int32_t sub_bits; };
@@ -232,7 +268,7 @@ __global__ __launch_bounds__(1024) void ist_jpeg_dc_kernel(const DevImg* imgs) {
 
 }  // namespace
 
-int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<uint8_t>* ok, void* stream_) {
+int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<uint8_t>* ok, void* stream_, void** scratch, size_t* scratch_bytes) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const size_t n_img = items.size();
   static const bool timing = std::getenv("IST_TIMING") != nullptr;
@@ -288,9 +324,21 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   const size_t o_p0 = take(4 * static_cast<size_t>(ns)), o_p1 = take(4 * static_cast<size_t>(ns)), o_cz0 = take(4 * static_cast<size_t>(ns)), o_cz1 = take(4 * static_cast<size_t>(ns));
   const size_t o_sp = take(4 * static_cast<size_t>(ns)), o_scz = take(4 * static_cast<size_t>(ns));
   const size_t o_nblk = take(4 * static_cast<size_t>(ns)), o_excl = take(4 * (static_cast<size_t>(ns) + 1)), o_flag = take(4), o_err = take(4 * n_img);
+  // the caller's grow-only scratch (a context keeps it across calls: no allocation, and no implicit device synchronisation
+  // of a free, per call), or a one-off allocation
   uint8_t* d = nullptr;
-  JG_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
-  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
+  struct Free { void* p; ~Free() { if (p) (void)hipFree(p); } } fr{nullptr};
+  if (scratch && scratch_bytes) {
+    if (*scratch_bytes < off) {
+      if (*scratch) { (void)hipFree(*scratch); *scratch = nullptr; *scratch_bytes = 0; }
+      JG_HIP(hipMalloc(scratch, off + off / 4));
+      *scratch_bytes = off + off / 4;
+    }
+    d = static_cast<uint8_t*>(*scratch);
+  } else {
+    JG_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
+    fr.p = d;
+  }
   std::vector<uint16_t> sub_img(static_cast<size_t>(ns));
   for (size_t k = 0; k < n_img; ++k) {
     const JpegGpuScan& S = *items[k].S;
@@ -328,7 +376,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     hipLaunchKernelGGL(ist_jpeg_sync_kernel, dim3(grid), dim3(256), 0, stream, A);
     JG_HIP(hipGetLastError());
     cur ^= 1;
-    if (pass == 0) continue;
+    if (pass == 0) continue;                       // (the first launch starts from guesses: a second one always runs)
     uint32_t flag = 1;
     JG_HIP(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, stream));
     JG_HIP(hipStreamSynchronize(stream));

@@ -99,6 +99,7 @@ void ist_ctx_destroy(ist_ctx* ctx) {
   if (ctx->scratch_src) (void)hipFree(ctx->scratch_src);
   if (ctx->scratch_dst) (void)hipFree(ctx->scratch_dst);
   if (ctx->scratch_dec) (void)hipFree(ctx->scratch_dec);
+  if (ctx->scratch_huff) (void)hipFree(ctx->scratch_huff);
   ctx->stager.reset();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -510,7 +511,7 @@ int decode_device_stage(ist_ctx* ctx, std::vector<Dec>& dec, const uint8_t* cons
       items.push_back(it); who.push_back(i);
     }
     std::vector<uint8_t> okv;
-    rc = jpeg_gpu_entropy_decode(items, &okv, ctx->stream);
+    rc = jpeg_gpu_entropy_decode(items, &okv, ctx->stream, &ctx->scratch_huff, &ctx->scratch_huff_bytes);
     if (rc) return rc;
     for (size_t k = 0; k < who.size(); ++k) {
       if (okv[k]) continue;

@@ -220,7 +220,7 @@ def test_gpu_entropy_decoder_agrees_with_the_host_decoder_on_mutated_scans(tmp_p
 
 def test_random_file_sets_through_the_whole_pipeline(tmp_path):
     """End-to-end differential test: random sets of files (baseline / progressive JPEG with EXIF orientations, PNG with
-    and without alpha, BMP, GIF), random direction / mode / gap / filter, through ist_stitch_files_png (GPU Huffman,
+    and without alpha, BMP, GIF, lossless and lossy WebP with EXIF orientations), random direction / mode / gap / filter, through ist_stitch_files_png (GPU Huffman,
     reconstruction, stitch, compressed PNG) against PIL's decoders + the CPU oracle."""
     rng = np.random.default_rng(31337)
     for case in range(80):
@@ -229,7 +229,7 @@ def test_random_file_sets_through_the_whole_pipeline(tmp_path):
         for k in range(n):
             h, w = int(rng.integers(8, 200)), int(rng.integers(8, 200))
             a = _photo(1000 + 10 * case + k, h, w)
-            kind = int(rng.integers(0, 6))
+            kind = int(rng.integers(0, 8))
             p = tmp_path / ("c%d_%d" % (case, k))
             o = 1
             if kind <= 1:
@@ -247,8 +247,18 @@ def test_random_file_sets_through_the_whole_pipeline(tmp_path):
                 p = p.with_suffix(".png"); Image.fromarray(rgba, "RGBA").save(p, "PNG")
             elif kind == 4:
                 p = p.with_suffix(".bmp"); Image.fromarray(a).save(p, "BMP")
-            else:
+            elif kind == 5:
                 p = p.with_suffix(".gif"); Image.fromarray(a).convert("P", palette=Image.ADAPTIVE).save(p, "GIF")
+            else:                                   # WebP: lossless RGBA or lossy RGB, orientation in the container's EXIF chunk
+                o = int(rng.integers(1, 9))
+                ex = Image.Exif()
+                ex[0x0112] = o
+                p = p.with_suffix(".webp")
+                if kind == 6:
+                    rgba = np.concatenate([a, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], -1)
+                    Image.fromarray(rgba, "RGBA").save(p, "WEBP", lossless=True, exact=True, exif=ex.tobytes())
+                else:
+                    Image.fromarray(a).save(p, "WEBP", quality=int(rng.integers(30, 96)), exif=ex.tobytes())
             bm = np.array(Image.open(p).convert("RGBA"))
             bm[bm[..., 3] == 0] = 0
             paths.append(str(p)); bitmaps.append(bm); orients.append(o)
