@@ -35,6 +35,22 @@ KERNEL_SOURCES = ["imagestitching_amd/csrc/ist_kernels.hip", "imagestitching_amd
                   "imagestitching_amd/csrc/ist_launch.h"]
 
 
+class StdoutGuard:
+    """Native libraries print banners to fd 1 (RCCL: its version block at communicator creation).  Everything written to
+    stdout while the guard is active goes to stderr; emit() restores fd 1 and prints the ONE JSON line of the contract."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        print(line, flush=True)
+
+
 def kernel_source_sha():
     """identifies the kernel + tiling a PMC measurement belongs to (profiles/*_pmc.json carry it)"""
     h = hashlib.sha256()
@@ -262,7 +278,7 @@ def run_single(args):
         "d2d_copy_yardstick": yard,
         "extra": extra,
     }
-    print(json.dumps(line))
+    args.out.emit(json.dumps(line))
 
 
 def d2d_yardstick(nbytes, dev, torch):
@@ -483,7 +499,7 @@ def run_sharded(args):
                                       "xGMI is point to point: a step is bounded below by busiest_link_bytes / one link's rate.",
                       "replicas_no_exchange": {"MPs": round(world * mp / t_rep, 1), "scaling": "weak", "note": "every GPU stitches its own whole 9x12 MP job"}},
         }
-        print(json.dumps(line))
+        args.out.emit(json.dumps(line))
     dist.destroy_process_group()
 
 
@@ -500,6 +516,7 @@ def main():
     if args.print_kernel_sha:
         print(kernel_source_sha())
         return
+    args.out = StdoutGuard()
     if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("IST_BENCH_FORCE_SHARDED"):
         run_sharded(args)
     else:

@@ -14,6 +14,7 @@
 // Exactly ONE frame header per file (a second SOF is JERR_SOF_DUPLICATE in libjpeg): every buffer below is sized from it.
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "ist_internal.h"
@@ -148,7 +149,7 @@ int exif_orientation(const uint8_t* d, size_t n) {
 
 }  // namespace
 
-int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, bool header_only, JpegGpuScan* gs) {
+static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool header_only, JpegGpuScan* gs) {
   if (!f || n < 4 || f[0] != 0xFF || f[1] != 0xD8) return fail(IST_E_DECODE, "not a JPEG file");
   Huff dc[4], ac[4];
   uint16_t qt[4][64]; bool have_q[4] = {false, false, false, false};
@@ -442,6 +443,12 @@ int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, boo
   if (!have_sof) return fail(IST_E_DECODE, "JPEG without a frame header");
   if (!header_only && J->scans == 0) return fail(IST_E_DECODE, "JPEG without image data");
   return IST_OK;
+}
+
+// the C boundary never lets an exception through: a header may announce planes the host cannot allocate
+int jpeg_parse_and_entropy_decode(const uint8_t* f, int64_t n, JpegImage* J, bool header_only, JpegGpuScan* gs) {
+  try { return jpeg_parse_inner(f, n, J, header_only, gs); }
+  catch (const std::bad_alloc&) { return fail(IST_E_NOMEM, "out of memory while decoding the JPEG"); }
 }
 
 std::vector<int16_t> jpeg_dense_coefficients(const JpegComp& c) {
