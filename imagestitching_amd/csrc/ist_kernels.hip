@@ -34,12 +34,7 @@ typedef u32x4 u32x4_a4 __attribute__((aligned(4)));   // RGBA rows are only pixe
 typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
 
 #define IST_DEV static __device__ __forceinline__
-#ifndef IST_X_EARLY
-#define IST_X_EARLY 1     // experiment switches (tools/ab_build.sh builds the alternatives)
-#endif
-#ifndef IST_X_SU
-#define IST_X_SU 8
-#endif
+
 
 IST_DEV u32x4 ld16(const uint8_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(p)); }
 IST_DEV void st16(uint8_t* p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a4*>(p)); }
@@ -421,10 +416,8 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
   // workgroup that has just started then already has its footprint in flight while it computes them.
   int fy0, fh;
   foot(0, &fy0, &fh);
-#if IST_X_EARLY
   if (!fresh) __syncthreads();                            // every wave is done reading the previous tile's footprint
   stage(fy0, fh, lds);
-#endif
   // Lane l owns pixels X0 + l + 64 p (p = 0..3), NOT 4 neighbours: consecutive lanes then read LDS words |kx| apart
   // instead of 4|kx| apart (measured: 77 % of the LDS cycles were bank conflicts with the neighbour mapping), and each
   // of the 4 stores of a wave is still 256 contiguous bytes.  Lanes past a ragged right edge keep computing (on the
@@ -466,15 +459,10 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
     }
   };
   for (int s = 0; s < nsub; ++s) {
-#if IST_X_EARLY
     if (s > 0) {
       __syncthreads();                                    // every wave is done reading the previous stage
       stage(fy0, fh, lds);
     }
-#else
-    if (s > 0 || !fresh) __syncthreads();
-    stage(fy0, fh, lds);
-#endif
     int ny0 = 0, nh = 0;
     if (s + 1 < nsub) foot(s + 1, &ny0, &nh);             // (tap arithmetic under the loads)
     const int Ya = Y0 + s * sub_h, Yb = min(Ya + sub_h, Y1);
@@ -509,7 +497,7 @@ IST_DEV bool tile_swap_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, int
   // ---- stage transposed: work item = (source row r, 4-pixel chunk c)
   const int chunks = (fw + 3) >> 2;
   const int total = chunks * fh;
-  constexpr int SU = IST_X_SU;                  // 16-B loads in flight per lane: a 64 x 64 tile's patch (<= 2048 chunks) is ONE round
+  constexpr int SU = 8;                  // 16-B loads in flight per lane: a 64 x 64 tile's patch (<= 2048 chunks) is ONE round
   for (int i0 = 0; i0 < total; i0 += 256 * SU) {
     u32x4 v[SU];
 #pragma unroll

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 CSV output (kernel trace + separate PMC passes) of `bench.py` into a small text file for
-profiles/.  usage: summarize.py <trace_dir> <fetch_dir> <write_dir> <label> <out.json> <trace counts e.g. 110,60,60,60> <pmc counts e.g. 22,12,12,12>
+profiles/.  usage: summarize.py <trace_dir> <fetch_dir> <write_dir> <label> <out.json> <trace counts total:timed e.g. 510:100,460:50,460:50,460:50> <pmc counts e.g. 422:20,412:10,412:10,412:10>
 bench.py runs its configurations back to back (uniform vertical, uniform horizontal, mixed vertical, mixed horizontal);
 consecutive dispatches of the same kernel + grid are one configuration."""
 import csv
@@ -18,14 +18,24 @@ def rows(d, pat):
 
 def groups(rs, value, counts):
     """split the ist_stitch dispatches, in time order, into bench configurations of known dispatch counts
-    (bench.py: warmup + steps per configuration)"""
+    (bench.py: pre-roll + warmup + steps per configuration); a count "total:timed" keeps only the last `timed` dispatches of
+    the group (the timed steps, after the untimed pre-roll and warm-up)"""
     mine = [r for r in rs if "ist_stitch" in r["Kernel_Name"]]
     out, i = [], 0
     for c in counts:
-        part = mine[i:i + c]
-        i += c
+        total, timed = (c, c) if isinstance(c, int) else c
+        part = mine[i:i + total][-timed:]
+        i += total
         if part:
             out.append([(part[0]["Kernel_Name"], part[0].get("Grid_Size") or part[0].get("Grid_Size_X")), [value(r) for r in part]])
+    return out
+
+
+def parse_counts(text):
+    out = []
+    for tok in text.split(","):
+        a, _, b = tok.partition(":")
+        out.append((int(a), int(b or a)))
     return out
 
 
@@ -38,7 +48,7 @@ def main():
     kt = sorted(rows(trace, "*_kernel_trace.csv"), key=lambda r: int(r["Start_Timestamp"]))
     out += ["", "## per bench configuration (kernel trace), durations in us"]
     machine = {}
-    for i, (key, d) in enumerate(groups(kt, lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), [int(x) for x in sys.argv[6].split(",")])):
+    for i, (key, d) in enumerate(groups(kt, lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), parse_counts(sys.argv[6]))):
         d2 = sorted(d)
         name = NAMES[i] if i < len(NAMES) else "config %d" % i
         out.append("%-42s kernel=%s grid=%s n=%d avg=%.2f median=%.2f min=%.2f max=%.2f" % (name, key[0].split("(")[0][-40:], key[1], len(d), sum(d) / len(d) / 1e3, d2[len(d2) // 2] / 1e3, d2[0] / 1e3, d2[-1] / 1e3))
@@ -46,7 +56,7 @@ def main():
     for cname, d, scale, note in (("FETCH_SIZE", fetch, 2.0, "x2: on gfx950 FETCH_SIZE reports 1/2 of a 16-B/lane stream, MI355X_MICROARCH.md HBM section"), ("WRITE_SIZE", write, 1.0, "exact for 16-B/lane streaming stores")):
         cc = sorted(rows(d, "*_counter_collection.csv"), key=lambda r: int(r["Start_Timestamp"]))
         out += ["", "## --pmc %s (own pass; KB per dispatch; %s)" % (cname, note)]
-        for i, (key, v) in enumerate(groups(cc, lambda r: float(r["Counter_Value"]), [int(x) for x in sys.argv[7].split(",")])):
+        for i, (key, v) in enumerate(groups(cc, lambda r: float(r["Counter_Value"]), parse_counts(sys.argv[7]))):
             name = NAMES[i] if i < len(NAMES) else "config %d" % i
             mean = sum(v) / len(v)
             out.append("%-42s n=%d mean=%.1f KB -> %.2f MB per launch" % (name, len(v), mean, scale * mean * 1024 / 1e6))

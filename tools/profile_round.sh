@@ -9,5 +9,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_tra
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_fetch -o f -- python3 $R/bench.py --steps 20 --warmup 2 --kernels-only > $R/gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_write -o w -- python3 $R/bench.py --steps 20 --warmup 2 --kernels-only > $R/gpurun_out/${TAG}_write.log 2>&1
 cd $R
-python3 profiles/summarize.py gpurun_out/${TAG}_trace gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write "$LABEL; commands: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --kernels-only ; rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 20 --warmup 2 --kernels-only" gpurun_out/${TAG}_pmc.json 110,60,60,60 22,12,12,12 > gpurun_out/${TAG}_summary.txt
+python3 profiles/summarize.py gpurun_out/${TAG}_trace gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write "$LABEL; commands: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --kernels-only ; rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 20 --warmup 2 --kernels-only" gpurun_out/${TAG}_pmc.json 510:100,460:50,460:50,460:50 422:20,412:10,412:10,412:10 > gpurun_out/${TAG}_summary.txt
 cat gpurun_out/${TAG}_summary.txt
