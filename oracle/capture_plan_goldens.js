@@ -11,6 +11,10 @@
  * place via require(); nothing from them is copied into this repo - only call traces (data) are stored.
  *
  *   node oracle/capture_plan_goldens.js [/root/reference] [tests/golden/plan_goldens.json]
+ *   node oracle/capture_plan_goldens.js /root/reference tests/golden/plan_goldens_random.json --random 400 20261004
+ *       instead of the named cases: N seeded random cases (1-12 images of 1..9000 px, EXIF orientations, file sizes around
+ *       the bigTask threshold, every platform, stored canvas limits from tiny to lifted, both directions, the three modes,
+ *       integer and fractional gaps)
  */
 'use strict';
 const path = require('path');
@@ -190,6 +194,42 @@ cases.push({ name: 'G9_tiny_1x1_and_wide', platform: 'devtools', canvasLimit: LI
 cases.push({ name: 'G9_single_android', platform: 'android', direction: 'horizontal', images: [{ w: 6000, h: 4000 }] });
 cases.push({ name: 'G9_gap20_h_original_ios', platform: 'ios', direction: 'horizontal', mode: 'original', gap: 20, images: MIXED7 });
 cases.push({ name: 'G9_stored_limit_android_8192', platform: 'android', canvasLimit: { size: 8192, pixels: 8192 * 8192 }, direction: 'vertical', gap: 5, images: MIXED9 });
+
+// ---- seeded random cases (xorshift32: the same list on every run) ---------------------------------------------
+function randomCases(n, seed) {
+  let s = seed >>> 0 || 1;
+  const rnd = () => { s ^= s << 13; s >>>= 0; s ^= s >>> 17; s ^= s << 5; s >>>= 0; return s / 4294967296; };
+  const ri = (lo, hi) => lo + Math.floor(rnd() * (hi - lo + 1));
+  const pick = (a) => a[Math.floor(rnd() * a.length)];
+  const dim = () => { const r = rnd(); return r < 0.1 ? ri(1, 8) : r < 0.55 ? ri(9, 1200) : ri(1201, 9000); };
+  const out = [];
+  for (let k = 0; k < n; k++) {
+    const count = rnd() < 0.25 ? ri(7, 12) : ri(1, 6);
+    const same = rnd() < 0.2 ? { w: dim(), h: dim() } : null;
+    const images = [];
+    for (let i = 0; i < count; i++) {
+      const im = same ? Object.assign({}, same) : { w: dim(), h: dim() };
+      if (rnd() < 0.3) im.orientation = ri(1, 8);
+      if (rnd() < 0.3) im.fileSize = pick([0, 1, 3 << 20, 9 << 20, 13 << 20, (25 << 20) - 1, 25 << 20, 40 << 20]);
+      images.push(im);
+    }
+    const c = { name: 'R' + k, platform: pick(['devtools', 'android', 'ios']), direction: pick(['vertical', 'horizontal']), images };
+    const m = pick(['', 'min', 'max', 'original']);
+    if (m) c.mode = m;
+    const g = rnd();
+    if (g < 0.5) c.gap = ri(0, 20); else if (g < 0.65) c.gap = Math.round(rnd() * 2000) / 100;
+    const l = rnd();
+    if (l < 0.2) c.canvasLimit = LIFT;
+    else if (l < 0.45) { const size = pick([64, 500, 1024, 2048, 4096, 8192, 12288, 16384, 32767]); c.canvasLimit = { size, pixels: pick([size * size, size * 1024, 4096 * 2048, 1 << 20, 1 << 24, 1 << 28]) }; }
+    out.push(c);
+  }
+  return out;
+}
+if (process.argv[4] === '--random') {
+  const list = randomCases(parseInt(process.argv[5] || '400', 10), parseInt(process.argv[6] || '1', 10));
+  cases.length = 0;
+  for (const c of list) cases.push(c);
+}
 
 (async () => {
   const out = { generator: 'oracle/capture_plan_goldens.js', reference: 'Iamctb/ImageStitching miniprogram/pages/index/index.js (run unmodified under Node ' + process.version + ' with a stub wx)', cases: [] };
