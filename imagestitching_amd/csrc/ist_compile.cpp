@@ -136,6 +136,15 @@ struct CompileKnobs {
   int lds_tile_w = 0;                  // 0: pick 256 / 128 / 64 per cell; IST_LDS_TILE_W pins one width
   int64_t lds_budget_words = 6144;     // 24 KiB footprint budget per workgroup
   bool no_lds = false, no_bands = false, no_tile_table = false, no_sort = false;
+  // SAMPLE_STREAM (measured on MI355X, tools/exp_paths.py): a ring of 2 row pairs per wave beats 3 and 4 (LDS per
+  // workgroup decides the workgroups per CU), tiles 8 rows tall beat 4 / 16 / 32, 256-pixel-wide tiles beat narrower ones
+  // wherever they fit 48 KiB, and the path beats the staged one from |ky| = 2 up (9 x 12 MP onto the iOS canvas, k = 2.2:
+  // 86 us against 94 us; k = 4: 47 against 74; the Android canvas, k = 6.65: 26 against 39).  Below 2 the staged path
+  // re-uses the source rows that neighbouring output rows share and wins (k = 1.33: 119 us against 126-140 us).
+  int stream = 2;                      // ring depth (0: never stream)
+  int stream_h = 8;                    // tile height
+  double stream_min_k = 2.0;           // stream for |ky| >= this
+  int64_t stream_cap = 12288;          // LDS words per workgroup that decide the tile width
 };
 bool tuning_mode() {
   static const bool on = [] { const char* e = std::getenv("IST_TUNING"); return e && *e && std::strcmp(e, "0") != 0; }();
@@ -150,6 +159,10 @@ static CompileKnobs read_knobs() {
   if ((e = std::getenv("IST_LDS_BUDGET")) != nullptr) k.lds_budget_words = std::max<int64_t>(256, std::atoll(e) / 4);
   if ((e = std::getenv("IST_LDS_RUN")) != nullptr) k.lds_run = std::min(16, std::max(1, std::atoi(e)));
   if ((e = std::getenv("IST_LDS_TILE_W")) != nullptr) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) k.lds_tile_w = v; }
+  if ((e = std::getenv("IST_STREAM")) != nullptr) k.stream = std::min(8, std::max(0, std::atoi(e)));
+  if ((e = std::getenv("IST_STREAM_MIN_K")) != nullptr) k.stream_min_k = std::atof(e);
+  if ((e = std::getenv("IST_STREAM_CAP")) != nullptr) k.stream_cap = std::max<int64_t>(1024, std::atoll(e) / 4);
+  if ((e = std::getenv("IST_STREAM_H")) != nullptr) k.stream_h = std::min(64, std::max(4, std::atoi(e) & ~3));
   k.no_lds = std::getenv("IST_NO_LDS") != nullptr;
   k.no_bands = std::getenv("IST_NO_BANDS") != nullptr;
   k.no_tile_table = std::getenv("IST_NO_TILE_TABLE") != nullptr;
@@ -338,11 +351,25 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
       const DevOp& r = out->ops[cell.op];
       const double akx = std::fabs(r.kx), aky = std::fabs(r.ky);
       const int64_t budget = knobs.lds_budget_words;
-      if (r.cx1 > r.cx0 && r.cy1 > r.cy0 && akx <= 4.0 && aky <= 8.0) {
+      if (knobs.stream >= 2 && r.cx1 > r.cx0 && r.cy1 > r.cy0 && aky >= knobs.stream_min_k && akx <= 64.0) {
+        // a strong shrink: neighbouring output rows share no source row, so every wave streams the row pairs of its own
+        // output rows (tile_sample_stream).  LDS = 4 waves x depth x 2 rows of the tile's x footprint; the widest tile
+        // that fits 48 KiB (64 KiB for the narrowest)
+        for (int tw = 256; tw >= 64; tw >>= 1) {
+          const int64_t wl = (static_cast<int64_t>(std::floor((tw - 1) * akx)) + 3 + 3) & ~3LL;    // pixels per LDS row
+          const int64_t need = 8 * knobs.stream * wl;
+          if (need > knobs.stream_cap && tw > 64) continue;
+          if (need > 16384) continue;                 // |kx| above ~16: the direct path
+          cell.path = PATH_SAMPLE_STREAM; cell.tile_w = tw; cell.sub_h = knobs.stream; cell.tile_h = knobs.stream_h;
+          out->lds_words = std::max<int32_t>(out->lds_words, static_cast<int32_t>(need));
+          break;
+        }
+      }
+      if (cell.path == PATH_SAMPLE && r.cx1 > r.cx0 && r.cy1 > r.cy0 && akx <= 4.0 && aky <= 8.0) {
         // tile shape: 256 pixels wide (4 per lane and row) whenever a stage of at least 4 rows fits the budget: measured on
         // MI355X (tools/sweep_resample.py) the wide tile wins even where a 128-wide one would carry more output pixels per
         // footprint (mixed horizontal strip, kx = ky = 1.87: 125 us against 137 us).  Narrower tiles (2 or 1 pixel per lane)
-        // only take the scales where the wide one does not fit at all (|k| from about 2.3 to 4).
+        // only take the scales where the wide one does not fit at all (|kx| from about 2.3 to 4 with |ky| below 2).
         int best_w = 0, best_h = 0; int64_t best_need = 0;
         const int w_lo = knobs.lds_tile_w ? knobs.lds_tile_w : 64, w_hi = knobs.lds_tile_w ? knobs.lds_tile_w : 256;
         for (int tw = w_hi; tw >= w_lo && !best_h; tw >>= 1) {
@@ -363,7 +390,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
         }
       }
     }
-    if (cell.path == PATH_SAMPLE_LDS || cell.path == PATH_SWAP_LDS) {}
+    if (cell.path == PATH_SAMPLE_LDS || cell.path == PATH_SWAP_LDS || cell.path == PATH_SAMPLE_STREAM) {}
     else if (cell.path == PATH_GENERAL) { cell.tile_w = 64; cell.tile_h = 64; }
     else if (cell.path == PATH_SAMPLE) { cell.tile_w = 256; cell.tile_h = 32; }
     else { cell.tile_w = knobs.tile_w; cell.tile_h = knobs.tile_h; }   // FILL / COPY: tile_w = 256 << n
@@ -388,11 +415,11 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     cell.tile_begin = tiles;
     tiles += nt;
     info.out_pixels += w * h;
-    out->kernel_kind = std::max<int32_t>(out->kernel_kind, (cell.path == PATH_FILL || cell.path == PATH_COPY) ? 0 : (cell.path == PATH_SAMPLE || cell.path == PATH_SAMPLE_LDS) ? 1 : 2);
+    out->kernel_kind = std::max<int32_t>(out->kernel_kind, (cell.path == PATH_FILL || cell.path == PATH_COPY) ? 0 : (cell.path == PATH_SAMPLE || cell.path == PATH_SAMPLE_LDS || cell.path == PATH_SAMPLE_STREAM) ? 1 : 2);
     switch (cell.path) {
       case PATH_FILL: info.tiles_fill += nt; break;
       case PATH_COPY: info.tiles_copy += nt; break;
-      case PATH_SAMPLE: case PATH_SAMPLE_LDS: case PATH_SWAP_LDS: info.tiles_sample += nt; break;
+      case PATH_SAMPLE: case PATH_SAMPLE_LDS: case PATH_SAMPLE_STREAM: case PATH_SWAP_LDS: info.tiles_sample += nt; break;
       default: info.tiles_general += nt; break;
     }
     for (int k = 0; k < cell.stack_len; ++k) {

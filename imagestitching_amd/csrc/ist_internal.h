@@ -48,6 +48,7 @@ enum : int32_t {
   PATH_COPY = 1,      // opaque constant under ONE 1:1 draw with integer offset: HBM copy (+ source-over if alpha<255)
   PATH_SAMPLE = 2,    // opaque constant under ONE axis-aligned draw, source x driven by canvas x
   PATH_SAMPLE_LDS = 4, // PATH_SAMPLE (bilinear, moderate scale) with the tile's source footprint staged in LDS
+  PATH_SAMPLE_STREAM = 6, // PATH_SAMPLE (bilinear): every wave streams its own rows' source row pairs through a private LDS ring
   PATH_SWAP_LDS = 5,   // ONE quarter-turned draw (EXIF 5-8), bilinear: footprint staged TRANSPOSED in LDS
   PATH_GENERAL = 3    // anything else: paint stack evaluated per pixel in canvas order (swap draws, overlaps,
                       // translucent canvas)
@@ -62,7 +63,7 @@ struct alignas(16) DevCell {
   int32_t tile_w, tile_h;
   int32_t tiles_x;
   int32_t band_x;           // tiles of this band's earlier cells in one tile row (prefix of tiles_x inside the band)
-  int32_t sub_h;            // SAMPLE_LDS: rows per pipeline stage (tile_h = sub_h * stages); 0 otherwise
+  int32_t sub_h;            // SAMPLE_LDS: rows per pipeline stage (tile_h = sub_h * stages); SAMPLE_STREAM: ring depth; 0 otherwise
   int64_t tile_begin;       // host-side bookkeeping
 };
 

@@ -474,6 +474,129 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------ SAMPLE, streamed
+// The same arithmetic as tile_sample_lds, with NO workgroup barrier: every wave owns output rows Y0 + wave + 4 j and a
+// private LDS ring of DEPTH row pairs.  It keeps the two source rows of its next DEPTH-1 output rows in flight (LDS-DMA)
+// while it blends the current one, and waits with a COUNTED s_waitcnt (vector memory operations retire in issue order,
+// loads and stores together), so loads, LDS reads, arithmetic and stores of one wave overlap instead of alternating
+// between a load phase and a compute phase of the whole workgroup.  Adjacent output rows belong to different waves of
+// the workgroup and fetch their shared source row at about the same time: the second request is an L2 hit.
+IST_DEV void wait_vm_upto(int n) {                 // wave-uniform n; waits until at most min(n, 24) operations remain
+#define IST_WAIT_CASE(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
+  switch (n) {
+    IST_WAIT_CASE(0) IST_WAIT_CASE(1) IST_WAIT_CASE(2) IST_WAIT_CASE(3) IST_WAIT_CASE(4) IST_WAIT_CASE(5)
+    IST_WAIT_CASE(6) IST_WAIT_CASE(7) IST_WAIT_CASE(8) IST_WAIT_CASE(9) IST_WAIT_CASE(10) IST_WAIT_CASE(11)
+    IST_WAIT_CASE(12) IST_WAIT_CASE(13) IST_WAIT_CASE(14) IST_WAIT_CASE(15) IST_WAIT_CASE(16) IST_WAIT_CASE(17)
+    IST_WAIT_CASE(18) IST_WAIT_CASE(19) IST_WAIT_CASE(20) IST_WAIT_CASE(21) IST_WAIT_CASE(22) IST_WAIT_CASE(23)
+    default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+  }
+#undef IST_WAIT_CASE
+}
+
+template <int NP>
+IST_DEV void tile_sample_stream(const LaunchArgs& A, const DevOp op, uint32_t bg, int X0, int Y0, int X1, int Y1, int depth, uint32_t* lds, bool fresh) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const Tap xa = bilinear_tap(op.kx, op.ox, X0, op.cx0, op.cx1), xb = bilinear_tap(op.kx, op.ox, X1 - 1, op.cx0, op.cx1);
+  const int fx0 = __builtin_amdgcn_readfirstlane(min(xa.base, xb.base)), fx1 = __builtin_amdgcn_readfirstlane(max(xa.base, xb.base) + 1);
+  const int wl = (fx1 - fx0 + 4) & ~3;            // LDS row stride in pixels (multiple of 4: 16-B aligned rows)
+  if (depth < 2 || Y1 - Y0 > 64 || op.cx1 <= op.cx0 || op.cy1 <= op.cy0 || 8 * depth * wl > A.lds_words) {   // uniform; not expected
+    tile_sample<IST_FILTER_BILINEAR>(A, op, bg, X0, Y0, X1, Y1);
+    return;
+  }
+  const size_t sp = A.pitch[op.image];
+  const uint8_t* src = A.src[op.image];
+  const RowTaps rows = row_taps(op.ky, op.oy, Y0, Y1, op.cy0, op.cy1);   // all 64 lanes active (readlane source)
+  const int nrows = (Y1 - Y0 - wave + 3) >> 2;    // output rows of this wave
+  uint32_t* ring = lds + wave * (2 * depth * wl);
+  if (!fresh) __syncthreads();                    // (grid-stride form) every wave is done with the previous tile's LDS
+  const int chunks = wl >> 2;
+  const int ni = (chunks + 63) >> 6;              // DMA instructions per source row
+  const int spr = min(NP, (X1 - X0 + 63) >> 6);   // store instructions per output row
+  bool counted = true;                            // false once a row went through registers (its operation count differs)
+  // the two source rows of output row j -> ring slot `slot`
+  auto issue = [&](int j, int slot) {
+    const Tap ty = row_tap(rows, wave + 4 * j);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int sy = ty.base + h;
+      const uint8_t* grow = src + static_cast<size_t>(sy) * sp;
+      uint32_t* lrow = ring + (2 * slot + h) * wl;
+      // reading up to 12 B past the last sampled column is harmless (next row of the same bitmap) except on the last
+      // sampled row, where it could leave the allocation: that row's edge pass goes through registers instead
+      const bool last_row = sy >= op.cy1;
+      for (int c0 = 0; c0 < chunks; c0 += 64) {
+        const int c = c0 + lane;
+        const int col = fx0 + 4 * c;
+        const bool edge = last_row && (fx0 + 4 * min(c0 + 63, chunks - 1) + 3 > op.cx1);    // wave-uniform
+        if (!edge) {
+          if (c < chunks)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t*)(grow + static_cast<size_t>(col) * 4),
+                                             (__attribute__((address_space(3))) uint32_t*)(lrow + 4 * c0), 16, 0, 0);
+        } else {
+          counted = false;
+          if (c < chunks) {
+            u32x4 v;
+            if (col + 3 <= op.cx1) v = ld16(grow + static_cast<size_t>(col) * 4);
+            else {
+              v.x = ld4(grow + static_cast<size_t>(min(col, op.cx1)) * 4);
+              v.y = ld4(grow + static_cast<size_t>(min(col + 1, op.cx1)) * 4);
+              v.z = ld4(grow + static_cast<size_t>(min(col + 2, op.cx1)) * 4);
+              v.w = ld4(grow + static_cast<size_t>(min(col + 3, op.cx1)) * 4);
+            }
+            *reinterpret_cast<u32x4*>(lrow + 4 * c) = v;
+          }
+        }
+      }
+    }
+  };
+  // prologue: the first depth-1 row pairs go out BEFORE the per-lane set-up (four fp64 column taps per lane)
+  const int ahead = depth - 1;
+  for (int j = 0; j < min(ahead, nrows); ++j) issue(j, j);
+  int Xl = X0 + lane;
+  asm volatile("" : "+v"(Xl));                            // (keeps the tap arithmetic below the loads issued above)
+  int lx[NP]; float wx[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const Tap t = bilinear_tap(op.kx, op.ox, min(Xl + 64 * p, X1 - 1), op.cx0, op.cx1);
+    lx[p] = t.base - fx0; wx[p] = t.t;
+  }
+  uint8_t* d = A.dst + static_cast<size_t>(Xl) * 4;
+  const bool opaque = (op.flags & OPF_OPAQUE) != 0;
+  int slot = 0, nslot = ahead;                            // ring slot of row j / of row j + depth - 1
+  for (int j = 0; j < nrows; ++j) {
+    // operations younger than row j's loads: the loads of the rows ahead of it and the stores of the rows since its issue
+    if (j + ahead < nrows) {
+      issue(j + ahead, nslot);
+      wait_vm_upto(counted ? ahead * 2 * ni + min(j, ahead) * spr : 0);
+    } else {
+      wait_vm_upto(counted ? (nrows - 1 - j) * 2 * ni : 0);
+    }
+    const int Y = Y0 + wave + 4 * j;
+    const Tap ty = row_tap(rows, wave + 4 * j);
+    const uint32_t* r0 = ring + 2 * slot * wl;
+    const uint32_t* r1 = r0 + wl;
+    uint32_t o[NP];
+    uint32_t p00[NP], p01[NP], p10[NP], p11[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { p00[p] = r0[lx[p]]; p01[p] = r0[lx[p] + 1]; p10[p] = r1[lx[p]]; p11[p] = r1[lx[p] + 1]; }
+    uint32_t all = 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) all &= p00[p] & p01[p] & p10[p] & p11[p];
+    if (opaque || (all >> 24) == 255u) bilerpN_opaque<NP>(p00, p01, p10, p11, wx, ty.t, o);
+    else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) o[p] = bilerp_over(p00[p], p01[p], p10[p], p11[p], wx[p], ty.t, bg, false);
+    }
+    uint8_t* dp = d + static_cast<size_t>(Y) * A.dst_pitch;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      if (Xl + 64 * p < X1) st4(dp + 256 * p, o[p]);
+    slot = slot + 1 == depth ? 0 : slot + 1;
+    nslot = nslot + 1 == depth ? 0 : nslot + 1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ SWAP via LDS
 // One quarter-turned draw (EXIF 5-8: source x is driven by canvas Y, source y by canvas X), bilinear.  A 64 x th
 // canvas tile needs a (th*|kx|+2)-column x (64*|ky|+2)-row source patch.  The patch is read row by row with coalesced
@@ -750,6 +873,11 @@ IST_DEV void run_tile(const LaunchArgs& A, int64_t tile, bool fresh) {
     if (c.tile_w == 256) tile_sample_lds<4>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
     else if (c.tile_w == 128) tile_sample_lds<2>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
     else tile_sample_lds<1>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
+  } else if ((PATHS & HAS_SAMPLE) && path == PATH_SAMPLE_STREAM) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (c.tile_w == 256) tile_sample_stream<4>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
+    else if (c.tile_w == 128) tile_sample_stream<2>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
+    else tile_sample_stream<1>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
   } else if ((PATHS & HAS_SWAP) && path == PATH_SWAP_LDS) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (!tile_swap_lds(A, op_, c.bg, X0, Y0, X1, Y1, lds)) tile_general(A, c, X0, Y0, X1, Y1);

@@ -86,8 +86,8 @@ def test_ragged_and_tiny(filt):
 
 
 @pytest.mark.parametrize("filt", ["nearest", "bilinear"])
-def test_heavy_downscale_uses_the_direct_gather_path(filt):
-    """scale factors beyond the LDS-staging budget (kx > 4): the phone-capped plans shrink 12 MP photos 6.6x."""
+def test_heavy_downscale(filt):
+    """the phone-capped plans shrink 12 MP photos 6.6x: nearest gathers directly, bilinear streams row pairs through LDS."""
     px = [U.smooth_image(120, 300, 2000), U.rand_image(121, 260, 1900), U.rand_image(122, 90, 300)]
     _check(px, "vertical", {"filter": filt, "mode": "min"})
     _check(px, "horizontal", {"filter": filt, "mode": "min"})
@@ -126,6 +126,24 @@ def test_lds_staged_path_edges():
     _check(px, "horizontal", {"filter": "bilinear", "mode": "max", "gap": 1})
     _check([U.rand_image(144, 300, 700), U.rand_image(145, 450, 1050)], "vertical", {"filter": "bilinear", "mode": "min"})   # 1.5x down
     _check([U.rand_image(146, 300, 700), U.rand_image(147, 1200, 2450)], "vertical", {"filter": "bilinear", "mode": "min"})  # 3.5x down
+
+
+@pytest.mark.parametrize("direction", ["vertical", "horizontal"])
+def test_streamed_path_scales_and_edges(direction):
+    """|ky| >= 2 (tile_sample_stream: per-wave LDS rings, counted waits): the threshold itself, 256 / 128 / 64-pixel-wide
+    tiles (kx 2..2.9 / ..6 / ..16), beyond it (direct path), flips, translucent taps, ragged right edges (output widths
+    that are no multiple of 64, so the store count per row changes), tiles shorter than 8 rows, the bottom-right tile whose
+    last source row goes through registers."""
+    base = (301, 77) if direction == "vertical" else (77, 301)        # the smallest image fixes the strip's cross size
+    for n, k in enumerate([2.0, 2.2, 2.9, 3.5, 6.65, 12.0, 17.0]):
+        w, h = int(round(base[0] * k)), int(round(base[1] * k))
+        px = [U.rand_image(300 + n, base[1], base[0]), U.rand_image(310 + n, h, w, opaque=(n % 2 == 0)), U.smooth_image(320 + n, h + 3, w + 5)]
+        _check(px, direction, {"filter": "bilinear", "mode": "min", "gap": n % 3})
+    px = [U.rand_image(330, 129, 517), U.rand_image(331, 400, 1300), U.rand_image(332, 1033, 2068, opaque=False)]
+    for o in (2, 3, 4):
+        _check(px, direction, {"filter": "bilinear", "mode": "min"}, orientations=[o] * 3)
+    p, job = ist.Stitcher(0).compile(U.hip_images(px), direction, {"filter": "bilinear", "mode": "min"})
+    assert job.info["tiles_sample"] > 0
 
 
 def test_empty_input_returns_none():

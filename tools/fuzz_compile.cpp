@@ -149,9 +149,14 @@ int main(int argc, char** argv) {
       tiles += int64_t(c.tiles_x) * ((c.Y1 - c.Y0 + c.tile_h - 1) / c.tile_h);
       area += int64_t(c.X1 - c.X0) * (c.Y1 - c.Y0);
       if (c.path != PATH_FILL) { CHECK(c.stack_len >= 1 && c.op == C.stacks[c.stack_off]); }
-      if (c.path == PATH_COPY || c.path == PATH_SAMPLE || c.path == PATH_SAMPLE_LDS || c.path == PATH_SWAP_LDS) { CHECK(c.stack_len == 1); CHECK(!(C.ops[c.op].flags & OPF_FILL)); }
+      if (c.path == PATH_COPY || c.path == PATH_SAMPLE || c.path == PATH_SAMPLE_LDS || c.path == PATH_SAMPLE_STREAM || c.path == PATH_SWAP_LDS) { CHECK(c.stack_len == 1); CHECK(!(C.ops[c.op].flags & OPF_FILL)); }
       if (c.path == PATH_SWAP_LDS) CHECK(C.ops[c.op].flags & OPF_SWAP);
-      if (c.path == PATH_COPY || c.path == PATH_SAMPLE || c.path == PATH_SAMPLE_LDS) CHECK(!(C.ops[c.op].flags & OPF_SWAP));
+      if (c.path == PATH_COPY || c.path == PATH_SAMPLE || c.path == PATH_SAMPLE_LDS || c.path == PATH_SAMPLE_STREAM) CHECK(!(C.ops[c.op].flags & OPF_SWAP));
+      if (c.path == PATH_SAMPLE_STREAM) {   // the kernel's own re-check must hold: ring fits the launch's LDS, tile fits the row-tap lanes
+        CHECK(c.sub_h >= 2 && c.tile_h <= 64 && (c.tile_w == 64 || c.tile_w == 128 || c.tile_w == 256));
+        const int64_t wl = (static_cast<int64_t>(std::floor((c.tile_w - 1) * std::fabs(C.ops[c.op].kx))) + 6) & ~3LL;
+        CHECK(8 * c.sub_h * wl <= C.lds_words);
+      }
       if (c.path == PATH_COPY) {
         const DevOp& r = C.ops[c.op];
         CHECK(r.flags & OPF_IDENTITY);
