@@ -133,6 +133,7 @@ static int64_t distinct_taps(double k, double o, int lo, int hi, int clo, int ch
 struct CompileKnobs {
   int tile_w = 256, tile_h = 8;        // FILL / COPY: ~64 KB of loads in flight per CU
   int lds_run = 2;                     // pipeline stages per workgroup on the SAMPLE_LDS path
+  int lds_tile_h = 0;                  // IST_LDS_TILE_H: stages per workgroup = this / rows per stage (instead of lds_run)
   int lds_tile_w = 0;                  // 0: pick 256 / 128 / 64 per cell; IST_LDS_TILE_W pins one width
   int64_t lds_budget_words = 6144;     // 24 KiB footprint budget per workgroup
   bool no_lds = false, no_bands = false, no_tile_table = false, no_sort = false;
@@ -158,6 +159,7 @@ static CompileKnobs read_knobs() {
   if (e && std::sscanf(e, "%dx%d", &w, &h) == 2 && w >= 256 && (w & (w - 1)) == 0 && h >= 1 && h <= 4096) { k.tile_w = w; k.tile_h = h; }
   if ((e = std::getenv("IST_LDS_BUDGET")) != nullptr) k.lds_budget_words = std::max<int64_t>(256, std::atoll(e) / 4);
   if ((e = std::getenv("IST_LDS_RUN")) != nullptr) k.lds_run = std::min(16, std::max(1, std::atoi(e)));
+  if ((e = std::getenv("IST_LDS_TILE_H")) != nullptr) k.lds_tile_h = std::min(64, std::max(0, std::atoi(e)));
   if ((e = std::getenv("IST_LDS_TILE_W")) != nullptr) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) k.lds_tile_w = v; }
   if ((e = std::getenv("IST_STREAM")) != nullptr) k.stream = std::min(8, std::max(0, std::atoi(e)));
   if ((e = std::getenv("IST_STREAM_MIN_K")) != nullptr) k.stream_min_k = std::atof(e);
@@ -383,7 +385,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
         }
         if (best_h) {
           // a workgroup walks `run` stages down its column (see tile_sample_lds)
-          const int run = knobs.lds_run;
+          const int run = knobs.lds_tile_h ? std::max(1, knobs.lds_tile_h / best_h) : knobs.lds_run;
           cell.path = PATH_SAMPLE_LDS; cell.tile_w = best_w; cell.sub_h = best_h; cell.tile_h = best_h * run;
           out->lds_half = std::max<int32_t>(out->lds_half, static_cast<int32_t>(best_need));
           out->lds_words = std::max<int32_t>(out->lds_words, out->lds_half);

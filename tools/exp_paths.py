@@ -30,6 +30,11 @@ WORKLOADS = [
     ("k4", [img(w, h) for w, h in UNI], "vertical", {"filter": "bilinear", "maxSide": 6804}),
     ("k5", [img(w, h) for w, h in UNI], "vertical", {"filter": "bilinear", "maxSide": 5443}),
     ("k10", [img(w, h) for w, h in UNI], "vertical", {"filter": "bilinear", "maxSide": 2722}),
+    ("h_k1.4", [img(4032, 3024)] * 8 + [img(3840, 2160)], "horizontal", {"filter": "bilinear"}),
+    ("v_k1.4", [img(4032, 3024)] * 8 + [img(2880, 2160)], "vertical", {"filter": "bilinear"}),
+    ("h_k1.87", [img(3024, 4032)] * 8 + [img(3840, 2160)], "horizontal", {"filter": "bilinear"}),
+    ("v_k1.87", [img(4032, 3024)] * 8 + [img(2160, 1620)], "vertical", {"filter": "bilinear"}),
+    ("exif6", [img(w, h, 6) for w, h in MIXED], "vertical", {"filter": "bilinear"}),
     ("exif3", [img(w, h, 3) for w, h in MIXED], "vertical", {"filter": "bilinear"}),
 ]
 label = sys.argv[1] if len(sys.argv) > 1 else ""

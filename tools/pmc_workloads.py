@@ -25,6 +25,7 @@ WORKLOADS = [
     ("ios_plan_bilinear (9x12MP vertical, iOS caps -> 1820x12288)", [img(w, h) for w, h in UNI], "vertical", {"filter": "bilinear", "platform": "ios", "superSample": 1}),
     ("ios_plan_nearest", [img(w, h) for w, h in UNI], "vertical", {"filter": "nearest", "platform": "ios", "superSample": 1}),
     ("android_plan_bilinear (606x4096)", [img(w, h) for w, h in UNI], "vertical", {"filter": "bilinear", "platform": "android", "superSample": 1}),
+    ("shrink_4x_bilinear (9x12MP vertical, maxSide 6804 -> 1008x6804)", [img(w, h) for w, h in UNI], "vertical", {"filter": "bilinear", "maxSide": 6804}),
     ("exif6_scaled (mixed sizes, every image quarter-turned and resampled)", [img(w, h, 6) for w, h in MIXED], "vertical", {"filter": "bilinear"}),
     ("exif5_scaled", [img(w, h, 5) for w, h in MIXED], "vertical", {"filter": "bilinear"}),
     ("exif8_scaled", [img(w, h, 8) for w, h in MIXED], "vertical", {"filter": "bilinear"}),
