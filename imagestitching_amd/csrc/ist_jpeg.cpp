@@ -264,10 +264,13 @@ static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool head
           const Huff& h = t < 4 ? dc[t] : ac[t - 4];
           JpegHuffTable& o = gs->tables[t];
           std::memset(&o, 0, sizeof o);
-          if (!h.present) { for (int l = 0; l < 18; ++l) o.maxcode[l] = -1; continue; }
+          if (!h.present) continue;                 // (all-zero: every pattern is "no code"; the scan cannot select it anyway)
           std::memcpy(o.look, h.look, sizeof o.look);
-          o.maxcode[0] = -1; o.maxcode[17] = 0x7FFFFFFF;
-          for (int l = 1; l <= 16; ++l) { o.maxcode[l] = h.maxcode[l]; o.valoff[l] = h.valptr[l] - h.mincode[l]; }
+          for (int k = 0; k < 8; ++k) {               // one past the last code of length 9+k, left-aligned
+            const int l = 9 + k;
+            o.lim[k] = static_cast<uint32_t>(h.mincode[l] + h.bits[l]) << (16 - l);
+            if (k < 7) o.vptr[k] = static_cast<uint8_t>(h.valptr[l + 1]);
+          }
           std::memcpy(o.vals, h.vals, sizeof o.vals);
         }
         // de-stuff: FF 00 -> FF; the scan ends at the first real marker

@@ -54,10 +54,14 @@ struct JpegImage {
 };
 
 // ---- what the GPU entropy decoder (ist_jpeg_gpu.hip) needs from the container: the de-stuffed scan and its tables ----
-struct JpegHuffTable {                 // one Huffman table in the form both decoders use
+struct alignas(16) JpegHuffTable {     // one Huffman table in the form the GPU decoder uses (LDS resident, 1328 bytes)
   uint16_t look[512];                  // 9-bit look-ahead: (length << 8) | symbol, 0 = longer than 9 bits
-  int32_t maxcode[18];                 // largest code of each length (-1: none)
-  int32_t valoff[17];                  // vals index = code + valoff[length]
+  // codes of 10..16 bits, branch-free: lim[k] = the first code of length 10+k, left-aligned to 16 bits (= one past the
+  // last code of length 9+k; canonical codes make it monotonic), lim[7] = one past the last 16-bit code.  With v = the
+  // next 16 bits: length = 10 + #{k in 1..6 : v >= lim[k]}, symbol = vals[vptr[length-10] + ((v - lim[length-10]) >> (16-length))]
+  uint32_t lim[8];
+  uint8_t vptr[8];                     // index in vals of the first symbol of length 10+k
+  uint8_t pad_[8];
   uint8_t vals[256];
 };
 struct JpegGpuScan {

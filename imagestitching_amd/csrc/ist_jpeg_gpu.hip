@@ -39,8 +39,13 @@ namespace ist {
 
 namespace {
 
-constexpr int kSubBitsDefault = 2048;   // bits per subsequence (IST_JPEG_SUB_BITS overrides, tuning): measured on nine 12 MP
-                                        // photos, whole call: 1024 bits 12 passes 4.5 ms, 2048 bits 7 passes 4.3 ms, 4096 bits 4 passes 5.4 ms
+// bits per subsequence (compile-time: it sizes the LDS staging area).  Whole call on nine 12 MP photos, round 2 kernels:
+// 1024 bits 4.5 ms, 2048 bits 4.3 ms, 4096 bits 5.4 ms.  With the bitstream staged in LDS the decode is no longer paced
+// by global-memory latency, and the shorter subsequence gives every SIMD two waves instead of one.
+constexpr int kSubBits = 1024;
+constexpr int kSyncThreads = 256;       // subsequences per workgroup of the synchronisation kernel
+constexpr int kWriteThreads = 128;      // ... of the writing kernel (it also holds one 8x8 block per thread in LDS)
+constexpr int kMarginWords = 64;        // staged behind a workgroup's own bits: a block can run 64 x 27 bits past its start
 constexpr int kMaxPasses = 64;
 
 __constant__ uint8_t kZig[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
@@ -55,92 +60,221 @@ struct DevImg {
   uint8_t slot_comp[10], slot_idx[10], dc_tab[3], ac_tab[3];
   int16_t* coef[3];
   int32_t h[3], v[3], blocks_x[3];
-  int32_t* dcdiff[3];                     // per component, decoding order
-  int32_t n_dc[3];
   uint32_t* err;                          // set when the TRUE path meets what the host decoder would call corrupt data
 };
 
 struct State { uint32_t p; uint32_t c; uint32_t z; };
 
-__device__ __forceinline__ uint32_t peek16(const uint8_t* s, uint32_t p) {
-  const uint32_t b = p >> 3;
-  const uint32_t w = (static_cast<uint32_t>(s[b]) << 16) | (static_cast<uint32_t>(s[b + 1]) << 8) | s[b + 2];
-  return (w >> (8 - (p & 7))) & 0xFFFFu;
+// (pointers read back from the LDS copy of the image record are generic to the compiler; the casts to address space 1
+// make their accesses global_load / global_store instead of flat ones)
+typedef const __attribute__((address_space(1))) uint8_t* GlobalBytes;
+typedef const __attribute__((address_space(1))) uint32_t* GlobalWords;
+typedef __attribute__((address_space(1))) int16_t* GlobalI16;
+typedef __attribute__((address_space(1))) uint32_t* GlobalU32;
+
+// What a workgroup keeps in LDS: the eight Huffman tables and the record of its image (a workgroup never spans two
+// images: the host pads every image's subsequences to a multiple of 256) and ITS PART OF THE BITSTREAM, byte-swapped
+// into big-endian words, plus a margin.  The decoding loop then touches global memory only to store finished blocks.
+// (Round 2's first version kept all of this in global memory.  What paced it was not the dependent look-ups but the
+// lock step: the 64 lanes of a wave refill their bit windows at different symbols, so nearly EVERY step of the wave
+// waited for somebody's global load — 1.8 us per symbol step with one wave per SIMD, measured.)
+template <int THREADS>
+struct WgShared {
+  JpegHuffTable tab[8];
+  uint32_t bits[THREADS * (kSubBits / 32) + kMarginWords];
+  DevImg img;
+  uint32_t slot_tabs[12];               // per MCU slot: (component << 16) | (AC table << 8) | DC table
+  uint8_t zig[64];
+};
+
+template <int THREADS>
+__device__ __forceinline__ void load_shared(WgShared<THREADS>* sh, const DevImg* img, uint32_t first_bit) {
+  static_assert(sizeof(DevImg) % 4 == 0 && sizeof(JpegHuffTable) % 4 == 0, "word copies");
+  const uint32_t* gi = reinterpret_cast<const uint32_t*>(img);
+  uint32_t* li = reinterpret_cast<uint32_t*>(&sh->img);
+  for (uint32_t k = threadIdx.x; k < sizeof(DevImg) / 4; k += THREADS) li[k] = gi[k];
+  const uint32_t* gt = reinterpret_cast<const uint32_t*>(img->tables);
+  uint32_t* lt = reinterpret_cast<uint32_t*>(sh->tab);
+  for (uint32_t k = threadIdx.x; k < 8 * sizeof(JpegHuffTable) / 4; k += THREADS) lt[k] = gt[k];
+  if (threadIdx.x < 64) sh->zig[threadIdx.x] = kZig[threadIdx.x];
+  if (threadIdx.x < 10) {
+    const uint32_t comp = img->slot_comp[threadIdx.x] < 3 ? img->slot_comp[threadIdx.x] : 0u;
+    sh->slot_tabs[threadIdx.x] = (img->dc_tab[comp] & 7u) | (static_cast<uint32_t>(img->ac_tab[comp] & 7u) << 8) | (comp << 16);
+  }
+  // the stream is 256-byte aligned on the device and carries 16 bytes of zero padding behind its last bit; first_bit
+  // is a multiple of kSubBits, so these are aligned word loads.  Words past the padding read as zero.
+  const uint32_t words_in_stream = static_cast<uint32_t>((img->bits >> 3) + 16) >> 2;
+  const GlobalWords gw = (GlobalWords)(img->stream) + (first_bit >> 5);
+  const uint32_t w0 = first_bit >> 5;
+  for (uint32_t k = threadIdx.x; k < THREADS * (kSubBits / 32) + kMarginWords; k += THREADS)
+    sh->bits[k] = (w0 + k < words_in_stream) ? __builtin_bswap32(gw[k]) : 0u;
+  __syncthreads();
 }
 
-// symbol + its length; a bit pattern that is no code (only ever met on a speculative, out-of-phase path) consumes one bit
+// at least the next 33 bits of the stream at bit position p, left-aligned in 64: enough for one code (<= 16 bits) and
+// its magnitude bits (<= 15), from ONE two-word LDS read.  Everything a thread can reach lies inside the staged words: a block is at most 27 + 63 * 26 = 1665 bits
+// long and the margin behind the workgroup's own bits is 2048; the index is clamped all the same.
+template <int THREADS>
+__device__ __forceinline__ uint64_t window(const WgShared<THREADS>* sh, uint32_t first_bit, uint32_t p) {
+  constexpr uint32_t kWords = THREADS * (kSubBits / 32) + kMarginWords;
+  const uint32_t q = p - first_bit;
+  const uint32_t i = min(q >> 5, kWords - 2u);
+  return ((static_cast<uint64_t>(sh->bits[i]) << 32) | sh->bits[i + 1]) << (q & 31u);
+}
+
+// symbol + its length; a bit pattern that is no code (only ever met on a speculative, out-of-phase path, or in a corrupt
+// file) consumes one bit.  Codes longer than 9 bits take three dependent LDS reads instead of a loop over the lengths.
 __device__ __forceinline__ int huff(const JpegHuffTable& h, uint32_t v16, uint32_t* len) {
   const uint32_t e = h.look[v16 >> 7];
   if (e) { *len = e >> 8; return static_cast<int>(e & 0xFF); }
-  for (int l = 10; l <= 16; ++l) {
-    const int code = static_cast<int>(v16 >> (16 - l));
-    if (code <= h.maxcode[l]) { *len = l; return h.vals[(code + h.valoff[l]) & 255]; }
-  }
-  *len = 1;
-  return -1;
+  const uint4 a = *reinterpret_cast<const uint4*>(&h.lim[0]), b = *reinterpret_cast<const uint4*>(&h.lim[4]);
+  if (v16 >= b.w) { *len = 1; return -1; }
+  const uint32_t k = (v16 >= a.y) + (v16 >= a.z) + (v16 >= a.w) + (v16 >= b.x) + (v16 >= b.y) + (v16 >= b.z);
+  *len = 10 + k;
+  return h.vals[(h.vptr[k] + ((v16 - h.lim[k]) >> (6 - k))) & 255];
 }
 
 __device__ __forceinline__ int extend_bits(uint32_t v, int s) { return (v < (1u << (s - 1))) ? static_cast<int>(v) - (1 << s) + 1 : static_cast<int>(v); }
 
-// Decodes from state S until the bit position reaches `limit`.  WRITE: store coefficients (block index `blk` counts
-// up from the caller's base).  Returns the number of blocks finished.
-template <bool WRITE>
-__device__ __forceinline__ uint32_t run(const DevImg& I, State& S, uint32_t limit, uint32_t blk) {
-  uint32_t done = 0;
-  const uint8_t* s = I.stream;
+// One symbol of the scan from state S (DC and AC share the code: only the table differs, so the two kinds of lanes of
+// a wave do not serialise).  *at = the zig-zag position a coded value belongs to (0 = the DC difference), *val = the
+// value (AC values only when AC_VALUES); *stored = a value was coded (otherwise EOB / ZRL / a bit pattern that is no
+// code, which consumes one bit and leaves the state in the block); *bad = the host decoder would call this corrupt.
+template <bool AC_VALUES, int THREADS>
+__device__ __forceinline__ void symbol(const WgShared<THREADS>* sh, uint32_t first_bit, State& S, uint32_t tabs, uint32_t* at, int* val, bool* stored, bool* bad) {
+  const bool isdc = S.z == 0;
+  uint32_t len;
+  const uint64_t w = window(sh, first_bit, S.p);
+  const int rs = huff(sh->tab[(isdc ? tabs : (tabs >> 8)) & 7u], static_cast<uint32_t>(w >> 48), &len);
+  S.p += len;
+  *stored = false; *bad = false;
+  if (rs < 0 && !isdc) { *bad = true; return; }
+  uint32_t r, sz;
+  if (isdc) { *bad = rs < 0 || rs > 11; r = 0; sz = (rs > 0 && rs <= 15) ? static_cast<uint32_t>(rs) : 0u; }
+  else { r = static_cast<uint32_t>(rs) >> 4; sz = static_cast<uint32_t>(rs) & 15u; }
+  if (!isdc && sz == 0) {
+    if (r == 15) S.z += 16; else S.z = 64;                  // ZRL / EOB
+    return;
+  }
+  S.z += r;
+  *at = S.z;
+  *stored = true;
+  *val = (sz && (AC_VALUES || isdc)) ? extend_bits(static_cast<uint32_t>((w << len) >> (64 - sz)), static_cast<int>(sz)) : 0;
+  S.p += sz;
+  S.z += 1;
+}
+
+// what a subsequence contributes to the ones behind it: blocks finished, and the sum of the DC differences coded in it,
+// per component (a block's DC difference counts where the block STARTS — the same rule as the block's ownership in the
+// writing pass)
+struct Tally { uint32_t blocks; int32_t dc[3]; };
+
+// Synchronisation passes: decodes from state S until the bit position reaches `limit`.
+// (Tried and dropped: two checkpoints per subsequence that let a re-decode stop as soon as it meets the previous
+// decode's path.  A workgroup's pass costs as much as its slowest lane and some lane always needs the whole
+// subsequence, so the passes got no shorter and every step paid for the check: 1.6 -> 2.0 ms.)
+template <int THREADS>
+__device__ __forceinline__ Tally run_count(const WgShared<THREADS>* sh, uint32_t first_bit, State& S, uint32_t limit) {
+  Tally T; T.blocks = 0; T.dc[0] = T.dc[1] = T.dc[2] = 0;
+  const uint32_t slots = static_cast<uint32_t>(sh->img.slots);
+  uint32_t tabs = sh->slot_tabs[S.c];
   while (S.p < limit) {
-    const uint32_t comp = I.slot_comp[S.c];
-    uint32_t len;
-    if (S.z == 0) {
-      const int t = huff(I.tables[I.dc_tab[comp]], peek16(s, S.p), &len);
-      S.p += len;
-      const int nb = (t > 0 && t <= 15) ? t : 0;
-      if (WRITE && blk < static_cast<uint32_t>(I.total_blocks) && (t < 0 || t > 11)) *I.err = 1u;
-      if (WRITE && blk < static_cast<uint32_t>(I.total_blocks)) {
-        const int diff = nb ? extend_bits(peek16(s, S.p) >> (16 - nb), nb) : 0;
-        const uint32_t mcu = blk / I.slots;
-        const uint32_t k = mcu * (I.h[comp] * I.v[comp]) + I.slot_idx[S.c];        // decoding-order index inside the component
-        I.dcdiff[comp][k] = diff;
-      }
-      S.p += nb;
-      S.z = 1;
-    } else {
-      const int rs = huff(I.tables[I.ac_tab[comp]], peek16(s, S.p), &len);
-      S.p += len;
-      if (rs < 0) { if (WRITE && blk < static_cast<uint32_t>(I.total_blocks)) *I.err = 1u; continue; }   // out-of-phase garbage: stay in the block
-      const uint32_t r = static_cast<uint32_t>(rs) >> 4, sz = static_cast<uint32_t>(rs) & 15;
-      if (sz == 0) {
-        if (r == 15) S.z += 16; else S.z = 64;                // ZRL / EOB
-      } else {
-        S.z += r;
-        if (WRITE && S.z >= 64 && blk < static_cast<uint32_t>(I.total_blocks)) *I.err = 1u;          // run past the block
-        if (WRITE && S.z < 64 && blk < static_cast<uint32_t>(I.total_blocks)) {
-          const int val = extend_bits(peek16(s, S.p) >> (16 - sz), static_cast<int>(sz));
-          const uint32_t mcu = blk / I.slots;
-          const uint32_t mx = mcu % I.mcus_x, my = mcu / I.mcus_x;
-          const uint32_t si = I.slot_idx[S.c];
-          const uint32_t bx = mx * I.h[comp] + si % I.h[comp], by = my * I.v[comp] + si / I.h[comp];
-          I.coef[comp][(static_cast<size_t>(by) * I.blocks_x[comp] + bx) * 64 + kZig[S.z]] = static_cast<int16_t>(val);
-        }
-        S.p += sz;
-        S.z += 1;
-      }
+    uint32_t at = 1; int val = 0; bool stored, bad;
+    symbol<false>(sh, first_bit, S, tabs, &at, &val, &stored, &bad);
+    if (stored && at == 0) {
+      const uint32_t comp = tabs >> 16;
+      T.dc[0] += comp == 0 ? val : 0; T.dc[1] += comp == 1 ? val : 0; T.dc[2] += comp == 2 ? val : 0;
     }
     if (S.z >= 64) {                                          // block finished
       S.z = 0;
-      S.c = (S.c + 1 == static_cast<uint32_t>(I.slots)) ? 0u : S.c + 1;
-      ++done; ++blk;
+      S.c = (S.c + 1 == slots) ? 0u : S.c + 1;
+      ++T.blocks;
+      tabs = sh->slot_tabs[S.c];
     }
   }
-  return done;
+  return T;
+}
+
+// Writing pass.  A block belongs to the subsequence its FIRST symbol starts in: the thread skips the tail of a block
+// that began further left (decoding it only to stay in step), then decodes every block that starts before `limit` to
+// its end — past `limit` if need be — into a 128-byte LDS slot and stores the slot as one full 128-byte block, DC
+// coefficient included (pred = the component's DC predictor where the subsequence starts, from the scan of the
+// tallies).  Every block of the image is therefore written exactly once, whole: the planes need no clearing pass,
+// there is no separate DC pass, and HBM sees full lines instead of one 2-byte store per non-zero coefficient.
+// `blk` = index of the block the start state is in.
+template <int THREADS>
+__device__ __forceinline__ void run_write(const WgShared<THREADS>* sh, uint32_t first_bit, uint32_t* slot, State S, uint32_t limit, uint32_t blk, int32_t pred0, int32_t pred1, int32_t pred2) {
+  const DevImg& I = sh->img;
+  GlobalU32 err = (GlobalU32)I.err;
+  const uint32_t total = static_cast<uint32_t>(I.total_blocks), slots = static_cast<uint32_t>(I.slots);
+  const uint32_t bits = static_cast<uint32_t>(I.bits);
+  uint32_t tabs = sh->slot_tabs[S.c];
+  auto next_block = [&]() {
+    S.z = 0;
+    S.c = (S.c + 1 == slots) ? 0u : S.c + 1;
+    ++blk;
+    tabs = sh->slot_tabs[S.c];
+  };
+  if (S.z != 0) {                                             // somebody else's block: only stay in step
+    while (S.z < 64 && S.p < bits) {
+      uint32_t at; int val; bool stored, bad;
+      symbol<false>(sh, first_bit, S, tabs, &at, &val, &stored, &bad);
+      if (bad) return;                                        // corrupt data on the true path: the block's owner reports it
+    }
+    if (S.z < 64) return;                                     // the scan ended inside it
+    next_block();
+  }
+  while (S.p < limit) {
+    const bool wr = blk < total;                              // (beyond: the padding bits behind the last block)
+    const uint32_t comp = tabs >> 16, si = I.slot_idx[S.c];
+    bool corrupt = false;
+    do {
+      uint32_t at = 0; int val = 0; bool stored, bad;
+      symbol<true>(sh, first_bit, S, tabs, &at, &val, &stored, &bad);
+      corrupt |= bad;
+      if (bad && !stored) break;                              // no code at all: stop here (every step of this pass is on the
+                                                              // true path, so the image is corrupt; a block is <= 64 steps otherwise)
+      if (stored) {
+        if (at == 0) {
+          pred0 += comp == 0 ? val : 0; pred1 += comp == 1 ? val : 0; pred2 += comp == 2 ? val : 0;
+          reinterpret_cast<int16_t*>(slot)[0] = static_cast<int16_t>(comp == 0 ? pred0 : comp == 1 ? pred1 : pred2);
+        } else if (at >= 64) corrupt = true;                  // run past the block
+        else reinterpret_cast<int16_t*>(slot)[sh->zig[at]] = static_cast<int16_t>(val);
+      }
+    } while (S.z < 64 && S.p < bits);
+    if (S.z < 64) corrupt = true;                             // the scan ended inside the block
+    if (wr) {
+      if (corrupt) *err = 1u;
+      const uint32_t h = static_cast<uint32_t>(I.h[comp]), v = static_cast<uint32_t>(I.v[comp]);
+      const uint32_t mcu = blk / slots;
+      const uint32_t mx = mcu % static_cast<uint32_t>(I.mcus_x), my = mcu / static_cast<uint32_t>(I.mcus_x);
+      const uint32_t bx = mx * h + si % h, by = my * v + si / h;
+      typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+      __attribute__((address_space(1))) V4* dst = (__attribute__((address_space(1))) V4*)((GlobalI16)I.coef[comp] + (static_cast<size_t>(by) * I.blocks_x[comp] + bx) * 64);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        V4 w;
+        w.x = slot[4 * q]; w.y = slot[4 * q + 1]; w.z = slot[4 * q + 2]; w.w = slot[4 * q + 3];
+        slot[4 * q] = 0u; slot[4 * q + 1] = 0u; slot[4 * q + 2] = 0u; slot[4 * q + 3] = 0u;
+        dst[q] = w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) slot[q] = 0u;
+    }
+    if (S.z < 64) return;
+    next_block();
+  }
 }
 
 struct SyncArgs {
   const DevImg* imgs; const uint16_t* sub_img;
   const uint32_t* in_p; const uint32_t* in_cz;       // exit states of the previous pass
-  uint32_t* out_p; uint32_t* out_cz; uint32_t* nblk;
+  uint32_t* out_p; uint32_t* out_cz;
+  uint32_t* tally;                                     // per subsequence: blocks, dc[3]
   uint32_t* start_p; uint32_t* start_cz;               // the start state each subsequence was last decoded from
-  uint32_t* changed; int32_t n_sub_total; int32_t pass; int32_t sub_bits;
+  uint32_t* half_total;                                // per 128 subsequences: the sum of their tallies
+  uint32_t* changed; int32_t pass;
 };
 
 // One LAUNCH = as many synchronisation passes as its workgroup needs: the 256 subsequences of a workgroup exchange exit
@@ -148,39 +282,45 @@ struct SyncArgs {
 // chain of out-of-phase subsequences is chased to its end inside one launch instead of one subsequence per
 // host-synchronised pass.  Across workgroups the first thread starts from the exit state its left neighbour reached in
 // the PREVIOUS launch; a launch in which no workgroup's last exit state changed is the global fixed point.  (The
-// "overflow" idea of the published scheme, restated for a barrier-synchronised workgroup.)  Measured on nine 12 MP
-// photos: fixed point after 2-3 launches instead of 7.
+// "overflow" idea of the published scheme, restated for a barrier-synchronised workgroup.)
 constexpr int kInnerPasses = 48;
 
-__global__ __launch_bounds__(256) void ist_jpeg_sync_kernel(const SyncArgs A) {
-  __shared__ uint32_t ex_p[256], ex_cz[256];
+__global__ __launch_bounds__(kSyncThreads) void ist_jpeg_sync_kernel(const SyncArgs A) {
+  __shared__ uint32_t ex_p[kSyncThreads], ex_cz[kSyncThreads];
+  __shared__ uint32_t tot[2][4];
+  __shared__ WgShared<kSyncThreads> sh;
   const int tid = threadIdx.x;
-  const int g = blockIdx.x * blockDim.x + tid;
-  const bool live = g < A.n_sub_total;
-  const DevImg* Ip = live ? &A.imgs[A.sub_img[g]] : &A.imgs[0];
-  const uint32_t i = live ? static_cast<uint32_t>(g - Ip->first_sub) : 0u;
+  const int g0 = blockIdx.x * kSyncThreads, g = g0 + tid;        // (the grid is exactly the padded subsequence count)
+  const DevImg* gimg = &A.imgs[A.sub_img[g0 / kWriteThreads]];   // one image per workgroup
+  const uint32_t first_bit = static_cast<uint32_t>(g0 - gimg->first_sub) * static_cast<uint32_t>(kSubBits);
+  if (tid < 8) tot[tid >> 2][tid & 3] = 0u;
+  load_shared(&sh, gimg, first_bit);
+  const uint32_t i = static_cast<uint32_t>(g - sh.img.first_sub);
+  const bool live = i < static_cast<uint32_t>(sh.img.n_sub);      // the padding subsequences of an image idle
   uint32_t limit = 0;
   if (live) {
-    const uint64_t end = static_cast<uint64_t>(i + 1) * static_cast<uint64_t>(A.sub_bits);
-    limit = static_cast<uint32_t>(end < static_cast<uint64_t>(Ip->bits) ? end : static_cast<uint64_t>(Ip->bits));
+    const uint64_t end = static_cast<uint64_t>(i + 1) * static_cast<uint64_t>(kSubBits);
+    limit = static_cast<uint32_t>(end < static_cast<uint64_t>(sh.img.bits) ? end : static_cast<uint64_t>(sh.img.bits));
   }
-  // what this subsequence last decoded from, and to (carried across launches in start_* / in_*)
+  // what this subsequence last decoded from, and to (carried across launches in start_* / in_* / tally)
   bool have = live && A.pass > 0;
   uint32_t st_p = have ? A.start_p[g] : 0u, st_cz = have ? A.start_cz[g] : 0u;
-  uint32_t my_p = have ? A.in_p[g] : 0u, my_cz = have ? A.in_cz[g] : 0u, nb = have ? A.nblk[g] : 0u;
+  uint32_t my_p = have ? A.in_p[g] : 0u, my_cz = have ? A.in_cz[g] : 0u;
+  Tally T; T.blocks = 0; T.dc[0] = T.dc[1] = T.dc[2] = 0;
+  if (have) { T.blocks = A.tally[4 * g]; T.dc[0] = static_cast<int32_t>(A.tally[4 * g + 1]); T.dc[1] = static_cast<int32_t>(A.tally[4 * g + 2]); T.dc[2] = static_cast<int32_t>(A.tally[4 * g + 3]); }
   bool settled = false;
   for (int it = 0; it < kInnerPasses; ++it) {
     uint32_t sp = 0, scz = 0;
     if (live && i != 0) {                            // (the first subsequence of an image starts from the true state 0, 0, 0)
       if (it == 0 || tid == 0) {                     // from the previous launch (or, in the very first pass, a guess: a block starts here)
-        if (A.pass == 0) { sp = i * static_cast<uint32_t>(A.sub_bits); scz = 0; }
+        if (A.pass == 0) { sp = i * static_cast<uint32_t>(kSubBits); scz = 0; }
         else { sp = A.in_p[g - 1]; scz = A.in_cz[g - 1]; }
       } else { sp = ex_p[tid - 1]; scz = ex_cz[tid - 1]; }      // from the left neighbour, this launch
     }
     const bool redo = live && !(have && st_p == sp && st_cz == scz);
     if (redo) {
       State S; S.p = sp; S.c = scz >> 8; S.z = scz & 255u;
-      nb = run<false>(*Ip, S, limit, 0);
+      T = run_count(&sh, first_bit, S, limit);
       my_p = S.p; my_cz = (S.c << 8) | S.z;
       st_p = sp; st_cz = scz; have = true;
     }
@@ -188,82 +328,71 @@ __global__ __launch_bounds__(256) void ist_jpeg_sync_kernel(const SyncArgs A) {
     ex_p[tid] = my_p; ex_cz[tid] = my_cz;
     if (!__syncthreads_or(redo ? 1 : 0)) { settled = true; break; }
   }
+  // the tallies of each half of the workgroup, for the writing pass's bases (integer adds: order does not matter)
+  if (live) {
+    atomicAdd(&tot[tid >> 7][0], T.blocks); atomicAdd(&tot[tid >> 7][1], static_cast<uint32_t>(T.dc[0]));
+    atomicAdd(&tot[tid >> 7][2], static_cast<uint32_t>(T.dc[1])); atomicAdd(&tot[tid >> 7][3], static_cast<uint32_t>(T.dc[2]));
+  }
+  __syncthreads();
+  if (tid < 8) A.half_total[(2 * blockIdx.x + (tid >> 2)) * 4 + (tid & 3)] = tot[tid >> 2][tid & 3];
   if (!live) return;
   // the launch changed something the NEXT workgroup depends on (or ran out of inner passes): not the fixed point yet
-  const bool last = tid == 255 || g == A.n_sub_total - 1;
+  const bool last = tid == kSyncThreads - 1 || i + 1 == static_cast<uint32_t>(sh.img.n_sub);
   if (A.pass == 0 || !settled || (last && (A.in_p[g] != my_p || A.in_cz[g] != my_cz))) {
     if (A.pass == 0 ? (tid == 0) : true) *A.changed = 1u;
   }
-  A.out_p[g] = my_p; A.out_cz[g] = my_cz; A.nblk[g] = nb;
+  A.out_p[g] = my_p; A.out_cz[g] = my_cz;
+  A.tally[4 * g] = T.blocks; A.tally[4 * g + 1] = static_cast<uint32_t>(T.dc[0]); A.tally[4 * g + 2] = static_cast<uint32_t>(T.dc[1]); A.tally[4 * g + 3] = static_cast<uint32_t>(T.dc[2]);
   A.start_p[g] = st_p; A.start_cz[g] = st_cz;
 }
 
-struct WriteArgs { const DevImg* imgs; const uint16_t* sub_img; const uint32_t* p; const uint32_t* cz; const uint32_t* blk_excl; int32_t n_sub_total; int32_t sub_bits; };
+struct WriteArgs { const DevImg* imgs; const uint16_t* sub_img; const uint32_t* p; const uint32_t* cz; const uint32_t* tally; const uint32_t* half_total; };
 
-__global__ __launch_bounds__(256) void ist_jpeg_write_kernel(const WriteArgs A) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= A.n_sub_total) return;
-  const DevImg& I = A.imgs[A.sub_img[g]];
+// One workgroup = 128 subsequences.  Its base (blocks finished and DC sums in front of it, inside its image) is the sum
+// of the half_total entries of the image in front of it; an exclusive scan of its own tallies gives every thread its own.
+__global__ __launch_bounds__(kWriteThreads) void ist_jpeg_write_kernel(const WriteArgs A) {
+  __shared__ WgShared<kWriteThreads> sh;
+  __shared__ uint32_t slots[kWriteThreads * 33];                 // one 8x8 block per thread, 33-word pitch (bank-conflict free)
+  __shared__ uint32_t sc[4][kWriteThreads];
+  __shared__ uint32_t base[4];
+  const int tid = threadIdx.x;
+  const int g0 = blockIdx.x * kWriteThreads, g = g0 + tid;
+  const DevImg* gimg = &A.imgs[A.sub_img[blockIdx.x]];
+  const uint32_t first_bit = static_cast<uint32_t>(g0 - gimg->first_sub) * static_cast<uint32_t>(kSubBits);
+  uint32_t* slot = slots + tid * 33;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) slot[q] = 0u;
+  if (tid < 4) base[tid] = 0u;
+  load_shared(&sh, gimg, first_bit);
+  const DevImg& I = sh.img;
   const uint32_t i = static_cast<uint32_t>(g - I.first_sub);
+  const bool live = i < static_cast<uint32_t>(I.n_sub);
+  // base of the workgroup: the halves of this image in front of it
+  {
+    uint32_t acc[4] = {0u, 0u, 0u, 0u};
+    for (int u = I.first_sub / kWriteThreads + tid; u < static_cast<int>(blockIdx.x); u += kWriteThreads)
+      for (int c = 0; c < 4; ++c) acc[c] += A.half_total[4 * u + c];
+    for (int c = 0; c < 4; ++c) if (acc[c]) atomicAdd(&base[c], acc[c]);
+  }
+  // exclusive scan of the workgroup's own tallies
+  uint32_t mine[4];
+  for (int c = 0; c < 4; ++c) { mine[c] = live ? A.tally[4 * g + c] : 0u; sc[c][tid] = mine[c]; }
+  __syncthreads();
+  for (int off = 1; off < kWriteThreads; off <<= 1) {
+    uint32_t t[4];
+    for (int c = 0; c < 4; ++c) t[c] = tid >= off ? sc[c][tid - off] : 0u;
+    __syncthreads();
+    for (int c = 0; c < 4; ++c) sc[c][tid] += t[c];
+    __syncthreads();
+  }
+  if (!live) return;
+  uint32_t ex[4];
+  for (int c = 0; c < 4; ++c) ex[c] = base[c] + sc[c][tid] - mine[c];
   State S;
   if (i == 0) { S.p = 0; S.c = 0; S.z = 0; } else { S.p = A.p[g - 1]; S.c = A.cz[g - 1] >> 8; S.z = A.cz[g - 1] & 255u; }
-  const uint64_t end = static_cast<uint64_t>(i + 1) * static_cast<uint64_t>(A.sub_bits);
+  const uint64_t end = static_cast<uint64_t>(i + 1) * static_cast<uint64_t>(kSubBits);
   const uint32_t limit = static_cast<uint32_t>(end < static_cast<uint64_t>(I.bits) ? end : static_cast<uint64_t>(I.bits));
-  run<true>(I, S, limit, A.blk_excl[g] - A.blk_excl[I.first_sub]);
-}
-
-// exclusive scan of n uint32 by ONE workgroup (n is ~130 k for nine 12 MP photos): chunk per thread, block scan, fix-up
-__global__ __launch_bounds__(1024) void ist_scan_u32_kernel(const uint32_t* in, uint32_t* out, int n) {
-  __shared__ uint32_t part[1024];
-  const int tid = threadIdx.x;
-  const int per = (n + 1023) / 1024;
-  const int a = tid * per, b = min(n, a + per);
-  uint32_t s = 0;
-  for (int i = a; i < b; ++i) s += in[i];
-  part[tid] = s;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const uint32_t t = tid >= off ? part[tid - off] : 0u;
-    __syncthreads();
-    part[tid] += t;
-    __syncthreads();
-  }
-  uint32_t run = tid ? part[tid - 1] : 0u;
-  for (int i = a; i < b; ++i) { const uint32_t v = in[i]; out[i] = run; run += v; }
-  if (tid == 1023) out[n] = part[1023];                       // total at [n]
-}
-
-// DC prediction: inclusive sum of the differences in decoding order, written to coefficient 0 of every block.
-// One workgroup per (image, component).
-__global__ __launch_bounds__(1024) void ist_jpeg_dc_kernel(const DevImg* imgs) {
-  __shared__ int32_t part[1024];
-  const DevImg& I = imgs[blockIdx.x / 3];
-  const int comp = blockIdx.x % 3;
-  const int n = I.n_dc[comp];
-  if (n <= 0) return;
-  const int32_t* d = I.dcdiff[comp];
-  const int tid = threadIdx.x;
-  const int per = (n + 1023) / 1024;
-  const int a = tid * per, b = min(n, a + per);
-  int32_t s = 0;
-  for (int i = a; i < b; ++i) s += d[i];
-  part[tid] = s;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int32_t t = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += t;
-    __syncthreads();
-  }
-  int32_t run = tid ? part[tid - 1] : 0;
-  const int bc = I.h[comp] * I.v[comp];
-  for (int k = a; k < b; ++k) {
-    run += d[k];
-    const int mcu = k / bc, si = k - mcu * bc;
-    const int mx = mcu % I.mcus_x, my = mcu / I.mcus_x;
-    const int bx = mx * I.h[comp] + si % I.h[comp], by = my * I.v[comp] + si / I.h[comp];
-    I.coef[comp][(static_cast<size_t>(by) * I.blocks_x[comp] + bx) * 64] = static_cast<int16_t>(run);
-  }
+  run_write(&sh, first_bit, slot, S, limit, ex[0], static_cast<int32_t>(ex[1]), static_cast<int32_t>(ex[2]), static_cast<int32_t>(ex[3]));
 }
 
 }  // namespace
@@ -280,16 +409,13 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     std::fprintf(stderr, "[ist timing]   huffman/%-20s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
     t_prev = t;
   };
-  int kSubBits = kSubBitsDefault;
-  if (const char* e = std::getenv("IST_JPEG_SUB_BITS")) { const int v = std::atoi(e); if (v >= 256 && v <= 65536) kSubBits = v; }
   ok->assign(n_img, 0);
   if (n_img == 0) return IST_OK;
 #define JG_HIP(e) do { const hipError_t e_ = (e); if (e_ != hipSuccess) return fail(IST_E_HIP, std::string(#e) + ": " + hipGetErrorString(e_)); } while (0)
-  // ---- one device arena: streams, tables, image records, per-subsequence state, DC differences
+  // ---- one device arena: streams, tables, image records, per-subsequence state
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
   std::vector<size_t> o_stream(n_img), o_tab(n_img);
-  std::vector<size_t> o_dc(n_img * 3, 0);
   std::vector<DevImg> H(n_img);
   int64_t n_sub_total = 0;
   for (size_t k = 0; k < n_img; ++k) {
@@ -297,6 +423,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     if (S.bits >= (1ll << 32) - 65536) return fail(IST_E_UNSUPPORTED, "JPEG scan too large for the GPU entropy decoder");
     // the kernels index slot_comp / slot_idx (10 entries, T.81 B.2.3) with the MCU slot: never launch outside that
     if (S.slots < 1 || S.slots > 10) return fail(IST_E_DECODE, "JPEG scan with more than 10 blocks per MCU");
+    if (S.stream.size() != static_cast<size_t>(S.bits / 8) + 16) return fail(IST_E_INVALID, "JPEG scan buffer without its padding");
     o_stream[k] = take(S.stream.size());
     o_tab[k] = take(sizeof(S.tables));
     DevImg& I = H[k];
@@ -305,7 +432,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     I.first_sub = static_cast<int32_t>(n_sub_total);
     I.n_sub = static_cast<int32_t>((S.bits + kSubBits - 1) / kSubBits);
     if (I.n_sub < 1) I.n_sub = 1;
-    n_sub_total += I.n_sub;
+    n_sub_total += (static_cast<int64_t>(I.n_sub) + 255) & ~255LL;        // a workgroup (256 subsequences) never spans two images
     I.slots = S.slots; I.mcus_x = J.mcus_x;
     I.total_blocks = J.mcus_x * J.mcus_y * S.slots;
     std::memcpy(I.slot_comp, S.slot_comp, 10); std::memcpy(I.slot_idx, S.slot_idx, 10);
@@ -313,17 +440,16 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     for (int c = 0; c < J.ncomp; ++c) {
       I.coef[c] = items[k].d_coef[c];
       I.h[c] = J.comp[c].h; I.v[c] = J.comp[c].v; I.blocks_x[c] = J.comp[c].blocks_x;
-      I.n_dc[c] = J.mcus_x * J.mcus_y * J.comp[c].h * J.comp[c].v;
-      o_dc[k * 3 + c] = take(static_cast<size_t>(I.n_dc[c]) * 4);
     }
-    for (int c = J.ncomp; c < 3; ++c) { I.h[c] = I.v[c] = 1; I.n_dc[c] = 0; }
+    for (int c = J.ncomp; c < 3; ++c) I.h[c] = I.v[c] = 1;
   }
   if (n_sub_total >= (1ll << 31) || n_img > 65535) return fail(IST_E_UNSUPPORTED, "too much JPEG data for one GPU entropy-decode batch");
   const int ns = static_cast<int>(n_sub_total);
-  const size_t o_img = take(sizeof(DevImg) * n_img), o_sub = take(2 * static_cast<size_t>(ns));
+  const int n_half = ns / kWriteThreads;            // groups of 128 subsequences (ns is a multiple of 256)
+  const size_t o_img = take(sizeof(DevImg) * n_img), o_sub = take(2 * static_cast<size_t>(n_half));
   const size_t o_p0 = take(4 * static_cast<size_t>(ns)), o_p1 = take(4 * static_cast<size_t>(ns)), o_cz0 = take(4 * static_cast<size_t>(ns)), o_cz1 = take(4 * static_cast<size_t>(ns));
   const size_t o_sp = take(4 * static_cast<size_t>(ns)), o_scz = take(4 * static_cast<size_t>(ns));
-  const size_t o_nblk = take(4 * static_cast<size_t>(ns)), o_excl = take(4 * (static_cast<size_t>(ns) + 1)), o_flag = take(4), o_err = take(4 * n_img);
+  const size_t o_tally = take(16 * static_cast<size_t>(ns)), o_half = take(16 * static_cast<size_t>(n_half)), o_flag = take(4), o_err = take(4 * n_img);
   // the caller's grow-only scratch (a context keeps it across calls: no allocation, and no implicit device synchronisation
   // of a free, per call), or a one-off allocation
   uint8_t* d = nullptr;
@@ -339,41 +465,36 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     JG_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
     fr.p = d;
   }
-  std::vector<uint16_t> sub_img(static_cast<size_t>(ns));
+  std::vector<uint16_t> half_img(static_cast<size_t>(n_half));           // image of every group of 128 subsequences
   for (size_t k = 0; k < n_img; ++k) {
     const JpegGpuScan& S = *items[k].S;
     JG_HIP(hipMemcpyAsync(d + o_stream[k], S.stream.data(), S.stream.size(), hipMemcpyHostToDevice, stream));
     JG_HIP(hipMemcpyAsync(d + o_tab[k], S.tables, sizeof(S.tables), hipMemcpyHostToDevice, stream));
     H[k].stream = d + o_stream[k];
     H[k].tables = reinterpret_cast<const JpegHuffTable*>(d + o_tab[k]);
-    for (int c = 0; c < 3; ++c) H[k].dcdiff[c] = reinterpret_cast<int32_t*>(d + o_dc[k * 3 + c]);
     H[k].err = reinterpret_cast<uint32_t*>(d + o_err) + k;
-    for (int i = 0; i < H[k].n_sub; ++i) sub_img[static_cast<size_t>(H[k].first_sub + i)] = static_cast<uint16_t>(k);
-    // the planes are written sparsely: zero them first
-    const JpegImage& J = *items[k].J;
-    for (int c = 0; c < J.ncomp; ++c)
-      JG_HIP(hipMemsetAsync(items[k].d_coef[c], 0, static_cast<size_t>(J.comp[c].blocks_x) * J.comp[c].blocks_y * 128, stream));
+    for (int i = 0; i < ((H[k].n_sub + 255) & ~255); i += kWriteThreads) half_img[static_cast<size_t>((H[k].first_sub + i) / kWriteThreads)] = static_cast<uint16_t>(k);
+    // (the writing pass stores every block of the planes whole, DC included: no clearing pass, no DC pass)
   }
   JG_HIP(hipMemsetAsync(d + o_err, 0, 4 * n_img, stream));
   JG_HIP(hipMemcpyAsync(d + o_img, H.data(), sizeof(DevImg) * n_img, hipMemcpyHostToDevice, stream));
-  JG_HIP(hipMemcpyAsync(d + o_sub, sub_img.data(), 2 * static_cast<size_t>(ns), hipMemcpyHostToDevice, stream));
+  JG_HIP(hipMemcpyAsync(d + o_sub, half_img.data(), 2 * static_cast<size_t>(n_half), hipMemcpyHostToDevice, stream));
   lap("alloc + uploads");
   const DevImg* d_img = reinterpret_cast<const DevImg*>(d + o_img);
   const uint16_t* d_sub = reinterpret_cast<const uint16_t*>(d + o_sub);
   uint32_t* P[2] = {reinterpret_cast<uint32_t*>(d + o_p0), reinterpret_cast<uint32_t*>(d + o_p1)};
   uint32_t* CZ[2] = {reinterpret_cast<uint32_t*>(d + o_cz0), reinterpret_cast<uint32_t*>(d + o_cz1)};
-  uint32_t* d_nblk = reinterpret_cast<uint32_t*>(d + o_nblk);
-  uint32_t* d_excl = reinterpret_cast<uint32_t*>(d + o_excl);
+  uint32_t* d_tally = reinterpret_cast<uint32_t*>(d + o_tally);
+  uint32_t* d_half = reinterpret_cast<uint32_t*>(d + o_half);
   uint32_t* d_flag = reinterpret_cast<uint32_t*>(d + o_flag);
-  const unsigned grid = static_cast<unsigned>((ns + 255) / 256);
   // ---- synchronisation passes until a pass changes nothing
   int cur = 0, passes_run = 0;
   bool converged = false;
   for (int pass = 0; pass < kMaxPasses; ++pass) {
     passes_run = pass + 1;
     JG_HIP(hipMemsetAsync(d_flag, 0, 4, stream));
-    SyncArgs A{d_img, d_sub, P[cur], CZ[cur], P[cur ^ 1], CZ[cur ^ 1], d_nblk, reinterpret_cast<uint32_t*>(d + o_sp), reinterpret_cast<uint32_t*>(d + o_scz), d_flag, ns, pass, kSubBits};
-    hipLaunchKernelGGL(ist_jpeg_sync_kernel, dim3(grid), dim3(256), 0, stream, A);
+    SyncArgs A{d_img, d_sub, P[cur], CZ[cur], P[cur ^ 1], CZ[cur ^ 1], d_tally, reinterpret_cast<uint32_t*>(d + o_sp), reinterpret_cast<uint32_t*>(d + o_scz), d_half, d_flag, pass};
+    hipLaunchKernelGGL(ist_jpeg_sync_kernel, dim3(static_cast<unsigned>(ns / kSyncThreads)), dim3(kSyncThreads), 0, stream, A);
     JG_HIP(hipGetLastError());
     cur ^= 1;
     if (pass == 0) continue;                       // (the first launch starts from guesses: a second one always runs)
@@ -382,26 +503,23 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     JG_HIP(hipStreamSynchronize(stream));
     if (!flag) { converged = true; break; }
   }
-  if (std::getenv("IST_TIMING")) std::fprintf(stderr, "[ist timing] GPU Huffman: %d subsequences, %s after %d passes\n", ns, converged ? "fixed point" : "NO fixed point", passes_run);
+  if (timing) std::fprintf(stderr, "[ist timing] GPU Huffman: %d subsequences of %d bits, %s after %d launches\n", ns, kSubBits, converged ? "fixed point" : "NO fixed point", passes_run);
   if (!converged) { JG_HIP(hipStreamSynchronize(stream)); return IST_OK; }      // every ok[] stays 0: the host decodes
   lap("sync passes");
-  // ---- block indices, coefficient write, DC integration
-  hipLaunchKernelGGL(ist_scan_u32_kernel, dim3(1), dim3(1024), 0, stream, d_nblk, d_excl, ns);
+  // ---- the writing pass
+  WriteArgs W{d_img, d_sub, P[cur], CZ[cur], d_tally, d_half};
+  hipLaunchKernelGGL(ist_jpeg_write_kernel, dim3(static_cast<unsigned>(n_half)), dim3(kWriteThreads), 0, stream, W);
   JG_HIP(hipGetLastError());
-  WriteArgs W{d_img, d_sub, P[cur], CZ[cur], d_excl, ns, kSubBits};
-  hipLaunchKernelGGL(ist_jpeg_write_kernel, dim3(grid), dim3(256), 0, stream, W);
-  JG_HIP(hipGetLastError());
-  hipLaunchKernelGGL(ist_jpeg_dc_kernel, dim3(static_cast<unsigned>(3 * n_img)), dim3(1024), 0, stream, d_img);
-  JG_HIP(hipGetLastError());
-  lap("scan + write + DC");
+  lap("write");
   // ---- validation: exactly the blocks the frame header promises, and nothing the host decoder would reject
-  std::vector<uint32_t> excl(static_cast<size_t>(ns) + 1), err(n_img);
-  JG_HIP(hipMemcpyAsync(excl.data(), d_excl, 4 * (static_cast<size_t>(ns) + 1), hipMemcpyDeviceToHost, stream));
+  std::vector<uint32_t> half(4 * static_cast<size_t>(n_half)), err(n_img);
+  JG_HIP(hipMemcpyAsync(half.data(), d_half, 16 * static_cast<size_t>(n_half), hipMemcpyDeviceToHost, stream));
   JG_HIP(hipMemcpyAsync(err.data(), d + o_err, 4 * n_img, hipMemcpyDeviceToHost, stream));
   JG_HIP(hipStreamSynchronize(stream));
   for (size_t k = 0; k < n_img; ++k) {
     const DevImg& I = H[k];
-    const uint32_t blocks = excl[static_cast<size_t>(I.first_sub + I.n_sub)] - excl[static_cast<size_t>(I.first_sub)];
+    uint32_t blocks = 0;
+    for (int u = I.first_sub / kWriteThreads; u < (I.first_sub + ((I.n_sub + 255) & ~255)) / kWriteThreads; ++u) blocks += half[4 * static_cast<size_t>(u)];
     (*ok)[k] = (blocks == static_cast<uint32_t>(I.total_blocks) && err[k] == 0) ? 1 : 0;
   }
   lap("validation");
