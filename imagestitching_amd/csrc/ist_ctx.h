@@ -8,6 +8,7 @@
 
 #include <memory>
 #include <mutex>
+#include <vector>
 
 #include "ist_host.h"
 #include "ist_internal.h"
@@ -19,6 +20,15 @@ struct ist_ctx {
   void* scratch_dst = nullptr; size_t scratch_dst_bytes = 0;
   void* scratch_dec = nullptr; size_t scratch_dec_bytes = 0;   // JPEG coefficient / sample planes of ist_decode_files_device
   void* scratch_huff = nullptr; size_t scratch_huff_bytes = 0; // GPU Huffman decoder: scans, tables, per-subsequence state
+  void* scratch_png = nullptr; size_t scratch_png_bytes = 0;   // compressing PNG encoder: one slot per 16 KiB chunk + its tables
+  void* scratch_file = nullptr; size_t scratch_file_bytes = 0; // device image of a PNG file on its way to the host
+  hipStream_t aux = nullptr;             // second stream of the host-path entry points (PNG slabs travel on it while later ones compress)
+  // device blocks of destroyed jobs' tables, re-used by the next job of this context instead of a hipMalloc + hipFree pair
+  // per job (a free also synchronises the device); at most kTablePool blocks are kept
+  static constexpr int kTablePool = 8;
+  struct TableBlock { uint8_t* p; size_t bytes; };
+  std::vector<TableBlock> table_pool;
+  std::mutex table_mu;
   std::mutex mu;                         // one host-path stitch in flight per context (index.js:772 isStitching)
   int png_level = 1;                     // 1: Paeth + run-length + Huffman; 0: stored deflate blocks (ist_ctx_set_png_level)
   std::unique_ptr<ist::Stager> stager;   // pinned staging ring, built on first use
@@ -30,6 +40,8 @@ struct ist_job {
   ist_ctx* ctx = nullptr;
   ist::Compiled host;
   uint8_t* d_tables = nullptr;           // ONE device allocation holding the five tables below
+  size_t d_tables_bytes = 0;
+  hipEvent_t launched = nullptr;         // recorded behind the job's latest launch: its tables may be re-used after it
   ist::DevOp* d_ops = nullptr;
   ist::DevCell* d_cells = nullptr;
   ist::DevBand* d_bands = nullptr;

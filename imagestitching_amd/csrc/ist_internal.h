@@ -111,9 +111,12 @@ int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, 
 
 // PNG export, compressing form (ist_png_deflate.hip); ist_png_encode_device picks it when the context's level is > 0
 int64_t png_deflate_bound(int64_t w, int64_t h);
-int png_encode_device_deflate(const void* canvas, size_t pitch, int64_t w, int64_t h, void* out, int64_t out_cap,
-                              int64_t* out_len, void* stream);
+// host_out (pinned, out_cap bytes) + aux stream, both optional: the file also lands in host memory, slab by slab, while
+// later slabs are still being compressed
+int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* out, int64_t out_cap,
+                              int64_t* out_len, void* stream, uint8_t* host_out, void* aux);
 int ctx_png_level(const ist_ctx* ctx);
+int ctx_png_scratch(ist_ctx* ctx, size_t need, void** p);   // the context's grow-only PNG scratch (kept across calls)
 
 }  // namespace ist
 

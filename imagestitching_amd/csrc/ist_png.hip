@@ -213,7 +213,7 @@ int ist_png_encode_device(ist_ctx* ctx, const void* canvas, size_t pitch, int64_
     return fail(IST_E_INVALID, "ist_png_encode_device: bad argument");
   if (w > (1ll << 29) || h > 2147483647ll) return fail(IST_E_OUTPUT_SIZE, "image too large for PNG");
   if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) return fail(IST_E_INVALID, "PNG output buffer must be 16-byte aligned");
-  if (ctx_png_level(ctx) > 0) return png_encode_device_deflate(canvas, pitch, w, h, out, out_cap, out_len, stream_);
+  if (ctx_png_level(ctx) > 0) return png_encode_device_deflate(ctx, canvas, pitch, w, h, out, out_cap, out_len, stream_, nullptr, nullptr);
   Layout L;
   make_layout(w, h, &L);
   if (L.total > out_cap) return fail(IST_E_INVALID, "PNG output buffer too small (see ist_png_bound)");

@@ -30,6 +30,11 @@ using namespace ist;
 
 namespace ist {
 int ctx_png_level(const ist_ctx* ctx) { return ctx ? ctx->png_level : 0; }
+int ctx_png_scratch(ist_ctx* ctx, size_t need, void** p) {
+  const int rc = grow_device(&ctx->scratch_png, &ctx->scratch_png_bytes, need);
+  *p = ctx->scratch_png;
+  return rc;
+}
 
 int grow_device(void** p, size_t* have, size_t need) {
   if (*have >= need) return IST_OK;
@@ -58,6 +63,41 @@ int read_back_pooled(const void* dev, size_t bytes, hipStream_t stream, uint8_t*
     return fail(IST_E_HIP, "result readback failed");
   }
   *out = host;
+  return IST_OK;
+}
+
+// The PNG file of a canvas in device memory -> a pooled pinned block (freed with ist_free).  `dfile` = device scratch of
+// at least ist_png_bound bytes (nullptr: the context's own).  The compressing encoder hands the file over slab by slab
+// while it is still compressing (png_encode_device_deflate); the stored form is encoded whole and copied once.
+// Caller holds ctx->mu.  Synchronises ctx->stream.
+int png_to_host(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* dfile, uint8_t** out_png, int64_t* out_len) {
+  const int64_t cap = ist_png_bound(w, h);
+  if (!dfile) {
+    const int rc = grow_device(&ctx->scratch_file, &ctx->scratch_file_bytes, static_cast<size_t>(cap));
+    if (rc) return rc;
+    dfile = ctx->scratch_file;
+  }
+  int64_t len = 0;
+  if (ctx->png_level > 0) {
+    if (!ctx->aux) {
+      // high priority: its small gather kernels should not queue behind the compression kernels' thousands of workgroups
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); ctx->aux = nullptr; return fail(IST_E_HIP, "hipStreamCreate failed"); }
+    }
+    uint8_t* host = static_cast<uint8_t*>(pool_take(static_cast<size_t>(cap)));
+    if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
+    const int rc = png_encode_device_deflate(ctx, canvas, pitch, w, h, dfile, cap, &len, ctx->stream, host, ctx->aux);
+    if (rc) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamSynchronize(ctx->stream); pool_give(host); return rc; }
+    *out_png = host; *out_len = len;
+    return IST_OK;
+  }
+  int rc = ist_png_encode_device(ctx, canvas, pitch, w, h, dfile, cap, &len, ctx->stream);
+  if (rc) return rc;
+  uint8_t* host = nullptr;
+  rc = read_back_pooled(dfile, static_cast<size_t>(len), ctx->stream, &host);
+  if (rc) return rc;
+  *out_png = host; *out_len = len;
   return IST_OK;
 }
 
@@ -100,6 +140,10 @@ void ist_ctx_destroy(ist_ctx* ctx) {
   if (ctx->scratch_dst) (void)hipFree(ctx->scratch_dst);
   if (ctx->scratch_dec) (void)hipFree(ctx->scratch_dec);
   if (ctx->scratch_huff) (void)hipFree(ctx->scratch_huff);
+  if (ctx->scratch_png) (void)hipFree(ctx->scratch_png);
+  if (ctx->scratch_file) (void)hipFree(ctx->scratch_file);
+  if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+  for (const ist_ctx::TableBlock& b : ctx->table_pool) (void)hipFree(b.p);
   ctx->stager.reset();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -128,7 +172,17 @@ ist_job* ist_job_create(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const 
   if (total) {
     std::vector<uint8_t> blob(total, 0);
     for (int k = 0; k < 5; ++k) if (bytes[k]) std::memcpy(blob.data() + at[k], from[k], bytes[k]);
-    if (hipMalloc(reinterpret_cast<void**>(&job->d_tables), total) != hipSuccess ||
+    {                                       // a block of an earlier job of this context, if one is large enough
+      std::lock_guard<std::mutex> lk(ctx->table_mu);
+      for (size_t k = 0; k < ctx->table_pool.size(); ++k)
+        if (ctx->table_pool[k].bytes >= total && ctx->table_pool[k].bytes <= 4 * total + (1u << 20)) {
+          job->d_tables = ctx->table_pool[k].p; job->d_tables_bytes = ctx->table_pool[k].bytes;
+          ctx->table_pool.erase(ctx->table_pool.begin() + static_cast<std::ptrdiff_t>(k));
+          break;
+        }
+    }
+    if (!job->d_tables && hipMalloc(reinterpret_cast<void**>(&job->d_tables), total) == hipSuccess) job->d_tables_bytes = total;
+    if (!job->d_tables ||
         hipMemcpy(job->d_tables, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess) {      // blocking: the tables are in place when this returns
       (void)hipGetLastError();
       fail(IST_E_HIP, "uploading the op tables failed");
@@ -184,14 +238,32 @@ int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch
   if ((reinterpret_cast<uintptr_t>(dst) & 3) != 0) return fail(IST_E_INVALID, "dst must be 4-byte aligned");
   DeviceGuard g(job->ctx->device);
   if (!g.ok) return fail(IST_E_NO_DEVICE, "hipSetDevice failed");
-  return launch_stitch(a, h.info.n_tiles, h.kernel_kind, stream);
+  const int rc = launch_stitch(a, h.info.n_tiles, h.kernel_kind, stream);
+  // behind the launch: ist_job_destroy hands the tables to the next job only after this launch has read them
+  if (rc == IST_OK && job->d_tables) {
+    if (!job->launched && hipEventCreateWithFlags(&job->launched, hipEventDisableTiming) != hipSuccess) { job->launched = nullptr; (void)hipGetLastError(); }
+    if (job->launched && hipEventRecord(job->launched, static_cast<hipStream_t>(stream)) != hipSuccess) (void)hipGetLastError();
+  }
+  return rc;
 }
 
 void ist_job_destroy(ist_job* job) {
   if (!job) return;
   if (job->ctx) {
     DeviceGuard g(job->ctx->device);
-    if (job->d_tables) (void)hipFree(job->d_tables);
+    bool idle = true;                      // the latest launch has read the tables (an event that cannot be waited for: free instead)
+    if (job->launched) { idle = hipEventSynchronize(job->launched) == hipSuccess; (void)hipEventDestroy(job->launched); }
+    if (job->d_tables) {
+      bool kept = false;
+      if (idle) {
+        std::lock_guard<std::mutex> lk(job->ctx->table_mu);
+        if (static_cast<int>(job->ctx->table_pool.size()) < ist_ctx::kTablePool && job->d_tables_bytes <= (64u << 20)) {
+          job->ctx->table_pool.push_back(ist_ctx::TableBlock{job->d_tables, job->d_tables_bytes});
+          kept = true;
+        }
+      }
+      if (!kept) (void)hipFree(job->d_tables);
+    }
   }
   delete job;
 }
@@ -282,18 +354,7 @@ int ist_render_png(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8
   DeviceGuard g(ctx->device);
   int rc = render_to_scratch(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, src, src_pitch, n_images, filter, nullptr, nullptr, nullptr);
   if (rc) return rc;
-  const int64_t cap = ist_png_bound(canvas_w, canvas_h);
-  void* dpng = nullptr;
-  IST_HIP(hipMalloc(&dpng, static_cast<size_t>(cap)));
-  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{dpng};
-  int64_t len = 0;
-  rc = ist_png_encode_device(ctx, ctx->scratch_dst, static_cast<size_t>(canvas_w) * 4, canvas_w, canvas_h, dpng, cap, &len, ctx->stream);
-  if (rc) return rc;
-  uint8_t* host = nullptr;
-  rc = read_back_pooled(dpng, static_cast<size_t>(len), ctx->stream, &host);
-  if (rc) return rc;
-  *out_png = host; *out_len = len;
-  return IST_OK;
+  return png_to_host(ctx, ctx->scratch_dst, static_cast<size_t>(canvas_w) * 4, canvas_w, canvas_h, nullptr, out_png, out_len);
 }
 
 // plan + render + PNG: onStitch stages 2-5 including the export (index.js:1251-1581), decode excluded
@@ -679,15 +740,13 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   rc = ist_job_launch(job, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, ctx->stream);
   if (rc) return rc;
   ph.lap(IST_PHASE_STITCH, "compile + stitch launch", ctx->stream);
-  // PNG export on the device, then the only D2H of the call
+  // PNG export on the device; the file's slabs cross PCIe (the only D2H of the call) while later slabs compress
   int64_t len = 0;
-  rc = ist_png_encode_device(ctx, d + o_canvas, canvas_pitch, out_plan->canvas_w, out_plan->canvas_h, d + o_png, png_cap, &len, ctx->stream);
-  if (rc) return rc;
-  ph.lap(IST_PHASE_PNG, "PNG encode (GPU)", ctx->stream);
   uint8_t* host = nullptr;
-  rc = read_back_pooled(d + o_png, static_cast<size_t>(len), ctx->stream, &host);
+  rc = png_to_host(ctx, d + o_canvas, canvas_pitch, out_plan->canvas_w, out_plan->canvas_h, d + o_png, &host, &len);
   if (rc) return rc;
-  ph.lap(IST_PHASE_D2H, "PNG D2H", nullptr);
+  ph.lap(IST_PHASE_PNG, "PNG encode (GPU) + D2H, overlapped", ctx->stream);
+  ph.lap(IST_PHASE_D2H, "(D2H: inside the PNG phase)", nullptr);
   *out_png = host; *out_len = len;
   pg.keep = true;
   return IST_OK;
@@ -706,18 +765,7 @@ int ist_png_encode_rgba8(ist_ctx* ctx, const uint8_t* pixels, size_t pitch, int6
   std::vector<RowsCopy> up{RowsCopy{ctx->scratch_dst, pixels, nullptr, pitch, row, static_cast<size_t>(h)}};
   rc = stager_of(ctx).upload(up, ctx->stream);
   if (rc) return rc;
-  const int64_t cap = ist_png_bound(w, h);
-  void* dpng = nullptr;
-  IST_HIP(hipMalloc(&dpng, static_cast<size_t>(cap)));
-  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{dpng};
-  int64_t len = 0;
-  rc = ist_png_encode_device(ctx, ctx->scratch_dst, row, w, h, dpng, cap, &len, ctx->stream);
-  if (rc) return rc;
-  uint8_t* host = nullptr;
-  rc = read_back_pooled(dpng, static_cast<size_t>(len), ctx->stream, &host);
-  if (rc) return rc;
-  *out_png = host; *out_len = len;
-  return IST_OK;
+  return png_to_host(ctx, ctx->scratch_dst, row, w, h, nullptr, out_png, out_len);
 }
 
 int ist_stitch_rgba8(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch,

@@ -25,7 +25,6 @@ namespace {
 
 inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (uint32_t(p[3]) << 24); }
 inline uint32_t le24(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16); }
-inline uint32_t le16(const uint8_t* p) { return p[0] | (p[1] << 8); }
 
 // ---- LSB-first bit reader (RFC 9649 section 3.1) --------------------------------------------------------------------
 struct Bits {
