@@ -105,24 +105,29 @@ static int64_t distinct_taps(double k, double o, int lo, int hi, int clo, int ch
     return c1 - c0 + 1;
   }
   if (filter == IST_FILTER_AREA) filter = IST_FILTER_BILINEAR;
-  std::vector<int32_t> idx;
-  idx.reserve(static_cast<size_t>(hi - lo) * 2);
-  for (int w = lo; w < hi; ++w) {
+  // the taps are monotonic in the canvas coordinate; clamping keeps them so
+  auto first_tap = [&](int w) -> int64_t {
     const double s = k * (static_cast<double>(w) + 0.5) + o;
-    if (filter == IST_FILTER_BILINEAR) {
-      double fl = std::floor(s - 0.5);
-      fl = std::min(std::max(fl, -4.0e9), 4.0e9);
-      const int64_t i0 = static_cast<int64_t>(fl);
-      idx.push_back(static_cast<int32_t>(std::min<int64_t>(std::max<int64_t>(i0, clo), chi)));
-      idx.push_back(static_cast<int32_t>(std::min<int64_t>(std::max<int64_t>(i0 + 1, clo), chi)));
-    } else {
-      double fl = std::floor(s);
-      fl = std::min(std::max(fl, -4.0e9), 4.0e9);
-      idx.push_back(static_cast<int32_t>(std::min<int64_t>(std::max<int64_t>(static_cast<int64_t>(fl), clo), chi)));
+    const double fl = std::min(std::max(std::floor(filter == IST_FILTER_BILINEAR ? s - 0.5 : s), -4.0e9), 4.0e9);
+    return static_cast<int64_t>(fl);
+  };
+  auto clampi = [&](int64_t v) { return std::min<int64_t>(std::max<int64_t>(v, clo), chi); };
+  const int64_t second = filter == IST_FILTER_BILINEAR ? 1 : 0;
+  if (std::fabs(k) <= 1.0) {
+    // neighbouring canvas coordinates are at most one source index apart: every index between the ends is touched
+    const int64_t a = first_tap(lo), b = first_tap(hi - 1);
+    return clampi(std::max(a, b) + second) - clampi(std::min(a, b)) + 1;
+  }
+  // a shrink skips indices: walk the coordinates in the direction the taps grow and count the new ones
+  int64_t count = 0, last = INT64_MIN;
+  for (int n = 0; n < hi - lo; ++n) {
+    const int64_t i0 = first_tap(k > 0.0 ? lo + n : hi - 1 - n);
+    for (int64_t v = i0; v <= i0 + second; ++v) {
+      const int64_t c = clampi(v);
+      if (c > last) { ++count; last = c; }
     }
   }
-  std::sort(idx.begin(), idx.end());
-  return static_cast<int64_t>(std::unique(idx.begin(), idx.end()) - idx.begin());
+  return count;
 }
 
 // Shape of a compiled job.  Production compiles use the constants below (the measured optima on MI355X) and touch
