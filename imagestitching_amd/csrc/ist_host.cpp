@@ -84,7 +84,7 @@ void pool_trim() {
 namespace {
 
 constexpr size_t kChunk = 4u << 20;      // one pinned chunk: 4 MiB (~75 us of PCIe, ~0.4 ms of one core's memcpy)
-constexpr int kLanes = 4;                // packing threads (each with its own stream and two chunks)
+constexpr int kLanes = 4;                // packing threads (each with its own stream and two chunks); 8 lanes made the banded path 1.5-4x SLOWER (measured)
 
 // a piece is what one chunk carries: n_rows whole rows, or one segment of a row that is longer than a chunk
 struct Piece { uint32_t item; size_t row0, n_rows, col0, n_cols; };

@@ -66,6 +66,15 @@ int read_back_pooled(const void* dev, size_t bytes, hipStream_t stream, uint8_t*
   return IST_OK;
 }
 
+// the context's second stream (high priority: its small kernels should not queue behind thousands of workgroups of the first)
+int ensure_aux(ist_ctx* ctx) {
+  if (ctx->aux) return IST_OK;
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); ctx->aux = nullptr; return fail(IST_E_HIP, "hipStreamCreate failed"); }
+  return IST_OK;
+}
+
 // The PNG file of a canvas in device memory -> a pooled pinned block (freed with ist_free).  `dfile` = device scratch of
 // at least ist_png_bound bytes (nullptr: the context's own).  The compressing encoder hands the file over slab by slab
 // while it is still compressing (png_encode_device_deflate); the stored form is encoded whole and copied once.
@@ -79,12 +88,7 @@ int png_to_host(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64
   }
   int64_t len = 0;
   if (ctx->png_level > 0) {
-    if (!ctx->aux) {
-      // high priority: its small gather kernels should not queue behind the compression kernels' thousands of workgroups
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); ctx->aux = nullptr; return fail(IST_E_HIP, "hipStreamCreate failed"); }
-    }
+    { const int rc = ensure_aux(ctx); if (rc) return rc; }
     uint8_t* host = static_cast<uint8_t*>(pool_take(static_cast<size_t>(cap)));
     if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
     const int rc = png_encode_device_deflate(ctx, canvas, pitch, w, h, dfile, cap, &len, ctx->stream, host, ctx->aux);
@@ -788,7 +792,10 @@ int ist_stitch_rgba8(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* 
     DeviceGuard g(ctx->device);
     rc = render_to_scratch(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, images, src, src_pitch,
                            n_images, filter, nullptr, nullptr, nullptr);
-    // the export (index.js:1577-1579): the whole canvas in one DMA into a pinned block of the pool
+    // the export (index.js:1577-1579): the whole canvas in one DMA into a pinned block of the pool.
+    // (Tried and dropped: rendering a vertical strip band by band so that band k's rows go down on a second stream while band
+    // k+1's sources go up.  With both directions busy the copy engines did not sustain full duplex: either the uploads or the
+    // downloads fell to ~16 GB/s, 13-48 ms per stitch against a steady 16.5 ms for upload-all, launch, download-all.)
     if (rc == IST_OK)
       rc = read_back_pooled(ctx->scratch_dst, static_cast<size_t>(out_plan->canvas_w) * 4 * static_cast<size_t>(out_plan->canvas_h), ctx->stream, out_pixels);
   }
