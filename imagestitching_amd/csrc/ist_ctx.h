@@ -41,7 +41,7 @@ struct ist_job {
   ist::Compiled host;
   uint8_t* d_tables = nullptr;           // ONE device allocation holding the five tables below
   size_t d_tables_bytes = 0;
-  hipEvent_t launched = nullptr;         // recorded behind the job's latest launch: its tables may be re-used after it
+  bool launched = false;                 // ist_job_destroy waits for the device before it hands the tables to the next job
   ist::DevOp* d_ops = nullptr;
   ist::DevCell* d_cells = nullptr;
   ist::DevBand* d_bands = nullptr;
