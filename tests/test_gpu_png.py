@@ -278,3 +278,22 @@ def test_compressed_png_many_random_shapes_and_contents():
         else:
             a = _screenshot_like(case, h, w)
         _check_compressed(np.ascontiguousarray(a))
+
+
+def test_compressed_png_of_several_slabs_reaches_the_host_whole(monkeypatch):
+    """A canvas of more than 4096 chunks (64 MiB of filtered stream) is compressed slab by slab, one ahead of the host, and
+    each slab's bytes travel to the pinned result on a second stream while the next one compresses (ist_png_deflate.hip):
+    three slabs here, each its own IDAT, the last one ragged; then the same with a small IDAT limit, so that slabs also
+    split inside.  Both files must decode (PIL, the product's decoder, and a by-hand chunk walk that checks every CRC
+    and the Adler-32) to the canvas."""
+    h, w = 9000, 4032                                             # 145 MB; a chunk is one row here: 9000 chunks = 4096 + 4096 + 808
+    a = np.empty((h, w, 4), np.uint8)
+    a[:3000] = _photo_like(11, 3000, w)
+    a[3000:6000] = U.rand_image(12, 3000, w, opaque=False)        # incompressible: stored chunks
+    a[6000:] = 255
+    a[6000::37, 100:900, :3] = 30                                 # flat with a few lines
+    for limit, least in ((None, 3), ("1048576", 40)):
+        if limit:
+            monkeypatch.setenv("IST_PNG_IDAT_LIMIT", limit)
+        png, n_idat = _check_compressed(a)
+        assert n_idat >= least, n_idat
