@@ -503,6 +503,7 @@ def run_sharded(args):
     full_src = [synth(k, w, h, dev) for k, (w, h) in enumerate(UNIFORM)]
     full_out = torch.empty((p_full.canvas_h, p_full.canvas_w, 4), dtype=torch.uint8, device=dev)
     t_rep = timed(lambda: job_full.launch(full_src, full_out), args.steps, 3)
+    B_full = int(job_full.info["algorithmic_bytes"])
     if rank == 0:
         line = {
             "metric": "stitched megapixels/sec (9x12 MP vertical)", "value": round(mp / value_sec, 1), "unit": "MP/s",
@@ -511,7 +512,13 @@ def run_sharded(args):
             "config": {"workload": "BASELINE configs[3]: 9 x 4032x3024 vertical stitch, image i on GPU i mod %d, bands gathered to "
                                    "GPU 0 with one grouped RCCL send/recv batch (%d bands received in place)" % (world, gather["image"]["bands_in_place"]),
                        "timed_region": "per-rank band launches + gather + root launch; inputs resident in each owner's HBM"},
-            "roofline": None, "cpu_baseline": None,
+            # the dominant kernel is the one of the N = 1 line; here it is timed on the whole 9 x 12 MP job that every rank
+            # launches in the replicas leg (wall time per launch of back-to-back launches, MAX over ranks; no PMC at N > 1)
+            "roofline": {"bound": "hbm", "achieved": round(B_full / t_rep / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(B_full / t_rep / 8e12, 4), "traffic": None, "kernel": "ist_stitch_kernel",
+                         "kernel_us": round(t_rep * 1e6, 2), "algorithmic_bytes_per_launch": B_full,
+                         "what": "per GPU, from the replicas leg (each rank launches the whole job); slowest rank"},
+            "cpu_baseline": None,
             "extra": {"regions": regions, "gather": gather,
                       "regions_note": "value = resident/image (the contract's region and BASELINE's split).  from_pinned_host and from_jpeg add each rank's own "
                                       "ingest (its PCIe link / its decoder) in front of the same step; /band deals equal output rows to every rank instead of whole images.  "
