@@ -87,26 +87,31 @@ struct WgShared {
   uint8_t zig[64];
 };
 
+// (THREADS = the subsequences whose bits are staged; the loops stride by the real workgroup size)
 template <int THREADS>
-__device__ __forceinline__ void load_shared(WgShared<THREADS>* sh, const DevImg* img, uint32_t first_bit) {
+__device__ __forceinline__ void load_record(WgShared<THREADS>* sh, const DevImg* img) {
   static_assert(sizeof(DevImg) % 4 == 0 && sizeof(JpegHuffTable) % 4 == 0, "word copies");
   const uint32_t* gi = reinterpret_cast<const uint32_t*>(img);
   uint32_t* li = reinterpret_cast<uint32_t*>(&sh->img);
-  for (uint32_t k = threadIdx.x; k < sizeof(DevImg) / 4; k += THREADS) li[k] = gi[k];
-  const uint32_t* gt = reinterpret_cast<const uint32_t*>(img->tables);
-  uint32_t* lt = reinterpret_cast<uint32_t*>(sh->tab);
-  for (uint32_t k = threadIdx.x; k < 8 * sizeof(JpegHuffTable) / 4; k += THREADS) lt[k] = gt[k];
+  for (uint32_t k = threadIdx.x; k < sizeof(DevImg) / 4; k += blockDim.x) li[k] = gi[k];
   if (threadIdx.x < 64) sh->zig[threadIdx.x] = kZig[threadIdx.x];
   if (threadIdx.x < 10) {
     const uint32_t comp = img->slot_comp[threadIdx.x] < 3 ? img->slot_comp[threadIdx.x] : 0u;
     sh->slot_tabs[threadIdx.x] = (img->dc_tab[comp] & 7u) | (static_cast<uint32_t>(img->ac_tab[comp] & 7u) << 8) | (comp << 16);
   }
+  __syncthreads();
+}
+template <int THREADS>
+__device__ __forceinline__ void load_stream(WgShared<THREADS>* sh, const DevImg* img, uint32_t first_bit) {
+  const uint32_t* gt = reinterpret_cast<const uint32_t*>(img->tables);
+  uint32_t* lt = reinterpret_cast<uint32_t*>(sh->tab);
+  for (uint32_t k = threadIdx.x; k < 8 * sizeof(JpegHuffTable) / 4; k += blockDim.x) lt[k] = gt[k];
   // the stream is 256-byte aligned on the device and carries 16 bytes of zero padding behind its last bit; first_bit
   // is a multiple of kSubBits, so these are aligned word loads.  Words past the padding read as zero.
   const uint32_t words_in_stream = static_cast<uint32_t>((img->bits >> 3) + 16) >> 2;
   const GlobalWords gw = (GlobalWords)(img->stream) + (first_bit >> 5);
   const uint32_t w0 = first_bit >> 5;
-  for (uint32_t k = threadIdx.x; k < THREADS * (kSubBits / 32) + kMarginWords; k += THREADS)
+  for (uint32_t k = threadIdx.x; k < THREADS * (kSubBits / 32) + kMarginWords; k += blockDim.x)
     sh->bits[k] = (w0 + k < words_in_stream) ? __builtin_bswap32(gw[k]) : 0u;
   __syncthreads();
 }
@@ -169,29 +174,51 @@ __device__ __forceinline__ void symbol(const WgShared<THREADS>* sh, uint32_t fir
 // writing pass)
 struct Tally { uint32_t blocks; int32_t dc[3]; };
 
-// Synchronisation passes: decodes from state S until the bit position reaches `limit`.
-// (Tried and dropped: two checkpoints per subsequence that let a re-decode stop as soon as it meets the previous
-// decode's path.  A workgroup's pass costs as much as its slowest lane and some lane always needs the whole
-// subsequence, so the passes got no shorter and every step paid for the check: 1.6 -> 2.0 ms.)
+// Synchronisation passes: decodes from state S until the bit position reaches `limit`, in two legs: up to bit `mid` of
+// the subsequence's range, then the rest.  The state between the legs is a CHECKPOINT.  A re-decode from a new start
+// state almost always falls into step with the previous decode of the same subsequence within a few symbols; when it
+// arrives at the checkpoint in the recorded state, the second leg would repeat the old path, so it is skipped: the exit
+// state is the old one and the tally is the new first leg + the old second leg.  A workgroup's pass costs as much as
+// its slowest lane: in the later passes, where only a few lanes re-decode, this cuts a pass from a whole subsequence to
+// its first quarter.  (As a test inside the symbol loop — two checkpoints, checked at every step — the same idea cost
+// every step of every pass and LOST 25 %; as a loop boundary it is free.)
+constexpr uint32_t kCheckBits = 256;
+struct Check { uint32_t p, cz; Tally t; };
+
 template <int THREADS>
-__device__ __forceinline__ Tally run_count(const WgShared<THREADS>* sh, uint32_t first_bit, State& S, uint32_t limit) {
+__device__ __forceinline__ Tally run_count(const WgShared<THREADS>* sh, uint32_t first_bit, State& S, uint32_t limit, uint32_t mid,
+                                           bool have_ref, uint32_t old_p, uint32_t old_cz, const Tally& old_t, Check& ck) {
   Tally T; T.blocks = 0; T.dc[0] = T.dc[1] = T.dc[2] = 0;
   const uint32_t slots = static_cast<uint32_t>(sh->img.slots);
   uint32_t tabs = sh->slot_tabs[S.c];
-  while (S.p < limit) {
-    uint32_t at = 1; int val = 0; bool stored, bad;
-    symbol<false>(sh, first_bit, S, tabs, &at, &val, &stored, &bad);
-    if (stored && at == 0) {
-      const uint32_t comp = tabs >> 16;
-      T.dc[0] += comp == 0 ? val : 0; T.dc[1] += comp == 1 ? val : 0; T.dc[2] += comp == 2 ? val : 0;
+  auto leg = [&](uint32_t until) {
+    while (S.p < until) {
+      uint32_t at = 1; int val = 0; bool stored, bad;
+      symbol<false>(sh, first_bit, S, tabs, &at, &val, &stored, &bad);
+      if (stored && at == 0) {
+        const uint32_t comp = tabs >> 16;
+        T.dc[0] += comp == 0 ? val : 0; T.dc[1] += comp == 1 ? val : 0; T.dc[2] += comp == 2 ? val : 0;
+      }
+      if (S.z >= 64) {                                          // block finished
+        S.z = 0;
+        S.c = (S.c + 1 == slots) ? 0u : S.c + 1;
+        ++T.blocks;
+        tabs = sh->slot_tabs[S.c];
+      }
     }
-    if (S.z >= 64) {                                          // block finished
-      S.z = 0;
-      S.c = (S.c + 1 == slots) ? 0u : S.c + 1;
-      ++T.blocks;
-      tabs = sh->slot_tabs[S.c];
-    }
+  };
+  leg(min(mid, limit));
+  const uint32_t cz = (S.c << 8) | S.z;
+  if (have_ref && ck.p == S.p && ck.cz == cz) {                 // in step with the previous decode from here on
+    const Tally first = T;
+    T.blocks += old_t.blocks - ck.t.blocks;
+    for (int c = 0; c < 3; ++c) T.dc[c] += old_t.dc[c] - ck.t.dc[c];
+    ck.t = first;
+    S.p = old_p; S.c = old_cz >> 8; S.z = old_cz & 255u;
+    return T;
   }
+  ck.p = S.p; ck.cz = cz; ck.t = T;
+  leg(limit);
   return T;
 }
 
@@ -273,6 +300,7 @@ struct SyncArgs {
   uint32_t* out_p; uint32_t* out_cz;
   uint32_t* tally;                                     // per subsequence: blocks, dc[3]
   uint32_t* start_p; uint32_t* start_cz;               // the start state each subsequence was last decoded from
+  uint32_t* checks;                                    // per subsequence: its checkpoint (p, cz, tally: 6 words)
   uint32_t* half_total;                                // per 128 subsequences: the sum of their tallies
   uint32_t* changed; int32_t pass;
 };
@@ -284,19 +312,36 @@ struct SyncArgs {
 // the PREVIOUS launch; a launch in which no workgroup's last exit state changed is the global fixed point.  (The
 // "overflow" idea of the published scheme, restated for a barrier-synchronised workgroup.)
 constexpr int kInnerPasses = 48;
+// GHOST LANES.  In the first launch the first thread of a workgroup has no left neighbour to take its start state from
+// (that neighbour belongs to the previous workgroup), so the whole workgroup used to settle on a guess, and the second
+// launch — whose only news is the previous workgroup's true exit state — re-decoded thread 0 of nearly EVERY workgroup:
+// a full subsequence time for the launch, since a pass costs as much as its slowest lane.  Now a fifth wave carries two
+// ghost lanes that decode the two subsequences in front of the workgroup (from a guess, then from each other), and
+// thread 0 starts from the second ghost's exit: after two subsequences the decoder is in step almost surely, so the
+// second launch finds nothing to redo and returns before it stages anything (0.35 -> 0.05 ms, measured).
+constexpr int kGhosts = 2;
+constexpr int kSyncBlock = kSyncThreads + 64;
 
-__global__ __launch_bounds__(kSyncThreads) void ist_jpeg_sync_kernel(const SyncArgs A) {
-  __shared__ uint32_t ex_p[kSyncThreads], ex_cz[kSyncThreads];
+__global__ __launch_bounds__(kSyncBlock) void ist_jpeg_sync_kernel(const SyncArgs A) {
+  __shared__ uint32_t ex_p[kSyncThreads + kGhosts], ex_cz[kSyncThreads + kGhosts];
   __shared__ uint32_t tot[2][4];
-  __shared__ WgShared<kSyncThreads> sh;
+  __shared__ WgShared<kSyncThreads + kGhosts> sh;
   const int tid = threadIdx.x;
-  const int g0 = blockIdx.x * kSyncThreads, g = g0 + tid;        // (the grid is exactly the padded subsequence count)
+  const bool owned = tid < kSyncThreads;
+  const int g0 = blockIdx.x * kSyncThreads;                      // (the grid is exactly the padded subsequence count / 256)
   const DevImg* gimg = &A.imgs[A.sub_img[g0 / kWriteThreads]];   // one image per workgroup
-  const uint32_t first_bit = static_cast<uint32_t>(g0 - gimg->first_sub) * static_cast<uint32_t>(kSubBits);
+  const int i0 = g0 - gimg->first_sub;                           // the workgroup's first subsequence inside its image
+  const int n_ghost = A.pass == 0 ? min(kGhosts, i0) : 0;
+  const uint32_t first_bit = static_cast<uint32_t>(i0 - n_ghost) * static_cast<uint32_t>(kSubBits);
   if (tid < 8) tot[tid >> 2][tid & 3] = 0u;
-  load_shared(&sh, gimg, first_bit);
+  load_record(&sh, gimg);
+  // e = position in the exchange arrays: ghosts first, then the owned subsequences; everybody's left neighbour is e - 1
+  const int ghost_k = tid - kSyncThreads;                        // 0 .. for the ghost wave's first lanes
+  const int e = owned ? tid + kGhosts : kGhosts - n_ghost + ghost_k;
+  const int g = owned ? g0 + tid : g0 - n_ghost + ghost_k;
   const uint32_t i = static_cast<uint32_t>(g - sh.img.first_sub);
-  const bool live = i < static_cast<uint32_t>(sh.img.n_sub);      // the padding subsequences of an image idle
+  const bool ghost = !owned && ghost_k < n_ghost;
+  const bool live = owned ? i < static_cast<uint32_t>(sh.img.n_sub) : ghost;      // the padding subsequences of an image idle
   uint32_t limit = 0;
   if (live) {
     const uint64_t end = static_cast<uint64_t>(i + 1) * static_cast<uint64_t>(kSubBits);
@@ -307,35 +352,53 @@ __global__ __launch_bounds__(kSyncThreads) void ist_jpeg_sync_kernel(const SyncA
   uint32_t st_p = have ? A.start_p[g] : 0u, st_cz = have ? A.start_cz[g] : 0u;
   uint32_t my_p = have ? A.in_p[g] : 0u, my_cz = have ? A.in_cz[g] : 0u;
   Tally T; T.blocks = 0; T.dc[0] = T.dc[1] = T.dc[2] = 0;
-  if (have) { T.blocks = A.tally[4 * g]; T.dc[0] = static_cast<int32_t>(A.tally[4 * g + 1]); T.dc[1] = static_cast<int32_t>(A.tally[4 * g + 2]); T.dc[2] = static_cast<int32_t>(A.tally[4 * g + 3]); }
-  bool settled = false;
-  for (int it = 0; it < kInnerPasses; ++it) {
-    uint32_t sp = 0, scz = 0;
-    if (live && i != 0) {                            // (the first subsequence of an image starts from the true state 0, 0, 0)
-      if (it == 0 || tid == 0) {                     // from the previous launch (or, in the very first pass, a guess: a block starts here)
-        if (A.pass == 0) { sp = i * static_cast<uint32_t>(kSubBits); scz = 0; }
-        else { sp = A.in_p[g - 1]; scz = A.in_cz[g - 1]; }
-      } else { sp = ex_p[tid - 1]; scz = ex_cz[tid - 1]; }      // from the left neighbour, this launch
+  Check ck; ck.p = 0xFFFFFFFFu; ck.cz = 0; ck.t = T;
+  if (have) {
+    T.blocks = A.tally[4 * g]; T.dc[0] = static_cast<int32_t>(A.tally[4 * g + 1]); T.dc[1] = static_cast<int32_t>(A.tally[4 * g + 2]); T.dc[2] = static_cast<int32_t>(A.tally[4 * g + 3]);
+    const uint32_t* q = A.checks + 6 * static_cast<size_t>(g);
+    ck.p = q[0]; ck.cz = q[1]; ck.t.blocks = q[2]; ck.t.dc[0] = static_cast<int32_t>(q[3]); ck.t.dc[1] = static_cast<int32_t>(q[4]); ck.t.dc[2] = static_cast<int32_t>(q[5]);
+  }
+  // a later launch in which nobody's start state moved has nothing to decode: skip the staging too
+  bool any = true;
+  if (A.pass > 0) {
+    const bool moved = live && i != 0 && !(st_p == A.in_p[g - 1] && st_cz == A.in_cz[g - 1]);
+    any = __syncthreads_or(moved ? 1 : 0) != 0;
+  }
+  bool settled = !any;
+  if (any) {
+    load_stream(&sh, gimg, first_bit);
+    for (int it = 0; it < kInnerPasses; ++it) {
+      uint32_t sp = 0, scz = 0;
+      if (live && i != 0) {                            // (the first subsequence of an image starts from the true state 0, 0, 0)
+        const bool has_left = e > kGhosts - n_ghost;   // a ghost or an owned lane to the left, inside this workgroup's exchange
+        if (A.pass == 0) {
+          if (it == 0 || !has_left) { sp = i * static_cast<uint32_t>(kSubBits); scz = 0; }           // a guess: a block starts here
+          else { sp = ex_p[e - 1]; scz = ex_cz[e - 1]; }
+        } else {
+          if (it == 0 || tid == 0) { sp = A.in_p[g - 1]; scz = A.in_cz[g - 1]; }                       // the previous launch's exit states
+          else { sp = ex_p[e - 1]; scz = ex_cz[e - 1]; }                                               // the left neighbour, this launch
+        }
+      }
+      const bool redo = live && !(have && st_p == sp && st_cz == scz);
+      if (redo) {
+        State S; S.p = sp; S.c = scz >> 8; S.z = scz & 255u;
+        T = run_count(&sh, first_bit, S, limit, i * static_cast<uint32_t>(kSubBits) + kCheckBits, have, my_p, my_cz, T, ck);
+        my_p = S.p; my_cz = (S.c << 8) | S.z;
+        st_p = sp; st_cz = scz; have = true;
+      }
+      __syncthreads();                                 // every thread has read its neighbour's previous exit state
+      if (live) { ex_p[e] = my_p; ex_cz[e] = my_cz; }
+      if (!__syncthreads_or(redo ? 1 : 0)) { settled = true; break; }
     }
-    const bool redo = live && !(have && st_p == sp && st_cz == scz);
-    if (redo) {
-      State S; S.p = sp; S.c = scz >> 8; S.z = scz & 255u;
-      T = run_count(&sh, first_bit, S, limit);
-      my_p = S.p; my_cz = (S.c << 8) | S.z;
-      st_p = sp; st_cz = scz; have = true;
-    }
-    __syncthreads();                                 // every thread has read its neighbour's previous exit state
-    ex_p[tid] = my_p; ex_cz[tid] = my_cz;
-    if (!__syncthreads_or(redo ? 1 : 0)) { settled = true; break; }
   }
   // the tallies of each half of the workgroup, for the writing pass's bases (integer adds: order does not matter)
-  if (live) {
+  if (live && owned) {
     atomicAdd(&tot[tid >> 7][0], T.blocks); atomicAdd(&tot[tid >> 7][1], static_cast<uint32_t>(T.dc[0]));
     atomicAdd(&tot[tid >> 7][2], static_cast<uint32_t>(T.dc[1])); atomicAdd(&tot[tid >> 7][3], static_cast<uint32_t>(T.dc[2]));
   }
   __syncthreads();
   if (tid < 8) A.half_total[(2 * blockIdx.x + (tid >> 2)) * 4 + (tid & 3)] = tot[tid >> 2][tid & 3];
-  if (!live) return;
+  if (!live || !owned) return;
   // the launch changed something the NEXT workgroup depends on (or ran out of inner passes): not the fixed point yet
   const bool last = tid == kSyncThreads - 1 || i + 1 == static_cast<uint32_t>(sh.img.n_sub);
   if (A.pass == 0 || !settled || (last && (A.in_p[g] != my_p || A.in_cz[g] != my_cz))) {
@@ -344,6 +407,8 @@ __global__ __launch_bounds__(kSyncThreads) void ist_jpeg_sync_kernel(const SyncA
   A.out_p[g] = my_p; A.out_cz[g] = my_cz;
   A.tally[4 * g] = T.blocks; A.tally[4 * g + 1] = static_cast<uint32_t>(T.dc[0]); A.tally[4 * g + 2] = static_cast<uint32_t>(T.dc[1]); A.tally[4 * g + 3] = static_cast<uint32_t>(T.dc[2]);
   A.start_p[g] = st_p; A.start_cz[g] = st_cz;
+  uint32_t* q = A.checks + 6 * static_cast<size_t>(g);
+  q[0] = ck.p; q[1] = ck.cz; q[2] = ck.t.blocks; q[3] = static_cast<uint32_t>(ck.t.dc[0]); q[4] = static_cast<uint32_t>(ck.t.dc[1]); q[5] = static_cast<uint32_t>(ck.t.dc[2]);
 }
 
 struct WriteArgs { const DevImg* imgs; const uint16_t* sub_img; const uint32_t* p; const uint32_t* cz; const uint32_t* tally; const uint32_t* half_total; };
@@ -363,7 +428,8 @@ __global__ __launch_bounds__(kWriteThreads) void ist_jpeg_write_kernel(const Wri
 #pragma unroll
   for (int q = 0; q < 32; ++q) slot[q] = 0u;
   if (tid < 4) base[tid] = 0u;
-  load_shared(&sh, gimg, first_bit);
+  load_record(&sh, gimg);
+  load_stream(&sh, gimg, first_bit);
   const DevImg& I = sh.img;
   const uint32_t i = static_cast<uint32_t>(g - I.first_sub);
   const bool live = i < static_cast<uint32_t>(I.n_sub);
@@ -449,6 +515,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   const size_t o_img = take(sizeof(DevImg) * n_img), o_sub = take(2 * static_cast<size_t>(n_half));
   const size_t o_p0 = take(4 * static_cast<size_t>(ns)), o_p1 = take(4 * static_cast<size_t>(ns)), o_cz0 = take(4 * static_cast<size_t>(ns)), o_cz1 = take(4 * static_cast<size_t>(ns));
   const size_t o_sp = take(4 * static_cast<size_t>(ns)), o_scz = take(4 * static_cast<size_t>(ns));
+  const size_t o_checks = take(24 * static_cast<size_t>(ns));
   const size_t o_tally = take(16 * static_cast<size_t>(ns)), o_half = take(16 * static_cast<size_t>(n_half)), o_flag = take(4), o_err = take(4 * n_img);
   // the caller's grow-only scratch (a context keeps it across calls: no allocation, and no implicit device synchronisation
   // of a free, per call), or a one-off allocation
@@ -493,8 +560,8 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   for (int pass = 0; pass < kMaxPasses; ++pass) {
     passes_run = pass + 1;
     JG_HIP(hipMemsetAsync(d_flag, 0, 4, stream));
-    SyncArgs A{d_img, d_sub, P[cur], CZ[cur], P[cur ^ 1], CZ[cur ^ 1], d_tally, reinterpret_cast<uint32_t*>(d + o_sp), reinterpret_cast<uint32_t*>(d + o_scz), d_half, d_flag, pass};
-    hipLaunchKernelGGL(ist_jpeg_sync_kernel, dim3(static_cast<unsigned>(ns / kSyncThreads)), dim3(kSyncThreads), 0, stream, A);
+    SyncArgs A{d_img, d_sub, P[cur], CZ[cur], P[cur ^ 1], CZ[cur ^ 1], d_tally, reinterpret_cast<uint32_t*>(d + o_sp), reinterpret_cast<uint32_t*>(d + o_scz), reinterpret_cast<uint32_t*>(d + o_checks), d_half, d_flag, pass};
+    hipLaunchKernelGGL(ist_jpeg_sync_kernel, dim3(static_cast<unsigned>(ns / kSyncThreads)), dim3(kSyncBlock), 0, stream, A);
     JG_HIP(hipGetLastError());
     cur ^= 1;
     if (pass == 0) continue;                       // (the first launch starts from guesses: a second one always runs)
