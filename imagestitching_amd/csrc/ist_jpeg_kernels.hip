@@ -133,12 +133,48 @@ __device__ __forceinline__ int chroma_at(const uint8_t* P, int pitch, int cw, in
   return (cur * 3 + (3 * r0[i - 1] + r1[i - 1]) + 8) >> 4;
 }
 
+__device__ __forceinline__ uint32_t ycc_to_rgba(int Yv, int cb, int cr) {
+  // 16-bit fixed point: FIX(1.40200)=91881, FIX(1.77200)=116130, FIX(0.71414)=46802, FIX(0.34414)=22554
+  const int r = Yv + ((91881 * cr + 32768) >> 16);
+  const int b = Yv + ((116130 * cb + 32768) >> 16);
+  const int g = Yv + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+  return static_cast<uint32_t>(clampi(r, 0, 255)) | (static_cast<uint32_t>(clampi(g, 0, 255)) << 8) |
+         (static_cast<uint32_t>(clampi(b, 0, 255)) << 16) | 0xFF000000u;
+}
+
+// 4:2:0 (the photo case), one thread per 4 output pixels x0 .. x0+3 of one row: the four pixels lie over chroma columns
+// i0 and i0+1 and blend with i0-1 and i0+2, so the thread reads 4 columns x 2 rows per chroma plane ONCE (the generic
+// path below reads 4 bytes per plane per PIXEL) and blends them vertically once.  Clamping a neighbour's column index to
+// the plane reproduces the edge rules of chroma_at exactly: (4 c + 8) >> 4 = (3 c + c + 8) >> 4.
+__device__ __forceinline__ void color4_h2v2(const ColorArgs& A, int x0, int y, uint32_t px[4]) {
+  const int j = y >> 1, i0 = x0 >> 1;
+  const int jn = (y & 1) ? min(j + 1, A.chh - 1) : max(j - 1, 0);
+  const int col[4] = {max(i0 - 1, 0), i0, min(i0 + 1, A.cw - 1), min(i0 + 2, A.cw - 1)};
+  int cb[4], cr[4];
+  {
+    const uint8_t* b0 = A.Cb + static_cast<size_t>(j) * A.pitch_c; const uint8_t* b1 = A.Cb + static_cast<size_t>(jn) * A.pitch_c;
+    const uint8_t* r0 = A.Cr + static_cast<size_t>(j) * A.pitch_c; const uint8_t* r1 = A.Cr + static_cast<size_t>(jn) * A.pitch_c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cb[k] = 3 * b0[col[k]] + b1[col[k]]; cr[k] = 3 * r0[col[k]] + r1[col[k]]; }
+  }
+  const uint32_t yy = *reinterpret_cast<const uint32_t*>(A.Y + static_cast<size_t>(y) * A.pitch_y + x0);   // (x0 % 4 == 0, pitch % 8 == 0)
+  // pixel k: own column own[k], neighbour nb[k], rounding 8 (even x) / 7 (odd x)
+  const int own[4] = {1, 1, 2, 2}, nb[4] = {0, 2, 1, 3}, rnd[4] = {8, 7, 8, 7};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int u = (cb[own[k]] * 3 + cb[nb[k]] + rnd[k]) >> 4, v = (cr[own[k]] * 3 + cr[nb[k]] + rnd[k]) >> 4;
+    px[k] = ycc_to_rgba(static_cast<int>((yy >> (8 * k)) & 255u), u - 128, v - 128);
+  }
+}
+
 // one thread per 4 output pixels
 __global__ __launch_bounds__(256) void ist_jpeg_color_kernel(const ColorArgs A) {
   const int gx = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int y = blockIdx.y;
   if (gx >= A.width) return;
   uint32_t px[4];
+  if (A.ncomp == 3 && A.hs == 2 && A.vs == 2) color4_h2v2(A, gx, y, px);
+  else
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int x = min(gx + k, A.width - 1);
