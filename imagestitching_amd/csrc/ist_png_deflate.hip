@@ -23,6 +23,7 @@
 //     stream exceeds the IDAT limit), a second kernel copies them into place, and ~100 header/trailer bytes are patched.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -57,6 +58,7 @@ struct DeflArgs {
   int32_t rows_per_chunk;        // > 0: a chunk is this many whole rows; 0: a chunk is a piece of one row
   int32_t pieces_per_row, piece_px;
   int64_t chunk0;                // first chunk of this launch (the canvas is encoded in slabs of chunks)
+  unsigned long long* dbg;       // IST_PNG_PHASES (tuning): 8 clock samples per chunk
 };
 
 __device__ __forceinline__ int padpos(int p) { return p + ((p >> 6) << 2); }
@@ -169,27 +171,44 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
 
   for (int i = tid; i < SLOT / 4; i += 256) outw[i] = 0;
   for (int i = tid; i < 288; i += 256) { hist[i] = 0; clen[i] = 0; code[i] = 0; }
+  if (P.dbg && tid == 0) P.dbg[chunk * 8 + 0] = wall_clock64();
   // ---- A. load + Paeth filter into LDS
   const int npix = npr * nrows;
-  for (int q = tid; q < npix; q += 256) {
-    const int r = q / npr, xx = q - r * npr;
-    const int64_t y = y0 + r; const int x = x0 + xx;
-    const uint8_t* row = P.canvas + static_cast<size_t>(y) * P.pitch;
-    const uint32_t cur = *reinterpret_cast<const uint32_t*>(row + 4 * static_cast<size_t>(x));
-    const uint32_t a = x > 0 ? *reinterpret_cast<const uint32_t*>(row + 4 * static_cast<size_t>(x - 1)) : 0u;
-    uint32_t b = 0, c = 0;
-    if (y > 0) {
-      b = *reinterpret_cast<const uint32_t*>(row - P.pitch + 4 * static_cast<size_t>(x));
-      c = x > 0 ? *reinterpret_cast<const uint32_t*>(row - P.pitch + 4 * static_cast<size_t>(x - 1)) : 0u;
-    }
-    const uint32_t fv = paeth4(cur, a, b, c);
-    const int pos = r * rowlen + hasf + 4 * xx;
+  // four pixels per thread and round, all sixteen loads issued before the first filter: the one-pixel-per-iteration form
+  // had four loads in flight per thread and spent 15 us of a chunk's 96 waiting for them (IST_PNG_PHASES, measured)
+  for (int q0 = tid; q0 < npix; q0 += 1024) {
+    uint32_t cur[4], a[4], b[4], c[4]; int pos[4]; bool first[4], on[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) filt[padpos(pos + k)] = static_cast<uint8_t>(fv >> (8 * k));
-    if (hasf && xx == 0) filt[padpos(r * rowlen)] = 4;          // filter type of the row
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + 256 * u;
+      on[u] = q < npix;
+      cur[u] = a[u] = b[u] = c[u] = 0u; pos[u] = 0; first[u] = false;
+      if (on[u]) {
+        const int r = q / npr, xx = q - r * npr;
+        const int64_t y = y0 + r; const int x = x0 + xx;
+        const uint8_t* row = P.canvas + static_cast<size_t>(y) * P.pitch;
+        cur[u] = *reinterpret_cast<const uint32_t*>(row + 4 * static_cast<size_t>(x));
+        if (x > 0) a[u] = *reinterpret_cast<const uint32_t*>(row + 4 * static_cast<size_t>(x - 1));
+        if (y > 0) {
+          b[u] = *reinterpret_cast<const uint32_t*>(row - P.pitch + 4 * static_cast<size_t>(x));
+          if (x > 0) c[u] = *reinterpret_cast<const uint32_t*>(row - P.pitch + 4 * static_cast<size_t>(x - 1));
+        }
+        pos[u] = r * rowlen + hasf + 4 * xx;
+        first[u] = hasf && xx == 0;
+        if (first[u]) filt[padpos(r * rowlen)] = 4;              // filter type of the row
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!on[u]) continue;
+      const uint32_t fv = paeth4(cur[u], a[u], b[u], c[u]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) filt[padpos(pos[u] + k)] = static_cast<uint8_t>(fv >> (8 * k));
+    }
   }
   __syncthreads();
 
+  if (P.dbg && tid == 0) P.dbg[chunk * 8 + 1] = wall_clock64();
   // ---- B. histogram (+ the end-of-block symbol), Adler partials
   const int base = tid * SPAN;
   const int n = max(0, min(SPAN, len - base));
@@ -209,6 +228,7 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
     P.ad_n[chunk] = static_cast<uint32_t>(len);
   }
 
+  if (P.dbg && tid == 0) P.dbg[chunk * 8 + 2] = wall_clock64();
   // ---- C. code lengths.  First a lower bound: no prefix code beats the entropy of the token symbols, so a chunk whose
   // entropy already exceeds its stored size (random data) skips the code construction altogether.
   const int lead = chunk == 0 ? 2 : 0;               // the zlib header travels with the first chunk
@@ -264,13 +284,19 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
     for (int i = tid; i < ns; i += 256) wt[i] = keys[i] >> 9;
     __syncthreads();
     if (tid == 0) {
+      // (the weights at the heads of the two queues are kept in registers: one LDS read per pick instead of two
+      // compares' worth)
       int li = 0, ii = ns, nn = ns;           // next unused leaf, next unused internal node, nodes so far
+      uint32_t wl = wt[0], wi = 0xFFFFFFFFu;  // their weights (0xFFFFFFFF: that queue is empty)
       for (int k = 0; k < ns - 1; ++k) {
-        int pick[2];
+        int pick[2]; uint32_t sum = 0;
+#pragma unroll
         for (int t = 0; t < 2; ++t) {
-          if (li < ns && (ii >= nn || wt[li] <= wt[ii])) pick[t] = li++; else pick[t] = ii++;
+          if (wl <= wi) { pick[t] = li++; sum += wl; wl = li < ns ? wt[li] : 0xFFFFFFFFu; }
+          else { pick[t] = ii++; sum += wi; wi = ii < nn ? wt[ii] : 0xFFFFFFFFu; }
         }
-        wt[nn] = wt[pick[0]] + wt[pick[1]];
+        wt[nn] = sum;
+        if (wi == 0xFFFFFFFFu && ii == nn) wi = sum;             // the new node is the internal queue's head
         parent[pick[0]] = static_cast<uint16_t>(nn); parent[pick[1]] = static_cast<uint16_t>(nn);
         ++nn;
       }
@@ -316,6 +342,7 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
     __syncthreads();
   }
 
+  if (P.dbg && tid == 0) P.dbg[chunk * 8 + 3] = wall_clock64();
   // ---- D. bits per thread, exclusive scan, choice between the Huffman and the stored form
   const int mybits = skip ? 0 : walk_span<1>(my, n, nullptr, clen, nullptr, nullptr);
   int incl = mybits;
@@ -333,6 +360,7 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
   const bool stored = skip || huff_bytes >= lead + 5 + len;
   for (int i = tid; i < SLOT / 4; i += 256) outw[i] = 0;
   __syncthreads();
+  if (P.dbg && tid == 0) P.dbg[chunk * 8 + 4] = wall_clock64();
   uint8_t* outb = reinterpret_cast<uint8_t*>(outw);
   int body_end;                                       // bytes before the alignment pads
   if (!stored) {
@@ -374,6 +402,7 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
   }
   __syncthreads();
 
+  if (P.dbg && tid == 0) P.dbg[chunk * 8 + 5] = wall_clock64();
   // ---- E. write the chunk to its slot; raw CRC of its bytes (each 16-byte unit shifted to the end of the chunk)
   for (int i = tid; i < 1024; i += 256) area[i] = P.tables[i];          // the code tables are dead: the area now holds the CRC tables
   __syncthreads();
@@ -398,6 +427,7 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
   if (lane == 0) wsum[wave] = crc;
   __syncthreads();
   if (tid == 0) P.crc[chunk] = wsum[0] ^ wsum[1] ^ wsum[2] ^ wsum[3];
+  if (P.dbg && tid == 0) P.dbg[chunk * 8 + 6] = wall_clock64();
 }
 
 struct GatherArgs { const uint8_t* slots; uint8_t* out; const int64_t* dst; const uint32_t* len16; int64_t chunk0; };
@@ -487,6 +517,9 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
   if (!res.p) return fail(IST_E_NOMEM, "out of pinned host memory for the PNG encoder");
   struct Events { std::vector<hipEvent_t> ev; ~Events() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); } } evs;
   evs.ev.assign(n_slabs, nullptr);
+  unsigned long long* d_dbg = nullptr;
+  static const bool phases = tuning_mode() && std::getenv("IST_PNG_PHASES") != nullptr;      // (IST_TUNING=1 processes only)
+  if (phases && hipMalloc(reinterpret_cast<void**>(&d_dbg), 64 * n) != hipSuccess) d_dbg = nullptr;
   auto compress = [&](size_t s) -> int {
     const size_t c0 = s * per_slab, cn = std::min(per_slab, n - c0);
     // the kernel writes its per-chunk results straight into the pinned host block (visible to the host behind the event).
@@ -502,6 +535,7 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
     A.tables = reinterpret_cast<const uint32_t*>(scratch + o_T); A.xpow16 = reinterpret_cast<const uint32_t*>(scratch + o_pow);
     A.rows_per_chunk = g.rows_per_chunk; A.pieces_per_row = g.pieces_per_row; A.piece_px = g.piece_px;
     A.chunk0 = static_cast<int64_t>(c0);
+    A.dbg = d_dbg;
     hipLaunchKernelGGL(ist_png_deflate_kernel, dim3(static_cast<unsigned>(cn)), dim3(256), 0, stream, A);
     PNG_HIP(hipGetLastError());
     PNG_HIP(hipEventCreateWithFlags(&evs.ev[s], hipEventDisableTiming));
@@ -620,6 +654,15 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
   }
   PNG_HIP(hipStreamSynchronize(aux));
   if (aux != stream) PNG_HIP(hipStreamSynchronize(stream));
+  if (d_dbg) {
+    std::vector<unsigned long long> hdbg(8 * n);
+    (void)hipMemcpy(hdbg.data(), d_dbg, 64 * n, hipMemcpyDeviceToHost);
+    (void)hipFree(d_dbg);
+    double sum[6] = {0, 0, 0, 0, 0, 0};
+    for (size_t j = 0; j < n; ++j) for (int k = 0; k < 6; ++k) sum[k] += static_cast<double>(hdbg[8 * j + k + 1] - hdbg[8 * j + k]);
+    static const char* names[6] = {"A load+filter", "B histogram+adler", "C code build", "D bit counts+scan", "body emit", "E slot write+crc"};
+    for (int k = 0; k < 6; ++k) std::fprintf(stderr, "[png phases] %-18s %8.2f us per chunk (100 MHz clock)\n", names[k], sum[k] / static_cast<double>(n) / 100.0);
+  }
 #undef PNG_HIP
 #undef patches
   if (host_out)                                        // signature, chunk headers, lengths, CRCs, trailer: ~30 bytes per slab
