@@ -35,6 +35,8 @@ WORKLOADS = [
     ("h_k1.87", [img(3024, 4032)] * 8 + [img(3840, 2160)], "horizontal", {"filter": "bilinear"}),
     ("v_k1.87", [img(4032, 3024)] * 8 + [img(2160, 1620)], "vertical", {"filter": "bilinear"}),
     ("exif6", [img(w, h, 6) for w, h in MIXED], "vertical", {"filter": "bilinear"}),
+    ("exif6_unit", [img(w, h, 6) for w, h in UNI], "vertical", {"filter": "bilinear"}),
+    ("exif8_unit_h", [img(w, h, 8) for w, h in UNI], "horizontal", {"filter": "bilinear"}),
     ("exif3", [img(w, h, 3) for w, h in MIXED], "vertical", {"filter": "bilinear"}),
 ]
 label = sys.argv[1] if len(sys.argv) > 1 else ""
