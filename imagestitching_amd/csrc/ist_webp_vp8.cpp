@@ -99,8 +99,10 @@ int get_coeffs(BoolDec& br, const Probs& probs, int ctx, int dq_dc, int dq_ac, i
 
 // ---- inverse transforms (section 14.3, 14.4) ------------------------------------------------------------------------
 inline int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
-inline int mul1(int a) { return ((a * 20091) >> 16) + a; }
-inline int mul2(int a) { return (a * 35468) >> 16; }
+// (64-bit products: a hostile file's coefficients reach 2^16 and more after the first pass, where the int product the format's
+// reference code uses overflows; valid streams never get there, so the results are unchanged)
+inline int mul1(int a) { return static_cast<int>((static_cast<int64_t>(a) * 20091) >> 16) + a; }
+inline int mul2(int a) { return static_cast<int>((static_cast<int64_t>(a) * 35468) >> 16); }
 
 void idct_add(const int16_t* in, uint8_t* dst, int stride) {
   int tmp[16];
