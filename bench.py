@@ -5,6 +5,11 @@ CPU oracle timed beside it.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+`--gpus N` with N > 1 ALWAYS runs N ranks, one per GPU: under torchrun the ranks exist already (WORLD_SIZE is set); invoked
+plainly, this process — before it imports torch or touches HIP — starts N rank processes of itself with RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and exits with the ranks' status (launch_ranks).  The line proves the
+rank count: extra.ranks_seen is an all-gather of every rank's device and PCI bus id.
+
 N = 1  : BASELINE.json configs[1] — 9 x 4032x3024 RGBA vertical stitch, bilinear, inputs resident in HBM, one fused
          launch per step (a "step" = one whole stitch).  Three buffer sets are rotated.
 N > 1  : BASELINE.json configs[3] — the same stitch with image i on GPU i mod N, bands gathered to GPU 0 over RCCL
@@ -420,12 +425,18 @@ def run_sharded(args):
     import imagestitching_amd as ist
     from imagestitching_amd import dist as D
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not os.environ.get("IST_BENCH_FORCE_SHARDED"):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus %d` (it launches its own ranks) or under "
+                         "torchrun with --nproc-per-node %d" % (args.gpus, world, args.gpus, args.gpus))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     local = int(os.environ.get("LOCAL_RANK", rank))
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d are visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ranks_seen = gather_ranks(dist, rank, local, torch)
     imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in UNIFORM]
     mp = 4032 * 27216 / 1e6
 
@@ -519,14 +530,265 @@ def run_sharded(args):
                          "kernel_us": round(t_rep * 1e6, 2), "algorithmic_bytes_per_launch": B_full,
                          "what": "per GPU, from the replicas leg (each rank launches the whole job); slowest rank"},
             "cpu_baseline": None,
-            "extra": {"regions": regions, "gather": gather,
+            "extra": {"ranks_seen": ranks_seen, "world_size": dist.get_world_size(), "regions": regions, "gather": gather,
                       "regions_note": "value = resident/image (the contract's region and BASELINE's split).  from_pinned_host and from_jpeg add each rank's own "
                                       "ingest (its PCIe link / its decoder) in front of the same step; /band deals equal output rows to every rank instead of whole images.  "
                                       "xGMI is point to point: a step is bounded below by busiest_link_bytes / one link's rate.",
                       "replicas_no_exchange": {"MPs": round(world * mp / t_rep, 1), "scaling": "weak", "note": "every GPU stitches its own whole 9x12 MP job"}},
         }
-        args.out.emit(json.dumps(line))
+    dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:
+        del job_full, full_src, full_out, st
+        torch.cuda.empty_cache()
+        if not os.environ.get("IST_BENCH_CHILD"):        # under torchrun rank 0 owns the line; under launch_ranks the parent finishes it
+            finish_line(line, args, world)
+        args.out.emit(json.dumps(line))
+
+
+# ---------------------------------------------------------------------------------------------------- rank launch + proof
+def gather_ranks(dist, rank, local, torch=None):
+    """what every rank really is: all-gathered, so rank 0's line shows N distinct processes on N distinct devices"""
+    import socket
+    me = {"rank": rank, "local_rank": local, "pid": os.getpid(), "host": socket.gethostname()}
+    if torch is not None and torch.cuda.is_available():
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        me.update(device=torch.cuda.current_device(), name=pr.name,
+                  pci="%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+                  uuid=str(getattr(pr, "uuid", "")))
+    seen = [None] * dist.get_world_size()
+    dist.all_gather_object(seen, me)
+    return seen
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def child_argv(args, extra=()):
+    a = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    for flag, on in (("--no-cpu", args.no_cpu), ("--quick", args.quick), ("--kernels-only", args.kernels_only), ("--dry-launch", args.dry_launch)):
+        if on:
+            a.append(flag)
+    return a + list(extra)
+
+
+def last_json_line(text):
+    for ln in reversed(text.splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` invoked plainly: THIS process has not imported torch and has not touched HIP; it starts N
+    fresh rank processes (never an exec of a process that initialised the GPU), waits for them, and prints rank 0's line.
+    A rank that fails takes the others down (they would wait for it in the collective for ever); exit status = the first
+    failure's."""
+    import subprocess
+    n = args.gpus
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), IST_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv(args), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + args.launch_timeout
+    status, why = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            status, why = bad[0][1], "rank %d exited with status %d" % bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            status, why = 124, "the ranks did not finish within --launch-timeout %d s" % args.launch_timeout
+            break
+        time.sleep(0.05)
+    if why:
+        for p in procs:                       # exactly the processes started above, by handle
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write("bench.py: %s\n" % why)
+        raise SystemExit(status if status > 0 else 1)
+    reader.join(10)
+    line = last_json_line(got[0].decode("utf-8", "replace") if got else "")
+    if line is None:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        raise SystemExit(1)
+    line.setdefault("extra", {})["launcher"] = "bench.py started %d rank processes itself (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*), one per GPU" % n
+    if not args.dry_launch:
+        finish_line(line, args, n)
+    args.out.emit(json.dumps(line))
+
+
+def finish_line(line, args, n):
+    """what the N > 1 line carries besides the ranks' own measurements: the CPU baseline (same leg as N = 1, run once the
+    ranks are done so that neither disturbs the other) and the SAME layout driven from ONE process through the C-ABI device
+    group (ist_group_*: what the N-API host binds) in a child process with its own time limit."""
+    import subprocess
+    if not args.no_cpu and not args.kernels_only:
+        try:
+            line["cpu_baseline"] = cpu_baseline()
+        except Exception as ex:
+            line["cpu_baseline"] = {"error": repr(ex)}
+    if args.kernels_only:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "IST_BENCH_CHILD", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--group-leg", str(n), "--steps", str(args.steps)], env=env,
+                           stdout=subprocess.PIPE, stderr=sys.stderr, timeout=args.group_timeout)
+        leg = last_json_line(r.stdout.decode("utf-8", "replace"))
+        line.setdefault("extra", {})["single_process_group"] = leg if leg is not None else {"error": "exit status %d, no JSON" % r.returncode}
+    except subprocess.TimeoutExpired:
+        line.setdefault("extra", {})["single_process_group"] = {"error": "timed out after %d s" % args.group_timeout}
+    except Exception as ex:
+        line.setdefault("extra", {})["single_process_group"] = {"error": repr(ex)}
+
+
+# ---------------------------------------------------------------------------------------------------- C-ABI device group leg
+def group_leg(n, steps, out):
+    """ONE process drives GPUs 0..n-1 through the C-ABI device group (ist_group_*; the N-API host's `devices` option).
+    Regions, per split:  resident (device pointers per part, canvas on the root, RCCL gather) and host_in_host_out
+    (ist_stitch_rgba8_multi: every device uploads only its rows over its own PCIe link and DMAs its finished band straight
+    into the pinned result - no gather, no root readback)."""
+    import numpy as np
+    import torch
+    import imagestitching_amd as ist
+    have = torch.cuda.device_count()
+    if have < n:
+        out.emit(json.dumps({"error": "%d devices asked for, %d visible" % (n, have)}))
+        return
+    devices = list(range(n))
+    mp = 4032 * 27216 / 1e6
+    imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in UNIFORM]
+    res = {"devices": devices, "regions": {}}
+    g = ist.StitchGroup(devices)
+    reps = max(5, min(50, steps // 4))
+    for split in ("image", "band"):
+        job = g.compile(imgs, "vertical", {"filter": "bilinear", "split": split})
+        srcs = []
+        for p in job.parts:
+            a, b = p["rows"]
+            w = UNIFORM[p["image"]][0]
+            t = torch.empty((b - a + 1, w, 4), dtype=torch.uint8, device="cuda:%d" % p["device"])[:b - a]
+            t.random_(0, 256)
+            srcs.append((t, a))
+        canvas = torch.empty((job.plan.canvas_h, job.plan.canvas_w, 4), dtype=torch.uint8, device="cuda:%d" % devices[0])
+        for _ in range(20):
+            job.launch(srcs, canvas)
+        g.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            job.launch(srcs, canvas)
+        g.sync()
+        dt = (time.perf_counter() - t0) / reps
+        res["regions"]["resident/" + split] = {"ms_per_step": round(dt * 1e3, 4), "MPs": round(mp / dt, 1), "parts": len(job.parts)}
+        job.close()
+        del srcs, canvas
+    g.close()
+    px = [synth_np(k, w, h) for k, (w, h) in enumerate(UNIFORM)]
+    himgs = [{"width": w, "height": h, "data": a, "opaque": True} for a, (w, h) in zip(px, UNIFORM)]
+    for split in ("image", "band"):
+        opts = {"filter": "bilinear", "devices": devices, "split": split}
+        r = ist.stitch(himgs, "vertical", opts)                 # warm-up: contexts, staging rings, result pool, cached group job
+        if split == "image":
+            res["checked"] = bool(np.array_equal(r["data"][:3024], px[0]) and np.array_equal(r["data"][-3024:], px[8]))
+        del r
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            r = ist.stitch(himgs, "vertical", opts)
+            ts.append(time.perf_counter() - t0)
+            del r
+        t = sorted(ts)[len(ts) // 2]
+        res["regions"]["host_in_host_out/" + split] = {"ms_per_stitch": round(t * 1e3, 3), "MPs": round(mp / t, 1),
+                                                       "pcie_payload_GBs": round(2 * 438.939648e6 / t / 1e9, 2)}
+    res["what"] = ("one process, ist_group_* over devices %s: resident = per-part device pointers, bands + one grouped RCCL batch into the root's canvas; "
+                   "host_in_host_out = pageable numpy in, every device uploads only its rows and DMAs its finished band into the pinned result" % devices)
+    out.emit(json.dumps(res))
+
+
+# ---------------------------------------------------------------------------------------------------- --dry-launch (CPU)
+class StubBackend:
+    """--dry-launch only: the sharding + exchange of dist.run_step on CPU tensors with gloo; a band's 'render' writes the id
+    of its image, so that the assembled strip can be checked without any raster (the oracle is not involved)."""
+
+    def __init__(self, sh, torch):
+        self.sh, self.torch = sh, torch
+        self.staging = {p.index: torch.empty(p.shape, dtype=torch.uint8) for p in sh.remote if not p.in_place}
+
+    def new_canvas(self):
+        return self.torch.full((self.sh.plan.canvas_h, self.sh.plan.canvas_w, 4), 0xFF, dtype=self.torch.uint8)
+
+    def render_band(self, part, srcs):
+        return self.torch.full(part.shape, part.image + 1, dtype=self.torch.uint8)
+
+    def render_root(self, srcs, canvas):
+        for p in self.sh.parts:
+            if p.slot == 0:
+                canvas[p.Y0:p.Y1, p.X0:p.X1] = p.image + 1
+
+    def place(self, part, canvas):
+        canvas[part.Y0:part.Y1, part.X0:part.X1] = self.staging[part.index]
+
+
+def run_dry(args):
+    """N ranks, gloo, no GPU: proves the launch path (who starts the ranks, what the line says) on a CPU-only box"""
+    import torch
+    import torch.distributed as dist
+    from imagestitching_amd import dist as D
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = gather_ranks(dist, rank, int(os.environ.get("LOCAL_RANK", rank)))
+    sizes = [(64, 48)] * 9
+    imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in sizes]
+    ok, t0 = True, time.perf_counter()
+    for split in ("image", "band"):
+        sh = D.ShardedStitch(imgs, "vertical", {"filter": "bilinear"}, rank, world, 0, split=split)
+        be = StubBackend(sh, torch)
+        canvas = be.new_canvas() if rank == 0 else None
+        for _ in range(args.warmup + args.steps):
+            D.run_step(sh, be, [None] * len(sizes), canvas, dist)
+        dist.barrier()
+        if rank == 0:
+            ok = ok and all(bool((canvas[p.Y0:p.Y1, p.X0:p.X1] == p.image + 1).all()) for p in sh.parts)
+    dt = time.perf_counter() - t0
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        args.out.emit(json.dumps({"metric": "dry launch (no GPU, gloo, stub render)", "value": 0.0, "unit": "MP/s", "n_gpus": world, "steps": args.steps,
+                                  "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / max(1, 2 * (args.steps + args.warmup)), 4), "dry_launch": True,
+                                  "extra": {"ranks_seen": seen, "world_size": world, "strip_assembled": ok}}))
+        if not ok:
+            raise SystemExit(3)
 
 
 def main():
@@ -538,12 +800,25 @@ def main():
     ap.add_argument("--quick", action="store_true", help="headline config only")
     ap.add_argument("--kernels-only", action="store_true", help="only the resident-input kernel configurations (what the rocprofv3 passes run)")
     ap.add_argument("--print-kernel-sha", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true", help="N ranks on CPU (gloo, stub render): exercises the rank launch and the line, no GPU")
+    ap.add_argument("--launch-timeout", type=int, default=900, help="seconds the self-started ranks may take")
+    ap.add_argument("--group-timeout", type=int, default=240, help="seconds the single-process device-group leg may take")
+    ap.add_argument("--group-leg", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.print_kernel_sha:
         print(kernel_source_sha())
         return
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
     args.out = StdoutGuard()
-    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("IST_BENCH_FORCE_SHARDED"):
+    have_ranks = "WORLD_SIZE" in os.environ
+    if args.group_leg:
+        group_leg(args.group_leg, args.steps, args.out)
+    elif args.gpus > 1 and not have_ranks:
+        launch_ranks(args)                 # nothing above has imported torch or touched HIP
+    elif args.dry_launch:
+        run_dry(args)
+    elif args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("IST_BENCH_FORCE_SHARDED"):
         run_sharded(args)
     else:
         run_single(args)
