@@ -74,6 +74,7 @@ SYMBOLS = [
     ("ist_abi_version", C.c_int, []),
     ("ist_last_error", C.c_char_p, []),
     ("ist_device_count", C.c_int, []),
+    ("ist_debug_device_allocs", C.c_int64, []),
     ("ist_limits_default", None, [C.c_int, C.POINTER(Limits)]),
     ("ist_limits_unlimited", None, [C.POINTER(Limits)]),
     ("ist_plan_compute", C.c_int, [C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Limits), C.POINTER(Plan)]),
@@ -84,6 +85,7 @@ SYMBOLS = [
                                   C.POINTER(Part), C.c_int, C.POINTER(C.c_int)]),
     ("ist_ctx_create", C.c_void_p, [C.c_int]),
     ("ist_ctx_destroy", None, [C.c_void_p]),
+    ("ist_ctx_sync", C.c_int, [C.c_void_p]),
     ("ist_ctx_set_png_level", C.c_int, [C.c_void_p, C.c_int]),
     ("ist_job_create", C.c_void_p, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(Op), C.c_int,
                                     C.POINTER(ImageDesc), C.c_int, C.c_int, C.POINTER(Region)]),

@@ -22,6 +22,7 @@ struct ist_ctx {
   void* scratch_huff = nullptr; size_t scratch_huff_bytes = 0; // GPU Huffman decoder: scans, tables, per-subsequence state
   void* scratch_png = nullptr; size_t scratch_png_bytes = 0;   // compressing PNG encoder: one slot per 16 KiB chunk + its tables
   void* scratch_file = nullptr; size_t scratch_file_bytes = 0; // device image of a PNG file on its way to the host
+  void* scratch_arena = nullptr; size_t scratch_arena_bytes = 0; // file pipeline: bitmaps + JPEG planes + canvas + PNG of one call
   hipStream_t aux = nullptr;             // second stream of the host-path entry points (PNG slabs travel on it while later ones compress)
   // device blocks of destroyed jobs' tables, re-used by the next job of this context instead of a hipMalloc + hipFree pair
   // per job (a free also synchronises the device); at most kTablePool blocks are kept
@@ -41,7 +42,14 @@ struct ist_job {
   ist::Compiled host;
   uint8_t* d_tables = nullptr;           // ONE device allocation holding the five tables below
   size_t d_tables_bytes = 0;
-  bool launched = false;                 // ist_job_destroy waits for the device before it hands the tables to the next job
+  // the streams the job was launched on since it was created (ist_job_destroy waits for THOSE before it hands the tables to
+  // the next job - not for the whole device: other streams of a shared device keep running); more than kStreams distinct
+  // ones fall back to a device-wide wait
+  static constexpr int kStreams = 4;
+  hipStream_t launched_on[kStreams] = {nullptr, nullptr, nullptr, nullptr};
+  int n_launched_on = 0;
+  bool launched = false, launched_many = false;
+  std::mutex launch_mu;
   ist::DevOp* d_ops = nullptr;
   ist::DevCell* d_cells = nullptr;
   ist::DevBand* d_bands = nullptr;
@@ -64,6 +72,7 @@ struct DeviceGuard {
 
 // grow-only device scratch
 int grow_device(void** p, size_t* have, size_t need);
+
 
 }  // namespace ist
 

@@ -119,16 +119,19 @@ inline uint8_t* dev_of(const RowsCopy& it, const Piece& p) { return static_cast<
 
 }  // namespace
 
+void Stager::release_lane(Lane& l) {
+  if (l.stream) (void)hipStreamSynchronize(l.stream);
+  for (int s = 0; s < 2; ++s) { if (l.done[s]) (void)hipEventDestroy(l.done[s]); if (l.chunk[s]) (void)hipHostFree(l.chunk[s]); l.done[s] = nullptr; l.chunk[s] = nullptr; }
+  if (l.tail) (void)hipEventDestroy(l.tail);
+  if (l.stream) (void)hipStreamDestroy(l.stream);
+  l.tail = nullptr; l.stream = nullptr;
+}
+
 Stager::~Stager() {
   int prev = -1;
   (void)hipGetDevice(&prev);
   if (hipSetDevice(device_) != hipSuccess) return;
-  for (Lane& l : lanes_) {
-    if (l.stream) (void)hipStreamSynchronize(l.stream);
-    for (int s = 0; s < 2; ++s) { if (l.done[s]) (void)hipEventDestroy(l.done[s]); if (l.chunk[s]) (void)hipHostFree(l.chunk[s]); }
-    if (l.tail) (void)hipEventDestroy(l.tail);
-    if (l.stream) (void)hipStreamDestroy(l.stream);
-  }
+  for (Lane& l : lanes_) release_lane(l);
   if (gate_) (void)hipEventDestroy(gate_);
   if (prev >= 0) (void)hipSetDevice(prev);
 }
@@ -136,7 +139,8 @@ Stager::~Stager() {
 int Stager::ensure() {
   if (!lanes_.empty()) return IST_OK;
   std::vector<Lane> lanes(kLanes);
-  bool ok = hipEventCreateWithFlags(&gate_, hipEventDisableTiming) == hipSuccess;
+  hipEvent_t gate = nullptr;
+  bool ok = hipEventCreateWithFlags(&gate, hipEventDisableTiming) == hipSuccess;
   for (Lane& l : lanes) {
     ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
          hipEventCreateWithFlags(&l.tail, hipEventDisableTiming) == hipSuccess;
@@ -145,9 +149,21 @@ int Stager::ensure() {
            hipEventCreateWithFlags(&l.done[s], hipEventDisableTiming) == hipSuccess &&
            hipEventRecord(l.done[s], l.stream) == hipSuccess;           // recorded once: synchronising it is always legal
   }
-  lanes_.swap(lanes);           // (a partially built set is released by the destructor)
-  if (!ok) { (void)hipGetLastError(); return fail(IST_E_HIP, "allocating the pinned staging ring failed"); }
+  if (!ok) {                    // nothing half-built is published: the next call starts over
+    (void)hipGetLastError();
+    for (Lane& l : lanes) release_lane(l);
+    if (gate) (void)hipEventDestroy(gate);
+    return fail(IST_E_HIP, "allocating the pinned staging ring failed");
+  }
+  lanes_.swap(lanes);
+  gate_ = gate;
   return IST_OK;
+}
+
+int Stager::sync() {
+  bool ok = true;
+  for (Lane& l : lanes_) if (l.stream) ok = (hipStreamSynchronize(l.stream) == hipSuccess) && ok;
+  return ok ? IST_OK : fail(IST_E_HIP, "hipStreamSynchronize failed");
 }
 
 int Stager::upload(const std::vector<RowsCopy>& items, hipStream_t after) { return run(items, true, after); }

@@ -3,7 +3,7 @@
 // Reference anchor: the mini-program hands the platform a decoded bitmap per image (utils/canvas.js:27-121) and gets
 // the finished strip back from the export (utils/canvas.js:205-242); on a discrete GPU both cross PCIe.
 //
-// Rules of this layer (DESIGN.md section 9, the round-1 abort):
+// Rules of this layer (DESIGN.md section 4c, the round-1 abort):
 //   * the library NEVER page-locks memory it does not own (no hipHostRegister of caller buffers) and never issues a
 //     2-D (pitched) runtime copy: every DMA is a linear copy between device memory and pinned memory the library
 //     allocated itself (hipHostMalloc);
@@ -47,10 +47,12 @@ class Stager {
   // Downloads every item; `before` is a stream whose already-submitted work produces the data.  Returns when the
   // caller's buffers are complete.
   int download(const std::vector<RowsCopy>& items, hipStream_t before);
+  int sync();                             // waits for every lane's stream
 
  private:
   struct Lane { hipStream_t stream = nullptr; void* chunk[2] = {nullptr, nullptr}; hipEvent_t done[2] = {nullptr, nullptr}; hipEvent_t tail = nullptr; };
   int ensure();
+  static void release_lane(Lane& l);
   int run(const std::vector<RowsCopy>& items, bool up, hipStream_t other);
   int device_;
   std::vector<Lane> lanes_;

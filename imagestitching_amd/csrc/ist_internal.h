@@ -99,6 +99,11 @@ struct Compiled {
   ist_job_info info{};
 };
 
+// every device allocation of the library goes through these two (counted: ist_debug_device_allocs).  dev_malloc returns
+// the hipError_t as an int (0 = hipSuccess) so that this header needs nothing of HIP.
+int dev_malloc(void** p, size_t bytes);
+void dev_free(void* p);
+
 // true when the process was started with IST_TUNING=1 (decided once): only then are tuning knobs read from the environment
 bool tuning_mode();
 

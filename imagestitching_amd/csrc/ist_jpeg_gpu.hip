@@ -520,16 +520,16 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   // the caller's grow-only scratch (a context keeps it across calls: no allocation, and no implicit device synchronisation
   // of a free, per call), or a one-off allocation
   uint8_t* d = nullptr;
-  struct Free { void* p; ~Free() { if (p) (void)hipFree(p); } } fr{nullptr};
+  struct Free { void* p; ~Free() { dev_free(p); } } fr{nullptr};
   if (scratch && scratch_bytes) {
     if (*scratch_bytes < off) {
-      if (*scratch) { (void)hipFree(*scratch); *scratch = nullptr; *scratch_bytes = 0; }
-      JG_HIP(hipMalloc(scratch, off + off / 4));
+      if (*scratch) { dev_free(*scratch); *scratch = nullptr; *scratch_bytes = 0; }
+      if (dev_malloc(scratch, off + off / 4) != 0) { (void)hipGetLastError(); return fail(IST_E_NOMEM, "out of device memory for the Huffman decoder"); }
       *scratch_bytes = off + off / 4;
     }
     d = static_cast<uint8_t*>(*scratch);
   } else {
-    JG_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
+    if (dev_malloc(reinterpret_cast<void**>(&d), off) != 0) { (void)hipGetLastError(); return fail(IST_E_NOMEM, "out of device memory for the Huffman decoder"); }
     fr.p = d;
   }
   std::vector<uint16_t> half_img(static_cast<size_t>(n_half));           // image of every group of 128 subsequences

@@ -16,6 +16,17 @@
 //   * one ncclGroupStart/ncclGroupEnd holds every send and receive of the step (RCCL has no gatherv).  xGMI is point to
 //     point: each sender has its own link to the root, so there is no ring and no tree to build.
 // RCCL is dlopen'ed on first use (librccl.so.1): hosts that stay on one GPU never load it.
+//
+// HOST SINK (ist_group_stitch_rgba8 on a strip of full-width bands): the export of the reference is host-destined
+// (index.js:1577-1581, utils/canvas.js:205-242), so nothing has to meet on one GPU: every device uploads only the rows its
+// parts sample over its own PCIe link, renders them into compact bands and DMAs each finished band STRAIGHT into its byte
+// range of the pooled pinned result (a full-width band is contiguous there) - no xGMI gather and no 439 MB readback over
+// the root's single link.  The root's launch supplies everything that is not a band (background rows, gaps).  Strips whose
+// bands are not full-width (horizontal, centred) keep the gather + root readback.
+//
+// Nothing is allocated per call after the first: band / staging buffers are grow-only arenas of the group (jobs hold
+// offsets; streams are in order, so jobs may share them), and the one-call host path keeps its compiled group jobs in a
+// small LRU keyed by (canvas, ops, images, filter, split).
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 
@@ -25,7 +36,9 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
+#include <utility>
 
 #include "ist_ctx.h"
 #include "ist_internal.h"
@@ -88,6 +101,13 @@ struct ist_group {
   std::vector<ncclComm_t> comm;           // one communicator handle per distinct device; empty while the group is one device
   bool self_send = false;                 // test knob (IST_TUNING=1 IST_GROUP_SELF_SEND=1): same-device bands also travel through RCCL
   std::mutex mu;
+  // grow-only arenas (jobs hold offsets into them): compact bands per device, staging bands on the root
+  std::vector<void*> band_arena; std::vector<size_t> band_bytes;
+  void* staging = nullptr; size_t staging_bytes = 0;
+  // compiled jobs of the one-call host path, most recently used last
+  struct Cached { std::string key; ist_group_job* job; };
+  std::vector<Cached> cache;
+  static constexpr size_t kCacheJobs = 4;
 };
 
 struct ist_group_job {
@@ -97,14 +117,18 @@ struct ist_group_job {
   struct PartRt {
     ist_part part;
     int rank = 0;                         // device index of the owner
-    bool local = false;                   // rendered on the root's device straight into the canvas
+    bool local = false;                   // device sink: rendered on the root's device straight into the canvas
     ist_job* band_job = nullptr;          // slot != 0
-    void* band = nullptr;                 // compact band on the owner's device (remote parts)
+    size_t band_off = 0;                  // compact band in the owner's arena (slot != 0)
     ist_job* place_job = nullptr;         // root: staged band -> canvas
-    void* staging = nullptr;              // root device
+    size_t staging_off = 0;               // root arena (remote parts that are not full-width)
   };
   std::vector<PartRt> parts;
   ist_job* root_job = nullptr;
+  std::vector<size_t> band_need;          // per device: bytes of band arena this job addresses
+  size_t staging_need = 0;
+  bool host_sink_ok = false;              // every band is full-width: bands can be DMA'ed straight into a host canvas
+  std::vector<std::pair<int64_t, int64_t>> root_rows;   // host sink: canvas row ranges the root's launch delivers
 };
 
 namespace {
@@ -114,14 +138,44 @@ void group_job_free(ist_group_job* j) {
   for (auto& p : j->parts) {
     if (p.band_job) ist_job_destroy(p.band_job);
     if (p.place_job) ist_job_destroy(p.place_job);
-    if (p.band) { DeviceGuard g(j->g->devs[static_cast<size_t>(p.rank)]); (void)hipFree(p.band); }
-    if (p.staging) { DeviceGuard g(j->g->devs[0]); (void)hipFree(p.staging); }
   }
   if (j->root_job) ist_job_destroy(j->root_job);
   delete j;
 }
 
 inline size_t part_bytes(const ist_part& p) { return static_cast<size_t>(p.X1 - p.X0) * 4 * static_cast<size_t>(p.Y1 - p.Y0); }
+inline size_t round256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+int group_sync_locked(ist_group* g) {
+  for (size_t r = 0; r < g->devs.size(); ++r) {
+    DeviceGuard dg(g->devs[r]);
+    if (hipStreamSynchronize(g->ctx[r]->stream) != hipSuccess) return fail(IST_E_HIP, "hipStreamSynchronize failed");
+  }
+  DeviceGuard dg(g->devs[0]);
+  if (hipStreamSynchronize(g->recv_stream) != hipSuccess) return fail(IST_E_HIP, "hipStreamSynchronize failed");
+  return IST_OK;
+}
+
+// the arenas cover what `job` addresses; growing one waits for the group's streams first (earlier launches may still use it)
+int ensure_arenas(ist_group* g, const ist_group_job* job) {
+  bool grow = job->staging_need > g->staging_bytes;
+  for (size_t r = 0; r < g->devs.size(); ++r) grow = grow || job->band_need[r] > g->band_bytes[r];
+  if (!grow) return IST_OK;
+  int rc = group_sync_locked(g);
+  if (rc) return rc;
+  for (size_t r = 0; r < g->devs.size(); ++r) {
+    if (job->band_need[r] <= g->band_bytes[r]) continue;
+    DeviceGuard dg(g->devs[r]);
+    rc = grow_device(&g->band_arena[r], &g->band_bytes[r], job->band_need[r]);
+    if (rc) return fail(IST_E_NOMEM, "out of device memory for the bands of device " + std::to_string(g->devs[r]));
+  }
+  if (job->staging_need > g->staging_bytes) {
+    DeviceGuard dg(g->devs[0]);
+    rc = grow_device(&g->staging, &g->staging_bytes, job->staging_need);
+    if (rc) return fail(IST_E_NOMEM, "out of device memory for the staging bands");
+  }
+  return IST_OK;
+}
 
 }  // namespace
 
@@ -146,6 +200,8 @@ ist_group* ist_group_create(const int* devices, int ndev) {
     if (!c) return nullptr;
     g->ctx.push_back(c);
   }
+  g->band_arena.assign(g->devs.size(), nullptr);
+  g->band_bytes.assign(g->devs.size(), 0);
   {
     DeviceGuard dg(g->devs[0]);
     if (hipStreamCreateWithFlags(&g->recv_stream, hipStreamNonBlocking) != hipSuccess) { fail(IST_E_HIP, "hipStreamCreate failed"); return nullptr; }
@@ -164,8 +220,13 @@ ist_group* ist_group_create(const int* devices, int ndev) {
 
 void ist_group_destroy(ist_group* g) {
   if (!g) return;
+  (void)group_sync_locked(g);
+  for (auto& c : g->cache) group_job_free(c.job);
+  g->cache.clear();
   for (ncclComm_t c : g->comm) if (c) (void)rccl()->CommDestroy(c);
-  if (g->recv_stream) { DeviceGuard dg(g->devs[0]); (void)hipStreamSynchronize(g->recv_stream); (void)hipStreamDestroy(g->recv_stream); }
+  for (size_t r = 0; r < g->devs.size(); ++r) if (g->band_arena[r]) { DeviceGuard dg(g->devs[r]); dev_free(g->band_arena[r]); }
+  if (g->staging) { DeviceGuard dg(g->devs[0]); dev_free(g->staging); }
+  if (g->recv_stream) { DeviceGuard dg(g->devs[0]); (void)hipStreamDestroy(g->recv_stream); }
   for (ist_ctx* c : g->ctx) ist_ctx_destroy(c);
   delete g;
 }
@@ -187,33 +248,51 @@ ist_group_job* ist_group_job_create(ist_group* g, int64_t canvas_w, int64_t canv
     return nullptr;
   std::unique_ptr<ist_group_job, void (*)(ist_group_job*)> job(new ist_group_job, group_job_free);
   job->g = g; job->cw = canvas_w; job->ch = canvas_h; job->n_images = n_images;
+  job->band_need.assign(g->devs.size(), 0);
   static const uint8_t transparent[4] = {0, 0, 0, 0};
   const uint8_t* clear = clear_rgba ? clear_rgba : transparent;
   // the root's own launch: every op that is not a sharded draw (fills), the draws slot 0 owns a part of, and - listed
   // last, so that nothing lies on top of them - a HOLE over every part someone else writes
   std::vector<ist_op> root_ops;
-  std::vector<char> root_draw(static_cast<size_t>(n_ops), 0), sharded(static_cast<size_t>(n_ops), 0);
-  for (int k = 0; k < n_parts; ++k) { sharded[static_cast<size_t>(cut[k].op)] = 1; if (cut[k].slot == 0) root_draw[static_cast<size_t>(cut[k].op)] = 1; }
+  std::vector<char> root_draw(static_cast<size_t>(n_ops), 0);
+  for (int k = 0; k < n_parts; ++k) if (cut[k].slot == 0) root_draw[static_cast<size_t>(cut[k].op)] = 1;
   for (int k = 0; k < n_ops; ++k)
     if (ops[k].kind != IST_OP_DRAW || root_draw[static_cast<size_t>(k)]) root_ops.push_back(ops[k]);
-  (void)sharded;                               // (a draw that shards into nothing draws nothing: dropping it changes no pixel)
+  // (a draw that shards into nothing draws nothing: dropping it changes no pixel)
+  job->host_sink_ok = true;
   for (int k = 0; k < n_parts; ++k) {
     const ist_part& p = cut[k];
     ist_group_job::PartRt rt;
     rt.part = p;
     rt.rank = g->slot_rank[static_cast<size_t>(p.slot)];
     rt.local = rt.rank == 0 && !g->self_send;
+    if (p.slot != 0) {
+      if (!p.in_place) job->host_sink_ok = false;
+      rt.band_off = job->band_need[static_cast<size_t>(rt.rank)];
+      job->band_need[static_cast<size_t>(rt.rank)] += round256(part_bytes(p));
+      ist_op hole;
+      std::memset(&hole, 0, sizeof hole);
+      hole.kind = IST_OP_HOLE; hole.image = -1;
+      hole.m[0] = 1.0; hole.m[3] = 1.0;
+      hole.d[0] = p.X0; hole.d[1] = p.Y0; hole.d[2] = p.X1 - p.X0; hole.d[3] = p.Y1 - p.Y0;
+      root_ops.push_back(hole);
+    }
     job->parts.push_back(rt);
-    if (p.slot == 0) continue;
-    ist_op hole;
-    std::memset(&hole, 0, sizeof hole);
-    hole.kind = IST_OP_HOLE; hole.image = -1;
-    hole.m[0] = 1.0; hole.m[3] = 1.0;
-    hole.d[0] = p.X0; hole.d[1] = p.Y0; hole.d[2] = p.X1 - p.X0; hole.d[3] = p.Y1 - p.Y0;
-    root_ops.push_back(hole);
   }
   job->root_job = ist_job_create(g->ctx[0], canvas_w, canvas_h, clear, root_ops.data(), static_cast<int>(root_ops.size()), images, n_images, filter, nullptr);
   if (!job->root_job) return nullptr;
+  // host sink: the canvas rows that no band delivers come from the root's launch (the complement of the bands' rows)
+  if (job->host_sink_ok) {
+    std::vector<std::pair<int64_t, int64_t>> holes;
+    for (const auto& rt : job->parts) if (rt.part.slot != 0) holes.emplace_back(rt.part.Y0, rt.part.Y1);
+    std::sort(holes.begin(), holes.end());
+    int64_t y = 0;
+    for (const auto& h : holes) {
+      if (h.first > y) job->root_rows.emplace_back(y, h.first);
+      y = std::max(y, h.second);
+    }
+    if (y < canvas_h) job->root_rows.emplace_back(y, canvas_h);
+  }
   // the first fill of the list paints the background of every band (index.js:1423-1424)
   int fill_at = -1;
   for (int k = 0; k < n_ops && fill_at < 0; ++k) if (ops[k].kind == IST_OP_FILL) fill_at = k;
@@ -226,15 +305,10 @@ ist_group_job* ist_group_job_create(ist_group* g, int64_t canvas_w, int64_t canv
     const ist_region clip{p.X0, p.Y0, p.X1 - p.X0, p.Y1 - p.Y0};
     rt.band_job = ist_job_create(g->ctx[static_cast<size_t>(rt.rank)], canvas_w, canvas_h, clear, two, n2, images, n_images, filter, &clip);
     if (!rt.band_job) return nullptr;
-    if (rt.local) continue;
-    {
-      DeviceGuard dg(g->devs[static_cast<size_t>(rt.rank)]);
-      if (hipMalloc(&rt.band, part_bytes(p)) != hipSuccess) { (void)hipGetLastError(); fail(IST_E_NOMEM, "out of device memory for a band"); return nullptr; }
-    }
-    if (p.in_place) continue;
+    if (rt.local || p.in_place) continue;
     // staged: received into a compact band on the root, then placed by a 1:1 draw clipped to the box
-    DeviceGuard dg(g->devs[0]);
-    if (hipMalloc(&rt.staging, part_bytes(p)) != hipSuccess) { (void)hipGetLastError(); fail(IST_E_NOMEM, "out of device memory for a staging band"); return nullptr; }
+    rt.staging_off = job->staging_need;
+    job->staging_need += round256(part_bytes(p));
     ist_op put;
     std::memset(&put, 0, sizeof put);
     put.kind = IST_OP_DRAW; put.image = 0;
@@ -261,42 +335,30 @@ int ist_group_job_parts(const ist_group_job* job, ist_part* parts, int max_parts
   return IST_OK;
 }
 
-// src[k] / src_pitch[k] belong to PART k: the device address (on the part's device) of ROW 0 of the part's image.  A slot
-// that holds only rows [sy0, sy1) passes the address of row sy0 minus sy0 * pitch.  dst: the canvas on the root's device,
-// rows contiguous.  Asynchronous; ist_group_sync waits for the canvas.
-int ist_group_job_launch(ist_group_job* job, const void* const* src, const size_t* src_pitch, int n_parts, void* dst, size_t dst_pitch) {
-  if (!job || !src || !dst) return fail(IST_E_INVALID, "ist_group_job_launch: NULL argument");
-  if (n_parts != static_cast<int>(job->parts.size())) return fail(IST_E_INVALID, "ist_group_job_launch: one source pointer per part is expected");
-  if (dst_pitch != static_cast<size_t>(job->cw) * 4) return fail(IST_E_INVALID, "ist_group_job_launch: the canvas rows must be contiguous (dst_pitch == canvas_w * 4)");
-  ist_group* g = job->g;
-  std::lock_guard<std::mutex> lock(g->mu);
+}  // extern "C"
+
+namespace {
+
+// one band of a non-root slot into `to` (a compact band, or - biased by the caller - the canvas itself), on its owner's stream
+int launch_band(ist_group_job* job, size_t k, const void* const* src, const size_t* src_pitch, void* to, size_t to_pitch, bool compact) {
+  auto& rt = job->parts[k];
+  const ist_part& p = rt.part;
+  if (!src[k]) return fail(IST_E_DECODE, "图片" + std::to_string(p.image) + "解码异常");
   const size_t ni = static_cast<size_t>(job->n_images);
   std::vector<const void*> one(ni, nullptr);
   std::vector<size_t> one_pitch(ni, 0);
-  bool any_remote = false;
-  // 1. every band on its owner's stream
-  for (size_t k = 0; k < job->parts.size(); ++k) {
-    auto& rt = job->parts[k];
-    const ist_part& p = rt.part;
-    if (p.slot == 0) continue;
-    if (!src[k]) return fail(IST_E_DECODE, "图片" + std::to_string(p.image) + "解码异常");
-    std::fill(one.begin(), one.end(), nullptr);
-    one[static_cast<size_t>(p.image)] = src[k];
-    one_pitch[static_cast<size_t>(p.image)] = src_pitch ? src_pitch[k] : 0;
-    int rc;
-    if (rt.local) {
-      rc = ist_job_launch(rt.band_job, one.data(), src_pitch ? one_pitch.data() : nullptr, job->n_images, dst, dst_pitch, g->ctx[0]->stream);
-    } else {
-      const size_t bp = static_cast<size_t>(p.X1 - p.X0) * 4;
-      const uintptr_t biased = reinterpret_cast<uintptr_t>(rt.band) - (static_cast<uintptr_t>(p.Y0) * bp + static_cast<uintptr_t>(p.X0) * 4);
-      rc = ist_job_launch(rt.band_job, one.data(), src_pitch ? one_pitch.data() : nullptr, job->n_images, reinterpret_cast<void*>(biased), bp,
-                          g->ctx[static_cast<size_t>(rt.rank)]->stream);
-      any_remote = true;
-    }
-    if (rc) return rc;
-  }
-  // 2. the root's own launch: slot 0's pointers, by image
-  std::fill(one.begin(), one.end(), nullptr);
+  one[static_cast<size_t>(p.image)] = src[k];
+  one_pitch[static_cast<size_t>(p.image)] = src_pitch ? src_pitch[k] : 0;
+  void* dst = to;
+  if (compact) dst = reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(to) - (static_cast<uintptr_t>(p.Y0) * to_pitch + static_cast<uintptr_t>(p.X0) * 4));
+  return ist_job_launch(rt.band_job, one.data(), src_pitch ? one_pitch.data() : nullptr, job->n_images, dst, to_pitch,
+                        job->g->ctx[static_cast<size_t>(rt.rank)]->stream);
+}
+
+int launch_root(ist_group_job* job, const void* const* src, const size_t* src_pitch, void* dst, size_t dst_pitch) {
+  const size_t ni = static_cast<size_t>(job->n_images);
+  std::vector<const void*> one(ni, nullptr);
+  std::vector<size_t> one_pitch(ni, 0);
   for (size_t k = 0; k < job->parts.size(); ++k) {
     const ist_part& p = job->parts[k].part;
     if (p.slot != 0) continue;
@@ -304,7 +366,29 @@ int ist_group_job_launch(ist_group_job* job, const void* const* src, const size_
     one[static_cast<size_t>(p.image)] = src[k];
     one_pitch[static_cast<size_t>(p.image)] = src_pitch ? src_pitch[k] : 0;
   }
-  int rc = ist_job_launch(job->root_job, one.data(), src_pitch ? one_pitch.data() : nullptr, job->n_images, dst, dst_pitch, g->ctx[0]->stream);
+  return ist_job_launch(job->root_job, one.data(), src_pitch ? one_pitch.data() : nullptr, job->n_images, dst, dst_pitch, job->g->ctx[0]->stream);
+}
+
+// device sink: bands + the root's launch + ONE grouped RCCL batch into the root's canvas.  Caller holds g->mu.
+int group_launch_locked(ist_group_job* job, const void* const* src, const size_t* src_pitch, void* dst, size_t dst_pitch) {
+  ist_group* g = job->g;
+  int rc = ensure_arenas(g, job);
+  if (rc) return rc;
+  bool any_remote = false;
+  // 1. every band on its owner's stream
+  for (size_t k = 0; k < job->parts.size(); ++k) {
+    auto& rt = job->parts[k];
+    if (rt.part.slot == 0) continue;
+    if (rt.local) rc = launch_band(job, k, src, src_pitch, dst, dst_pitch, false);
+    else {
+      rc = launch_band(job, k, src, src_pitch, static_cast<uint8_t*>(g->band_arena[static_cast<size_t>(rt.rank)]) + rt.band_off,
+                       static_cast<size_t>(rt.part.X1 - rt.part.X0) * 4, true);
+      any_remote = true;
+    }
+    if (rc) return rc;
+  }
+  // 2. the root's own launch: slot 0's pointers, by image
+  rc = launch_root(job, src, src_pitch, dst, dst_pitch);
   if (rc) return rc;
   if (!any_remote) return IST_OK;
   // 3. ONE grouped batch: every sender's bands to the root, the root's receives on their own stream
@@ -314,8 +398,10 @@ int ist_group_job_launch(ist_group_job* job, const void* const* src, const size_
   for (auto& rt : job->parts) {
     if (rt.part.slot == 0 || rt.local) continue;
     const size_t bytes = part_bytes(rt.part);
-    void* into = rt.part.in_place ? static_cast<void*>(static_cast<uint8_t*>(dst) + static_cast<size_t>(rt.part.Y0) * dst_pitch) : rt.staging;
-    nrc = R->Send(rt.band, bytes, kNcclUint8, 0, g->comm[static_cast<size_t>(rt.rank)], g->ctx[static_cast<size_t>(rt.rank)]->stream);
+    void* into = rt.part.in_place ? static_cast<void*>(static_cast<uint8_t*>(dst) + static_cast<size_t>(rt.part.Y0) * dst_pitch)
+                                  : static_cast<void*>(static_cast<uint8_t*>(g->staging) + rt.staging_off);
+    const void* band = static_cast<const uint8_t*>(g->band_arena[static_cast<size_t>(rt.rank)]) + rt.band_off;
+    nrc = R->Send(band, bytes, kNcclUint8, 0, g->comm[static_cast<size_t>(rt.rank)], g->ctx[static_cast<size_t>(rt.rank)]->stream);
     if (!nrc) nrc = R->Recv(into, bytes, kNcclUint8, rt.rank, g->comm[0], g->recv_stream);
     if (nrc) { (void)R->GroupEnd(); return nccl_fail("ncclSend/ncclRecv", nrc); }
   }
@@ -324,7 +410,7 @@ int ist_group_job_launch(ist_group_job* job, const void* const* src, const size_
   // 4. staged bands: placed behind their receive (same stream)
   for (auto& rt : job->parts) {
     if (!rt.place_job) continue;
-    const void* band = rt.staging;
+    const void* band = static_cast<const uint8_t*>(g->staging) + rt.staging_off;
     const size_t bp = static_cast<size_t>(rt.part.X1 - rt.part.X0) * 4;
     rc = ist_job_launch(rt.place_job, &band, &bp, 1, dst, dst_pitch, g->recv_stream);
     if (rc) return rc;
@@ -332,20 +418,46 @@ int ist_group_job_launch(ist_group_job* job, const void* const* src, const size_
   return IST_OK;
 }
 
+std::string job_key(int64_t cw, int64_t ch, const ist_op* ops, int n_ops, const ist_image_desc* images, int n_images, int filter, int split) {
+  std::string k;
+  auto put = [&](const void* p, size_t n) { k.append(static_cast<const char*>(p), n); };
+  put(&cw, sizeof cw); put(&ch, sizeof ch); put(&filter, sizeof filter); put(&split, sizeof split); put(&n_ops, sizeof n_ops); put(&n_images, sizeof n_images);
+  for (int i = 0; i < n_ops; ++i) {            // field by field: struct padding is not part of the key
+    const ist_op& o = ops[i];
+    put(&o.kind, sizeof o.kind); put(&o.image, sizeof o.image); put(o.m, sizeof o.m); put(o.s, sizeof o.s); put(o.d, sizeof o.d); put(o.rgba, sizeof o.rgba);
+  }
+  for (int i = 0; i < n_images; ++i) {
+    const ist_image_desc& d = images[i];
+    const int32_t v[6] = {d.width, d.height, d.orientation, d.bmp_width, d.bmp_height, d.opaque};
+    put(v, sizeof v);
+  }
+  return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+// src[k] / src_pitch[k] belong to PART k: the device address (on the part's device) of ROW 0 of the part's image.  A slot
+// that holds only rows [sy0, sy1) passes the address of row sy0 minus sy0 * pitch.  dst: the canvas on the root's device,
+// rows contiguous.  Asynchronous; ist_group_sync waits for the canvas.
+int ist_group_job_launch(ist_group_job* job, const void* const* src, const size_t* src_pitch, int n_parts, void* dst, size_t dst_pitch) {
+  if (!job || !src || !dst) return fail(IST_E_INVALID, "ist_group_job_launch: NULL argument");
+  if (n_parts != static_cast<int>(job->parts.size())) return fail(IST_E_INVALID, "ist_group_job_launch: one source pointer per part is expected");
+  if (dst_pitch != static_cast<size_t>(job->cw) * 4) return fail(IST_E_INVALID, "ist_group_job_launch: the canvas rows must be contiguous (dst_pitch == canvas_w * 4)");
+  std::lock_guard<std::mutex> lock(job->g->mu);
+  return group_launch_locked(job, src, src_pitch, dst, dst_pitch);
+}
+
 int ist_group_sync(ist_group* g) {
   if (!g) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
-  for (size_t r = 0; r < g->devs.size(); ++r) {
-    DeviceGuard dg(g->devs[r]);
-    if (hipStreamSynchronize(g->ctx[r]->stream) != hipSuccess) return fail(IST_E_HIP, "hipStreamSynchronize failed");
-  }
-  DeviceGuard dg(g->devs[0]);
-  if (hipStreamSynchronize(g->recv_stream) != hipSuccess) return fail(IST_E_HIP, "hipStreamSynchronize failed");
-  return IST_OK;
+  return group_sync_locked(g);
 }
 
 // ---- host path: stitch(images, direction, {devices}) ------------------------------------------------------------------
 // plan -> parts -> every device uploads ONLY the source rows its parts sample (its own PCIe link, its own packing threads)
-// -> bands + gather -> the root's canvas comes back as one pooled pinned block.
+// -> HOST SINK: every band is DMA'ed by its device straight into the pooled pinned result (no gather, no root readback);
+//    otherwise: bands + gather -> the root's canvas comes back as one pooled pinned block.
 int ist_group_stitch_rgba8(ist_group* g, const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch, int n_images,
                            int direction, int mode, double gap, const ist_limits* limits, int filter, int split, ist_plan* out_plan,
                            uint8_t** out_pixels) {
@@ -362,9 +474,31 @@ int ist_group_stitch_rgba8(ist_group* g, const ist_image_desc* images, const uin
   rc = ist_plan_ops(out_plan, images, n_images, ops.data(), &n_ops);
   if (rc != IST_OK) return rc;
   static const uint8_t transparent[4] = {0, 0, 0, 0};
-  ist_group_job* job = ist_group_job_create(g, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, images, n_images, filter, split);
-  if (!job) return g_last_code ? g_last_code : IST_E_INVALID;
-  struct JobFree { ist_group_job* j; ~JobFree() { ist_group_job_destroy(j); } } jf{job};
+  std::lock_guard<std::mutex> glock(g->mu);            // one host-path stitch in flight per group (index.js:772 isStitching)
+  // the compiled group job: from the LRU, or compiled now and kept
+  ist_group_job* job = nullptr;
+  {
+    const std::string key = job_key(out_plan->canvas_w, out_plan->canvas_h, ops.data(), n_ops, images, n_images, filter, split);
+    for (size_t k = 0; k < g->cache.size(); ++k)
+      if (g->cache[k].key == key) {
+        ist_group::Cached c = g->cache[k];
+        g->cache.erase(g->cache.begin() + static_cast<std::ptrdiff_t>(k));
+        g->cache.push_back(c);
+        job = c.job;
+        break;
+      }
+    if (!job) {
+      job = ist_group_job_create(g, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, images, n_images, filter, split);
+      if (!job) return g_last_code ? g_last_code : IST_E_INVALID;
+      if (g->cache.size() >= ist_group::kCacheJobs) {    // every call ends with the group idle: the oldest job is not in flight
+        group_job_free(g->cache.front().job);
+        g->cache.erase(g->cache.begin());
+      }
+      g->cache.push_back(ist_group::Cached{key, job});
+    }
+  }
+  rc = ensure_arenas(g, job);
+  if (rc) return rc;
 
   // holdings: per (device, image) the union of the rows its parts sample, + 16 readable bytes behind the last row
   const size_t nd = g->devs.size();
@@ -377,38 +511,24 @@ int ist_group_stitch_rgba8(ist_group* g, const ist_image_desc* images, const uin
     else { it->second.lo = std::min(it->second.lo, rt.part.sy0); it->second.hi = std::max(it->second.hi, rt.part.sy1); }
   }
   auto width_of = [&](int i) { return static_cast<size_t>(images[i].bmp_width > 0 ? images[i].bmp_width : images[i].width); };
-  std::vector<int> up_rc(nd, IST_OK);
-  std::vector<std::string> up_err(nd);
-  std::vector<std::unique_lock<std::mutex>> locks;
-  for (size_t r = 0; r < nd; ++r) locks.emplace_back(g->ctx[r]->mu);
-  {
-    std::vector<std::thread> th;
-    for (size_t r = 0; r < nd; ++r) th.emplace_back([&, r]() {
-      ist_ctx* c = g->ctx[r];
-      DeviceGuard dg(c->device);
-      size_t total = 0;
-      for (auto& kv : hold[r]) { kv.second.off = total; total += ((width_of(kv.first) * 4 * static_cast<size_t>(kv.second.hi - kv.second.lo) + 16) + 255) & ~static_cast<size_t>(255); }
-      int rc2 = grow_device(&c->scratch_src, &c->scratch_src_bytes, total ? total : 256);
-      std::vector<RowsCopy> up;
-      for (auto& kv : hold[r]) {
-        const size_t row = width_of(kv.first) * 4, hp = src_pitch ? src_pitch[kv.first] : row;
-        if (hp < row) { rc2 = fail(IST_E_INVALID, "src_pitch too small"); break; }
-        up.push_back(RowsCopy{static_cast<uint8_t*>(c->scratch_src) + kv.second.off, src[kv.first] + static_cast<size_t>(kv.second.lo) * hp, nullptr, hp, row,
-                              static_cast<size_t>(kv.second.hi - kv.second.lo)});
-      }
-      if (rc2 == IST_OK) { if (!c->stager) c->stager.reset(new Stager(c->device)); rc2 = c->stager->upload(up, c->stream); }
-      up_rc[r] = rc2;
-      if (rc2) up_err[r] = g_last_error;
-    });
-    for (auto& t : th) t.join();
-  }
-  for (size_t r = 0; r < nd; ++r) if (up_rc[r]) return fail(up_rc[r], up_err[r]);
-  // canvas on the root, part pointers (row 0 of the image as seen from the holding)
+  const size_t canvas_pitch = static_cast<size_t>(out_plan->canvas_w) * 4;
+  const size_t canvas_bytes = canvas_pitch * static_cast<size_t>(out_plan->canvas_h);
+  const bool host_sink = job->host_sink_ok && !g->self_send;
   ist_ctx* root = g->ctx[0];
-  const size_t canvas_bytes = static_cast<size_t>(out_plan->canvas_w) * 4 * static_cast<size_t>(out_plan->canvas_h);
   {
     DeviceGuard dg(root->device);
     rc = grow_device(&root->scratch_dst, &root->scratch_dst_bytes, canvas_bytes);
+    if (rc) return rc;
+  }
+  uint8_t* host = static_cast<uint8_t*>(pool_take(canvas_bytes));
+  if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
+  struct HostGuard { uint8_t* p; ist_group* g; bool keep = false; ~HostGuard() { if (!keep) { (void)group_sync_locked(g); pool_give(p); } } } hg{host, g};
+  // part pointers: row 0 of the image as seen from the holding (offsets are known before the uploads run)
+  for (size_t r = 0; r < nd; ++r) {
+    size_t total = 0;
+    for (auto& kv : hold[r]) { kv.second.off = total; total += round256(width_of(kv.first) * 4 * static_cast<size_t>(kv.second.hi - kv.second.lo) + 16); }
+    DeviceGuard dg(g->devs[r]);
+    rc = grow_device(&g->ctx[r]->scratch_src, &g->ctx[r]->scratch_src_bytes, total ? total : 256);
     if (rc) return rc;
   }
   std::vector<const void*> psrc(job->parts.size(), nullptr);
@@ -420,44 +540,99 @@ int ist_group_stitch_rgba8(ist_group* g, const ist_image_desc* images, const uin
     psrc[k] = reinterpret_cast<const void*>(reinterpret_cast<uintptr_t>(g->ctx[static_cast<size_t>(rt.rank)]->scratch_src) + h.off - static_cast<uintptr_t>(h.lo) * row);
     ppitch[k] = row;
   }
-  rc = ist_group_job_launch(job, psrc.data(), ppitch.data(), static_cast<int>(job->parts.size()), root->scratch_dst, static_cast<size_t>(out_plan->canvas_w) * 4);
-  if (rc) return rc;
-  rc = ist_group_sync(g);
-  if (rc) return rc;
+  // one host thread per device: upload its rows, then (host sink) render its bands and send each home over its own link
+  std::vector<int> up_rc(nd, IST_OK);
+  std::vector<std::string> up_err(nd);
+  std::vector<std::unique_lock<std::mutex>> locks;
+  for (size_t r = 0; r < nd; ++r) locks.emplace_back(g->ctx[r]->mu);
   {
-    DeviceGuard dg(root->device);
-    uint8_t* host = static_cast<uint8_t*>(pool_take(canvas_bytes));
-    if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
-    if (hipMemcpyAsync(host, root->scratch_dst, canvas_bytes, hipMemcpyDeviceToHost, root->stream) != hipSuccess || hipStreamSynchronize(root->stream) != hipSuccess) {
-      (void)hipGetLastError(); pool_give(host);
-      return fail(IST_E_HIP, "result readback failed");
-    }
-    *out_pixels = host;
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < nd; ++r) th.emplace_back([&, r]() {
+      ist_ctx* c = g->ctx[r];
+      DeviceGuard dg(c->device);
+      int rc2 = IST_OK;
+      std::vector<RowsCopy> up;
+      for (auto& kv : hold[r]) {
+        const size_t row = width_of(kv.first) * 4, hp = src_pitch ? src_pitch[kv.first] : row;
+        if (hp < row) { rc2 = fail(IST_E_INVALID, "src_pitch too small"); break; }
+        up.push_back(RowsCopy{static_cast<uint8_t*>(c->scratch_src) + kv.second.off, src[kv.first] + static_cast<size_t>(kv.second.lo) * hp, nullptr, hp, row,
+                              static_cast<size_t>(kv.second.hi - kv.second.lo)});
+      }
+      if (rc2 == IST_OK) { if (!c->stager) c->stager.reset(new Stager(c->device)); rc2 = c->stager->upload(up, c->stream); }
+      if (rc2 == IST_OK && host_sink) {
+        for (size_t k = 0; k < job->parts.size() && rc2 == IST_OK; ++k) {
+          const auto& rt = job->parts[k];
+          if (rt.part.slot == 0 || static_cast<size_t>(rt.rank) != r) continue;
+          uint8_t* band = static_cast<uint8_t*>(g->band_arena[r]) + rt.band_off;
+          rc2 = launch_band(job, k, psrc.data(), ppitch.data(), band, canvas_pitch, true);
+          if (rc2 == IST_OK && hipMemcpyAsync(host + static_cast<size_t>(rt.part.Y0) * canvas_pitch, band, part_bytes(rt.part), hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            rc2 = fail(IST_E_HIP, "band readback failed");
+          }
+        }
+        if (rc2 == IST_OK && r == 0) {                 // the root: everything that is not a band
+          rc2 = launch_root(job, psrc.data(), ppitch.data(), root->scratch_dst, canvas_pitch);
+          for (size_t q = 0; q < job->root_rows.size() && rc2 == IST_OK; ++q) {
+            const size_t y0 = static_cast<size_t>(job->root_rows[q].first), y1 = static_cast<size_t>(job->root_rows[q].second);
+            if (hipMemcpyAsync(host + y0 * canvas_pitch, static_cast<uint8_t*>(root->scratch_dst) + y0 * canvas_pitch, (y1 - y0) * canvas_pitch, hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+              (void)hipGetLastError();
+              rc2 = fail(IST_E_HIP, "result readback failed");
+            }
+          }
+        }
+      }
+      up_rc[r] = rc2;
+      if (rc2) up_err[r] = g_last_error;
+    });
+    for (auto& t : th) t.join();
   }
+  for (size_t r = 0; r < nd; ++r) if (up_rc[r]) return fail(up_rc[r], up_err[r]);
+  if (!host_sink) {
+    rc = group_launch_locked(job, psrc.data(), ppitch.data(), root->scratch_dst, canvas_pitch);
+    if (rc) return rc;
+    rc = group_sync_locked(g);
+    if (rc) return rc;
+    DeviceGuard dg(root->device);
+    if (hipMemcpyAsync(host, root->scratch_dst, canvas_bytes, hipMemcpyDeviceToHost, root->stream) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "result readback failed"); }
+  }
+  rc = group_sync_locked(g);
+  if (rc) return rc;
+  hg.keep = true;
+  *out_pixels = host;
   pg.keep = true;
   return IST_OK;
 }
 
-// stitch(images, direction, {devices: [...]}) in one call: groups are cached per device list
+// stitch(images, direction, {devices: [...]}) in one call: groups are cached per device list (the most recent kGroups lists)
 int ist_stitch_rgba8_multi(const int* devices, int ndev, const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch,
                            int n_images, int direction, int mode, double gap, const ist_limits* limits, int filter, int split,
                            ist_plan* out_plan, uint8_t** out_pixels) {
   if (!devices || ndev < 1) return fail(IST_E_INVALID, "ist_stitch_rgba8_multi: empty device list");
+  constexpr size_t kGroups = 4;
+  struct Entry { std::vector<int> key; std::shared_ptr<ist_group> g; };
   static std::mutex mu;
-  static std::map<std::vector<int>, ist_group*>* cache = new std::map<std::vector<int>, ist_group*>();   // never destroyed: no HIP calls at exit
-  ist_group* g = nullptr;
+  static std::vector<Entry>* cache = new std::vector<Entry>();   // never destroyed: no HIP calls at exit
+  std::shared_ptr<ist_group> g;
   {
     std::lock_guard<std::mutex> lock(mu);
     const std::vector<int> key(devices, devices + ndev);
-    auto it = cache->find(key);
-    if (it != cache->end()) g = it->second;
-    else {
-      g = ist_group_create(devices, ndev);
-      if (!g) return g_last_code ? g_last_code : IST_E_INVALID;
-      (*cache)[key] = g;
+    for (size_t k = 0; k < cache->size(); ++k)
+      if ((*cache)[k].key == key) {
+        Entry e = (*cache)[k];
+        cache->erase(cache->begin() + static_cast<std::ptrdiff_t>(k));
+        cache->push_back(e);
+        g = e.g;
+        break;
+      }
+    if (!g) {
+      ist_group* raw = ist_group_create(devices, ndev);
+      if (!raw) return g_last_code ? g_last_code : IST_E_INVALID;
+      g.reset(raw, ist_group_destroy);            // an evicted group is destroyed when its last call has returned
+      if (cache->size() >= kGroups) cache->erase(cache->begin());
+      cache->push_back(Entry{key, g});
     }
   }
-  return ist_group_stitch_rgba8(g, images, src, src_pitch, n_images, direction, mode, gap, limits, filter, split, out_plan, out_pixels);
+  return ist_group_stitch_rgba8(g.get(), images, src, src_pitch, n_images, direction, mode, gap, limits, filter, split, out_plan, out_pixels);
 }
 
 }  // extern "C"

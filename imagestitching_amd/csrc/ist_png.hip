@@ -242,8 +242,8 @@ int ist_png_encode_device(ist_ctx* ctx, const void* canvas, size_t pitch, int64_
   const size_t o_tab = 0, o_pow = o_tab + up16(bytes_tab), o_T = o_pow + up16(bytes_pow), o_s1 = o_T + up16(bytes_T),
                o_s2 = o_s1 + up16(bytes_s), o_crc = o_s2 + up16(bytes_s), scratch_bytes = o_crc + up16(bytes_crc);
   uint8_t* scratch = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&scratch), scratch_bytes) != hipSuccess) return fail(IST_E_NOMEM, "PNG scratch allocation failed");
-  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{scratch};
+  if (dev_malloc(reinterpret_cast<void**>(&scratch), scratch_bytes) != hipSuccess) return fail(IST_E_NOMEM, "PNG scratch allocation failed");
+  struct Free { void* p; ~Free() { dev_free(p); } } fr{scratch};    // (a free waits for the device: the early returns below are safe)
 #define PNG_HIP(e) do { const hipError_t e_ = (e); if (e_ != hipSuccess) return fail(IST_E_HIP, std::string(#e) + ": " + hipGetErrorString(e_)); } while (0)
   PNG_HIP(hipMemcpyAsync(scratch + o_tab, L.row_tab.data(), bytes_tab, hipMemcpyHostToDevice, stream));
   PNG_HIP(hipMemcpyAsync(scratch + o_pow, xpow.data(), bytes_pow, hipMemcpyHostToDevice, stream));

@@ -513,13 +513,30 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
   // ---- every slab's compression goes out now, each followed by the copy of its per-chunk results and an event
   // (pinned: a device-to-host copy into pageable memory would block this thread until the slab is compressed, and the
   // slabs' launches would no longer run ahead of the host)
+  struct Events { std::vector<hipEvent_t> ev; ~Events() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); } } evs;   // (a slab that was never launched has no event: destroying NULL would leave a sticky error for the next launch check)
+  evs.ev.assign(n_slabs, nullptr);
   struct Pinned { uint8_t* p; ~Pinned() { if (p) pool_give(p); } } res{static_cast<uint8_t*>(pool_take(20 * per_slab * n_slabs))};
   if (!res.p) return fail(IST_E_NOMEM, "out of pinned host memory for the PNG encoder");
-  struct Events { std::vector<hipEvent_t> ev; ~Events() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); } } evs;
-  evs.ev.assign(n_slabs, nullptr);
+  // file offset of every chunk: pinned host memory the gather kernel reads in place (a pageable source would cost one small
+  // staged copy per slab on the aux stream; those, and the header patches, were ~0.5 ms of stream time per slab)
+  struct PinnedDst { int64_t* p; ~PinnedDst() { if (p) pool_give(p); } } dstp{static_cast<int64_t*>(pool_take(8 * n))};
+  if (!dstp.p) return fail(IST_E_NOMEM, "out of pinned host memory for the PNG encoder");
   unsigned long long* d_dbg = nullptr;
+  // EVERY way out of this function below - the errors too - first waits for both streams: the kernels in flight write their
+  // per-chunk results into `res` and read `dstp` in place, and a block given back to the pool while slab s+1 is still
+  // compressing could be handed to another thread's call.  (Declared after the two blocks: destroyed before them.)
+  struct Drain {
+    hipStream_t a, b; unsigned long long** dbg; bool armed = true;
+    ~Drain() {
+      if (armed) { (void)hipStreamSynchronize(a); if (b != a) (void)hipStreamSynchronize(b); }
+      if (*dbg) { dev_free(*dbg); *dbg = nullptr; }
+    }
+  } drain{stream, aux, &d_dbg};
   static const bool phases = tuning_mode() && std::getenv("IST_PNG_PHASES") != nullptr;      // (IST_TUNING=1 processes only)
-  if (phases && hipMalloc(reinterpret_cast<void**>(&d_dbg), 64 * n) != hipSuccess) d_dbg = nullptr;
+  if (phases && dev_malloc(reinterpret_cast<void**>(&d_dbg), 64 * n) != hipSuccess) d_dbg = nullptr;
+  // test knob (IST_TUNING=1 IST_PNG_FAIL_AT=<slab>): fail the layout of that slab the way a damaged result would, so that the
+  // error path above is exercised with kernels in flight
+  static const long fail_at = (tuning_mode() && std::getenv("IST_PNG_FAIL_AT")) ? std::atol(std::getenv("IST_PNG_FAIL_AT")) : -1;
   auto compress = [&](size_t s) -> int {
     const size_t c0 = s * per_slab, cn = std::min(per_slab, n - c0);
     // the kernel writes its per-chunk results straight into the pinned host block (visible to the host behind the event).
@@ -550,10 +567,6 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
   const uint64_t M = 65521;
   uint64_t a = 1, b = 0;
   struct Patch { int64_t at; uint8_t b[64]; int n; };
-  // file offset of every chunk: pinned host memory the gather kernel reads in place (a pageable source would cost one small
-  // staged copy per slab on the aux stream; those, and the header patches, were ~0.5 ms of stream time per slab)
-  struct PinnedDst { int64_t* p; ~PinnedDst() { if (p) pool_give(p); } } dstp{static_cast<int64_t*>(pool_take(8 * n))};
-  if (!dstp.p) return fail(IST_E_NOMEM, "out of pinned host memory for the PNG encoder");
   int64_t* const dst = dstp.p;
   const int64_t limit = idat_limit();
   static const uint8_t trailer_block[5] = {0x01, 0x00, 0x00, 0xFF, 0xFF};          // final, empty stored block
@@ -600,6 +613,7 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
     const size_t c0 = s * per_slab, cn = std::min(per_slab, n - c0);
     if (s + 1 < n_slabs) { const int rc = compress(s + 1); if (rc) return rc; }
     PNG_HIP(hipEventSynchronize(evs.ev[s]));
+    if (fail_at >= 0 && static_cast<size_t>(fail_at) == s) return fail(IST_E_HIP, "PNG deflate kernel returned an impossible chunk length (forced: IST_PNG_FAIL_AT)");
     const uint8_t* r = res.p + 20 * per_slab * s;
     const uint32_t* len16 = reinterpret_cast<const uint32_t*>(r);
     const uint32_t* crc = reinterpret_cast<const uint32_t*>(r + 4 * per_slab);
@@ -654,10 +668,10 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
   }
   PNG_HIP(hipStreamSynchronize(aux));
   if (aux != stream) PNG_HIP(hipStreamSynchronize(stream));
+  drain.armed = false;                                 // both streams are idle
   if (d_dbg) {
     std::vector<unsigned long long> hdbg(8 * n);
     (void)hipMemcpy(hdbg.data(), d_dbg, 64 * n, hipMemcpyDeviceToHost);
-    (void)hipFree(d_dbg);
     double sum[6] = {0, 0, 0, 0, 0, 0};
     for (size_t j = 0; j < n; ++j) for (int k = 0; k < 6; ++k) sum[k] += static_cast<double>(hdbg[8 * j + k + 1] - hdbg[8 * j + k]);
     static const char* names[6] = {"A load+filter", "B histogram+adler", "C code build", "D bit counts+scan", "body emit", "E slot write+crc"};

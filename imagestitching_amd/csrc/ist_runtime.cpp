@@ -6,6 +6,7 @@
 // There is deliberately no CPU fallback: without a HIP device every rendering entry point fails.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <chrono>
 #include <cstdio>
@@ -36,10 +37,17 @@ int ctx_png_scratch(ist_ctx* ctx, size_t need, void** p) {
   return rc;
 }
 
+static std::atomic<int64_t> g_dev_allocs{0};
+int dev_malloc(void** p, size_t bytes) {
+  g_dev_allocs.fetch_add(1, std::memory_order_relaxed);
+  return static_cast<int>(hipMalloc(p, bytes));
+}
+void dev_free(void* p) { if (p) (void)hipFree(p); }
+
 int grow_device(void** p, size_t* have, size_t need) {
   if (*have >= need) return IST_OK;
-  if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
-  IST_HIP(hipMalloc(p, need));
+  if (*p) { dev_free(*p); *p = nullptr; *have = 0; }
+  if (dev_malloc(p, need) != 0) { (void)hipGetLastError(); return fail(IST_E_NOMEM, "out of device memory (" + std::to_string(need >> 20) + " MiB)"); }
   *have = need;
   return IST_OK;
 }
@@ -109,6 +117,8 @@ int png_to_host(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64
 
 extern "C" {
 
+int64_t ist_debug_device_allocs(void) { return g_dev_allocs.load(std::memory_order_relaxed); }
+
 int ist_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -137,17 +147,30 @@ int ist_ctx_set_png_level(ist_ctx* ctx, int level) {
   return IST_OK;
 }
 
+int ist_ctx_sync(ist_ctx* ctx) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  DeviceGuard g(ctx->device);
+  bool ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+  if (ctx->aux) ok = (hipStreamSynchronize(ctx->aux) == hipSuccess) && ok;
+  if (ctx->stager) ok = (ctx->stager->sync() == IST_OK) && ok;
+  if (!ok) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipStreamSynchronize failed"); }
+  return IST_OK;
+}
+
 void ist_ctx_destroy(ist_ctx* ctx) {
   if (!ctx) return;
   DeviceGuard g(ctx->device);
-  if (ctx->scratch_src) (void)hipFree(ctx->scratch_src);
-  if (ctx->scratch_dst) (void)hipFree(ctx->scratch_dst);
-  if (ctx->scratch_dec) (void)hipFree(ctx->scratch_dec);
-  if (ctx->scratch_huff) (void)hipFree(ctx->scratch_huff);
-  if (ctx->scratch_png) (void)hipFree(ctx->scratch_png);
-  if (ctx->scratch_file) (void)hipFree(ctx->scratch_file);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
+  dev_free(ctx->scratch_src);
+  dev_free(ctx->scratch_dst);
+  dev_free(ctx->scratch_dec);
+  dev_free(ctx->scratch_huff);
+  dev_free(ctx->scratch_png);
+  dev_free(ctx->scratch_file);
+  dev_free(ctx->scratch_arena);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
-  for (const ist_ctx::TableBlock& b : ctx->table_pool) (void)hipFree(b.p);
+  for (const ist_ctx::TableBlock& b : ctx->table_pool) dev_free(b.p);
   ctx->stager.reset();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -185,7 +208,7 @@ ist_job* ist_job_create(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const 
           break;
         }
     }
-    if (!job->d_tables && hipMalloc(reinterpret_cast<void**>(&job->d_tables), total) == hipSuccess) job->d_tables_bytes = total;
+    if (!job->d_tables && dev_malloc(reinterpret_cast<void**>(&job->d_tables), total) == hipSuccess) job->d_tables_bytes = total;
     if (!job->d_tables ||
         hipMemcpy(job->d_tables, blob.data(), total, hipMemcpyHostToDevice) != hipSuccess) {      // blocking: the tables are in place when this returns
       (void)hipGetLastError();
@@ -242,7 +265,17 @@ int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch
   if ((reinterpret_cast<uintptr_t>(dst) & 3) != 0) return fail(IST_E_INVALID, "dst must be 4-byte aligned");
   DeviceGuard g(job->ctx->device);
   if (!g.ok) return fail(IST_E_NO_DEVICE, "hipSetDevice failed");
-  job->launched = true;
+  {
+    std::lock_guard<std::mutex> lk(job->launch_mu);
+    job->launched = true;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int k = 0;
+    while (k < job->n_launched_on && job->launched_on[k] != st) ++k;
+    if (k == job->n_launched_on) {
+      if (k < ist_job::kStreams) job->launched_on[job->n_launched_on++] = st;
+      else job->launched_many = true;
+    }
+  }
   return launch_stitch(a, h.info.n_tiles, h.kernel_kind, stream);
 }
 
@@ -252,9 +285,16 @@ void ist_job_destroy(ist_job* job) {
     DeviceGuard g(job->ctx->device);
     // the tables go to the context's pool for the next job: every launch must have read them first.  (What hipFree did
     // implicitly.  NOT an event per launch: recorded behind every kernel it cost back-to-back launches 3 % — 135 -> 140 us,
-    // measured.)  One-shot jobs of the host-path entry points arrive here with an idle stream.
+    // measured.)  Only the streams the job ran on are waited for: a host that shares the device (torch, the device group's
+    // other streams) is not stalled by the death of one job.  One-shot jobs of the host-path entry points arrive here with
+    // an idle stream.  A stream the caller has destroyed since makes the wait fail: then, and only then, the device is waited for.
     bool idle = true;
-    if (job->launched) { idle = hipDeviceSynchronize() == hipSuccess; if (!idle) (void)hipGetLastError(); }
+    if (job->launched) {
+      bool per_stream = !job->launched_many;
+      for (int k = 0; k < job->n_launched_on && per_stream; ++k)
+        if (hipStreamSynchronize(job->launched_on[k]) != hipSuccess) { (void)hipGetLastError(); per_stream = false; }
+      if (!per_stream) { idle = hipDeviceSynchronize() == hipSuccess; if (!idle) (void)hipGetLastError(); }
+    }
     if (job->d_tables) {
       bool kept = false;
       if (idle) {
@@ -264,7 +304,7 @@ void ist_job_destroy(ist_job* job) {
           kept = true;
         }
       }
-      if (!kept) (void)hipFree(job->d_tables);
+      if (!kept) dev_free(job->d_tables);
     }
   }
   delete job;
@@ -459,13 +499,14 @@ int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_
   const size_t row = static_cast<size_t>(J.width) * 4;
   const size_t o_out = take(row * J.height);
   uint8_t* d = nullptr;
-  IST_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
-  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
+  rc = grow_device(&ctx->scratch_arena, &ctx->scratch_arena_bytes, off);
+  if (rc) return rc;
+  d = static_cast<uint8_t*>(ctx->scratch_arena);
   rc = jpeg_enqueue(J, d, L, d + o_out, row, ctx->stream);
   if (rc) return rc;
   std::vector<RowsCopy> down{RowsCopy{d + o_out, nullptr, out, out_pitch, row, static_cast<size_t>(J.height)}};
   rc = stager_of(ctx).download(down, ctx->stream);
-  (void)hipStreamSynchronize(ctx->stream);              // nothing of this call may still read the arena `fr` releases
+  (void)hipStreamSynchronize(ctx->stream);              // nothing of this call may still read the arena when the next call reuses it
   return rc;
 }
 
@@ -720,9 +761,10 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   const size_t o_canvas = take(canvas_pitch * static_cast<size_t>(out_plan->canvas_h));
   const int64_t png_cap = ist_png_bound(out_plan->canvas_w, out_plan->canvas_h);
   const size_t o_png = take(static_cast<size_t>(png_cap));
-  uint8_t* d = nullptr;
-  IST_HIP(hipMalloc(reinterpret_cast<void**>(&d), off));
-  struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{d};
+  // the arena lives in the context (grow-only): no allocation per call once it has seen the largest job
+  rc = grow_device(&ctx->scratch_arena, &ctx->scratch_arena_bytes, off);
+  if (rc) return rc;
+  uint8_t* d = static_cast<uint8_t*>(ctx->scratch_arena);
   ph.lap(IST_PHASE_PLAN_ARENA, "plan + device arena", nullptr);
   std::vector<uint8_t*> img(static_cast<size_t>(n));
   std::vector<const void*> dsrc(static_cast<size_t>(n));

@@ -146,6 +146,26 @@ def plan(images, direction, opts=None):
 _ctx_cache = {}
 
 
+def _drain_at_exit():
+    """Interpreter exit: wait for whatever the cached contexts still have in flight and hand the idle pinned result blocks
+    back, so that no DMA of the library is pending when the HIP runtime (or a profiler attached to it: rocprofv3's copy
+    tracing waited 30 s for completion callbacks otherwise) shuts down.  Contexts are NOT destroyed: jobs that are garbage
+    collected later still refer to them."""
+    for c in list(_ctx_cache.values()):
+        try:
+            L.lib.ist_ctx_sync(c)
+        except Exception:
+            pass
+    try:
+        L.lib.ist_pool_trim()
+    except Exception:
+        pass
+
+
+import atexit  # noqa: E402
+atexit.register(_drain_at_exit)
+
+
 def _ctx(device=0):
     c = _ctx_cache.get(device)
     if c is None:
@@ -303,6 +323,11 @@ def decode_files_device(blobs, device=0, out=None):
     dev = torch.device("cuda", device)
     if out is None:
         out = [torch.empty((h + 1, w, 4), dtype=torch.uint8, device=dev)[:h] for (w, h, _) in sizes]
+    else:
+        # the library writes `out` from its own streams: what the caller queued on these tensors (a launch still reading the
+        # previous bitmaps) must be done first (include/imagestitch.h, ist_decode_files_device "Ordering")
+        for d in {t.device for t in out}:
+            torch.cuda.current_stream(d).synchronize()
     files = (C.c_char_p * n)(*blobs)
     lens = (C.c_int64 * n)(*[len(b) for b in blobs])
     dst, pitch, rows = (C.c_void_p * n)(), (C.c_size_t * n)(), (C.c_int64 * n)()

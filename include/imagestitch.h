@@ -128,6 +128,9 @@ typedef struct ist_job ist_job;   /* one compiled op list (device-side cell/op t
 IST_API int ist_abi_version(void);
 IST_API const char* ist_last_error(void);
 IST_API int ist_device_count(void);                                   /* 0 when no HIP device is usable */
+/* device allocations (hipMalloc calls) the library has made in this process so far.  A measurement aid for hosts and tests:
+ * the steady state of every entry point allocates nothing (scratch, arenas and table blocks are kept and re-used). */
+IST_API int64_t ist_debug_device_allocs(void);
 
 /* ---- planner: pure CPU, bit-exact to index.js:1211-1216, 1251-1386, 1432-1433, 1522-1554 -------------------- */
 IST_API void ist_limits_default(int platform, ist_limits* out);        /* index.js:126-156 fallback branch */
@@ -166,6 +169,9 @@ IST_API int ist_shard_parts(const ist_op* ops, int n_ops, int64_t canvas_w, int6
 /* ---- device path: inputs and output already resident in HBM ------------------------------------------------- */
 IST_API ist_ctx* ist_ctx_create(int device);
 IST_API void ist_ctx_destroy(ist_ctx* ctx);
+/* waits for everything the context itself has in flight (its streams and staging lanes).  Hosts call it before process exit so
+ * that no DMA of the library is still pending when the runtime (or a profiler attached to it) shuts down. */
+IST_API int ist_ctx_sync(ist_ctx* ctx);
 /* PNG export form for every *_png entry point of this context.  1 (default): Paeth filter + run-length matches + a
  * dynamic Huffman code per 16 KiB, all on the GPU: photographs shrink to about 0.43 x raw (smaller than zlib level 6 on
  * the same filtered stream), flat areas (gaps, screenshots) to 2-3 per cent; random data stays 1:1.  0: stored deflate
@@ -262,7 +268,10 @@ IST_API int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t le
 /* files -> decoded bitmaps in CALLER-OWNED DEVICE memory (the Image.src step ending in HBM): baseline JPEG entropy decoding
  * and reconstruction on the GPU, progressive JPEG / PNG / BMP / GIF entropy stages on host threads.  dst[i] must hold
  * dst_rows[i] rows of dst_pitch[i] bytes (sizes from ist_image_info); out_descs (optional) receives what the planner needs
- * (size, EXIF orientation, opaque).  Returns when the bitmaps are complete. */
+ * (size, EXIF orientation, opaque).  Returns when the bitmaps are complete.
+ * Ordering: the library writes dst[i] from its OWN streams.  Whatever the caller has queued on those buffers (a launch
+ * that still reads the previous contents, a fill) must have completed before the call - the library cannot see the
+ * caller's streams.  The Python host synchronises the tensors' current torch stream before it calls. */
 IST_API int ist_decode_files_device(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images,
                                     void* const* dst, const size_t* dst_pitch, const int64_t* dst_rows, ist_image_desc* out_descs);
 /* phase times of the last ist_stitch_files_png / ist_decode_files_device on this context, in milliseconds (measurement

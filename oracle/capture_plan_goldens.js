@@ -15,6 +15,9 @@
  *       instead of the named cases: N seeded random cases (1-12 images of 1..9000 px, EXIF orientations, file sizes around
  *       the bigTask threshold, every platform, stored canvas limits from tiny to lifted, both directions, the three modes,
  *       integer and fractional gaps)
+ *   ... --check   (last argument, either form): regenerate in memory and compare with the file at the output path as PARSED
+ *       JSON (whitespace-insensitive: the committed random set is minified); the "reference" field, which names the Node
+ *       version that produced the file, is not compared.  Exit status 0 = identical, 2 = different; nothing is written.
  */
 'use strict';
 const path = require('path');
@@ -225,6 +228,7 @@ function randomCases(n, seed) {
   }
   return out;
 }
+const CHECK = process.argv[process.argv.length - 1] === '--check';
 if (process.argv[4] === '--random') {
   const list = randomCases(parseInt(process.argv[5] || '400', 10), parseInt(process.argv[6] || '1', 10));
   cases.length = 0;
@@ -234,6 +238,16 @@ if (process.argv[4] === '--random') {
 (async () => {
   const out = { generator: 'oracle/capture_plan_goldens.js', reference: 'Iamctb/ImageStitching miniprogram/pages/index/index.js (run unmodified under Node ' + process.version + ' with a stub wx)', cases: [] };
   for (const c of cases) out.cases.push(await runCase(c));
+  if (CHECK) {
+    const have = JSON.parse(fs.readFileSync(OUT, 'utf8'));
+    const now = JSON.parse(JSON.stringify(out));         // what a reader of the file would get (undefined dropped, -0 -> 0, ...)
+    let bad = have.cases.length === now.cases.length ? 0 : 1;
+    if (bad) realLog('case count differs:', have.cases.length, 'stored,', now.cases.length, 'regenerated');
+    for (let k = 0; k < Math.min(have.cases.length, now.cases.length); k++)
+      if (JSON.stringify(have.cases[k]) !== JSON.stringify(now.cases[k])) { bad++; realLog('case differs:', now.cases[k].name); }
+    realLog(bad ? 'CHECK FAILED' : 'check ok:', OUT, now.cases.length, 'cases regenerate identically from the reference');
+    process.exit(bad ? 2 : 0);
+  }
   fs.mkdirSync(path.dirname(OUT), { recursive: true });
   fs.writeFileSync(OUT, JSON.stringify(out, null, 1));
   realLog('wrote', OUT, out.cases.length, 'cases');

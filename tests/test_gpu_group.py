@@ -116,3 +116,63 @@ print("self send ok")
     env = dict(os.environ, IST_TUNING="1", IST_GROUP_SELF_SEND="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "self send ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_host_sink_every_band_is_read_back_by_its_own_device():
+    """with a host-destined result (the reference's export, index.js:1577-1581) every slot renders its
+    full-width bands compactly and DMAs each one straight into its byte range of the pinned result; the root's launch delivers
+    only the rows no band covers (gaps, the last gap after the strip).  BASELINE configs[3] geometry on eight slots of one
+    GPU must be bit-identical to the one-device result, both splits; a horizontal strip falls back to gather + readback."""
+    px = [U.rand_image(870 + i, 302, 403) for i in range(9)]
+    for opts in ({"filter": "bilinear"}, {"filter": "bilinear", "gap": 7}, {"filter": "nearest", "mode": "max", "gap": 2}):
+        one = ist.stitch(px, "vertical", opts)
+        for split in ("image", "band"):
+            many = ist.stitch(px, "vertical", dict(opts, devices=[0] * 8, split=split))
+            assert np.array_equal(many["data"], one["data"]), (opts, split)
+    one = ist.stitch(px, "horizontal", {"filter": "bilinear"})
+    many = ist.stitch(px, "horizontal", {"filter": "bilinear", "devices": [0] * 8})
+    assert np.array_equal(many["data"], one["data"])
+
+
+def test_no_device_allocation_after_the_first_call():
+    """the group keeps its compiled jobs (LRU) and its band / staging arenas; job tables come from the
+    context's pool.  20 calls with the same plan, then alternating plans: zero hipMallocs after warm-up."""
+    from imagestitching_amd import _lib as L
+    px = [U.rand_image(880 + i, h, w) for i, (w, h) in enumerate(SIZES)]
+    cases = [("vertical", {"filter": "bilinear", "mode": "max", "devices": [0, 0, 0]}),
+             ("horizontal", {"filter": "bilinear", "mode": "min", "devices": [0, 0, 0], "split": "band"})]
+    first = [ist.stitch(px, d, o)["data"].copy() for d, o in cases]
+    before = L.lib.ist_debug_device_allocs()
+    for k in range(20):
+        d, o = cases[k % 2]
+        r = ist.stitch(px, d, o)
+        assert np.array_equal(r["data"], first[k % 2])
+        del r
+    assert L.lib.ist_debug_device_allocs() == before
+
+
+def test_destroying_a_job_does_not_wait_for_an_unrelated_stream():
+    """ist_job_destroy waits for the streams the job ran on, not for the device."""
+    import time
+    import torch
+    st = ist.Stitcher(0)
+    a = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    b = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    imgs = [{"width": 128, "height": 96, "opaque": True}] * 3
+    srcs = [torch.empty((96, 128, 4), dtype=torch.uint8, device="cuda").random_(0, 256) for _ in range(3)]
+    p, job = st.compile(imgs, "vertical", {"filter": "bilinear"})
+    out = torch.empty((p.canvas_h, p.canvas_w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    done = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        for _ in range(300):                  # ~300 x 0.4 ms of copies on the other stream
+            b.copy_(a)
+        done.record()
+    job.launch(srcs, out)
+    t0 = time.perf_counter()
+    job.close()
+    dt = time.perf_counter() - t0
+    still_running = not done.query()
+    side.synchronize()
+    assert still_running and dt < 0.05, (still_running, dt)

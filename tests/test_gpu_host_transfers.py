@@ -1,6 +1,6 @@
 """The host <-> device layer of the host-buffer entry points (imagestitching_amd/csrc/ist_host.cpp).
 
-Round 1 saw an intermittent SIGABRT inside ist_png_encode_rgba8 on a 70000 x 8 image (DESIGN.md section 9): the call
+Round 1 saw an intermittent SIGABRT inside ist_png_encode_rgba8 on a 70000 x 8 image (DESIGN.md section 4c): the call
 page-locked the caller's heap block (hipHostRegister), issued a 70000-row pitched hipMemcpy2DAsync from it and walked a
 65535-row slab loop.  The library now never registers caller memory and never issues a pitched runtime copy: caller
 rows are packed through pinned chunks the library owns, and results come from a pinned pool.  These tests cover what

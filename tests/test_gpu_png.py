@@ -1,6 +1,7 @@
 """PNG export on the GPU: the file must be a valid PNG that decodes, with two independent
 decoders (PIL; and a by-hand chunk walk + zlib.decompress), to exactly the canvas bytes."""
 import io
+import os
 import struct
 import zlib
 
@@ -297,3 +298,35 @@ def test_compressed_png_of_several_slabs_reaches_the_host_whole(monkeypatch):
             monkeypatch.setenv("IST_PNG_IDAT_LIMIT", limit)
         png, n_idat = _check_compressed(a)
         assert n_idat >= least, n_idat
+
+
+def test_a_failed_encode_drains_its_streams_before_the_pinned_blocks_go_back_to_the_pool():
+    """every error return of the compressing encoder first waits for both streams - kernels in flight
+    write their per-chunk results into pooled pinned blocks.  IST_TUNING=1 IST_PNG_FAIL_AT=1 fails the layout of slab 1 while
+    slab 2 is compressing; the next encodes of the same process (which re-use those blocks) must still be right."""
+    import subprocess
+    import sys
+    code = """
+import sys, io
+sys.path.insert(0, %r)
+import numpy as np
+from PIL import Image
+import imagestitching_amd as ist
+Image.MAX_IMAGE_PIXELS = None
+big = np.random.default_rng(5).integers(0, 256, (9000, 4096, 4), dtype=np.uint8)     # 147 MB: three slabs of 64 MiB
+big[..., 3] = 255
+try:
+    ist.encode_png(big)
+    print("no failure")
+except ist.StitchError as e:
+    print("failed as asked:", e.reason)
+for k in range(4):
+    small = np.random.default_rng(10 + k).integers(0, 256, (700 + 13 * k, 900, 4), dtype=np.uint8)
+    png = ist.encode_png(small)
+    back = np.asarray(Image.open(io.BytesIO(png)).convert("RGBA"))
+    assert np.array_equal(back, small), k
+print("pool ok")
+""" % (U.ROOT,)
+    env = dict(os.environ, IST_TUNING="1", IST_PNG_FAIL_AT="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "failed as asked" in r.stdout and "pool ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
