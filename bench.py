@@ -381,9 +381,11 @@ def host_path_leg(ist, np, reps=4):
             "what": "PCIe-inclusive: pageable numpy in -> plan -> H2D through the pinned ring -> launch -> one D2H into a pooled pinned block (never `value`)"}
 
 
-def file_pipeline_leg(ist, reps=3):
-    """SURVEY 8f ranks 2-3 measured: nine 12 MP JPEGs -> one PNG through ist_stitch_files_png, per-stage milliseconds from
-    the C side (ist_ctx_last_timing: every phase ends with a stream sync while timing is on)"""
+def file_pipeline_leg(ist, reps=5):
+    """SURVEY 8f ranks 2-3 measured: nine 12 MP JPEGs -> one PNG through ist_stitch_files_png.  Two runs of the same call:
+    PIPELINED (production: every image decodes on its own thread + stream, band k is rendered and its PNG slabs cross PCIe
+    while later images are still in the Huffman decoder) = ms_end_to_end; and PHASE-TIMED (ist_ctx_set_timing: the same steps
+    with a barrier and a stream sync between them) = stages_ms, each stage with the bound it is priced against."""
     import tempfile
     tmp = tempfile.mkdtemp()
     paths = []
@@ -393,29 +395,53 @@ def file_pipeline_leg(ist, reps=3):
             f.write(photo_jpeg(k, w, h))
         paths.append(p)
     in_bytes = sum(os.path.getsize(p) for p in paths)
-    ist.stitch_files(paths, "vertical", copy=False)                 # warm-up
+    for _ in range(2):
+        ist.stitch_files(paths, "vertical", copy=False)             # warm-up: arena, streams, scratch, result pool
+    ts, png_len = [], 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res = ist.stitch_files(paths, "vertical", copy=False)
+        ts.append(time.perf_counter() - t0)
+        png_len = len(res["png"])
+        del res
+    best = min(ts)
     ist.set_phase_timing(True)
     try:
-        best, phases, png_len = None, None, 0
-        for _ in range(reps):
+        tbest, phases = None, None
+        for _ in range(3):
             t0 = time.perf_counter()
             res = ist.stitch_files(paths, "vertical", copy=False)
             dt = time.perf_counter() - t0
-            if best is None or dt < best:
-                best, phases, png_len = dt, ist.last_phase_times(), len(res["png"])
+            if tbest is None or dt < tbest:
+                tbest, phases = dt, ist.last_phase_times()
             del res
     finally:
         ist.set_phase_timing(False)
     canvas = 4032 * 27216 * 4
-    rate = lambda b, ms: round(b / (ms * 1e-3) / 1e9, 2) if ms > 0.01 else None      # noqa: E731
-    return {"ms_end_to_end": round(best * 1e3, 2), "jpeg_bytes_in": in_bytes, "png_bytes_out": png_len,
-            "stages_ms": {k: round(v, 3) for k, v in phases.items()},
-            "stages_GBs": {"entropy_gpu (scan bytes in)": rate(in_bytes, phases["entropy_gpu"]),
-                           "reconstruct (RGBA bytes out)": rate(canvas, phases["reconstruct"]),
-                           "stitch (algorithmic bytes)": rate(2 * canvas, phases["stitch"]),
-                           "png + d2h (canvas bytes in)": rate(canvas, phases["png"] + phases["d2h"])},
-            "what": "nine photo-like 12 MP JPEGs -> 4032x27216 PNG (level 1); includes reading the files; stage times carry one stream sync each; "
-                    "the PNG's slabs cross PCIe on a second stream while later slabs compress, so `png` holds the D2H too and `d2h` is ~0"}
+    px = 4032 * 27216
+    # what each stage is priced against (the line, not prose, says which stage is furthest from its ceiling):
+    #   entropy_gpu   instruction issue: 3 decodes of the scan (guess, re-decode from the neighbour's exit state, writing pass) x ~22 M
+    #                 symbols x ~200 instructions per symbol step, 64 lanes per wave, 1024 SIMDs issuing one wave-instruction per
+    #                 4 cycles at 2.4 GHz
+    #   reconstruct   HBM: coefficients in (3 B/px at 4:2:0) + sample planes out and in (1.5 + 1.5 B/px) + RGBA out (4 B/px)
+    #   stitch        HBM: 8 B per output pixel (the headline kernel)
+    #   png           PCIe payload: the file's bytes over this GPU's link (57 GB/s: the rate one pinned DMA sustains on these boxes),
+    #                 which the encoder must hide behind
+    symbols = in_bytes * 8 / 6.0
+    issue_rate = 1024 * 2.4e9 / 4 * 64 / 200.0
+    bounds = {"entropy_gpu": ("instruction issue (3 decodes x symbols x ~200 instr)", 3 * symbols / issue_rate * 1e3),
+              "reconstruct": ("hbm (10 B per pixel)", 10.0 * px / 8e12 * 1e3),
+              "stitch": ("hbm (8 B per pixel)", 8.0 * px / 8e12 * 1e3),
+              "png": ("pcie payload (file bytes at 57 GB/s)", png_len / 57e9 * 1e3)}
+    roof = {k: {"bound": b, "bound_ms": round(ms, 3), "achieved_ms": round(phases[k], 3), "frac": round(ms / phases[k], 3) if phases[k] > 0 else None}
+            for k, (b, ms) in bounds.items()}
+    return {"ms_end_to_end": round(best * 1e3, 2), "ms_end_to_end_all": [round(t * 1e3, 2) for t in ts],
+            "ms_phase_timed_run": round(tbest * 1e3, 2), "jpeg_bytes_in": in_bytes, "png_bytes_out": png_len,
+            "stages_ms": {k: round(v, 3) for k, v in phases.items()}, "stage_rooflines": roof,
+            "what": "nine photo-like 12 MP JPEGs -> 4032x27216 PNG (level 1); includes reading the files.  ms_end_to_end = the pipelined call "
+                    "(images decode on their own threads + streams, bands are rendered and exported as their image arrives); stages_ms = the same call "
+                    "with a barrier + stream sync after every stage (ist_ctx_set_timing), whose sum is therefore larger than the pipelined time; "
+                    "`png` holds the D2H (slabs cross PCIe while later slabs compress)"}
 
 
 # ---------------------------------------------------------------------------------------------------- N > 1

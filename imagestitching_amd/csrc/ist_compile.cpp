@@ -316,6 +316,24 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
       }
     if (partial || minified) {
       cell.path = PATH_GENERAL;                   // fractional edge strip: per-pixel coverage; box-averaged draw: per-pixel footprint
+      // ONE axis-aligned shrinking draw over an opaque colour (or an opaque draw): the streamed box filter (tile_area_stream).
+      // LDS: 4 waves x one row of float4 column sums over the tile's x footprint; the widest tile that fits 48 KiB.
+      if (!partial && cell.stack_len == 1 && !knobs.no_lds) {
+        const DevOp& r = out->ops[cell.op];
+        if (!(r.flags & (OPF_SWAP | OPF_FILL | OPF_HOLE)) && (bg_opaque || (r.flags & OPF_OPAQUE)) && r.cx1 >= r.cx0 && r.cy1 >= r.cy0 &&
+            std::fabs(r.ky) <= 64.0) {
+          const double bwx = std::max(std::fabs(r.kx), 1.0);
+          for (int tw = 256; tw >= 64; tw >>= 1) {
+            const int64_t wl = (static_cast<int64_t>(std::ceil((tw - 1) * std::fabs(r.kx) + bwx)) + 2 + 3) & ~3LL;   // source pixels per LDS row (>= the kernel's)
+            const int64_t need = 4 * 4 * wl;                  // 32-bit words: 4 waves x float4 per source pixel
+            if (need > 12288) continue;                       // 48 KiB
+            cell.path = PATH_AREA_STREAM; cell.tile_w = tw; cell.tile_h = 16; cell.sub_h = 0;
+            out->lds_words = std::max<int32_t>(out->lds_words, static_cast<int32_t>(need));
+            if (!bg_opaque) cell.bg = 0xFFFFFFFFu;            // never used: the draw is opaque
+            break;
+          }
+        }
+      }
     } else if (cell.stack_len == 0) {
       cell.path = PATH_FILL;
       if (!bg_opaque) cell.bg = clear_back;       // reads back un-premultiplied
@@ -397,7 +415,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
         }
       }
     }
-    if (cell.path == PATH_SAMPLE_LDS || cell.path == PATH_SWAP_LDS || cell.path == PATH_SAMPLE_STREAM) {}
+    if (cell.path == PATH_SAMPLE_LDS || cell.path == PATH_SWAP_LDS || cell.path == PATH_SAMPLE_STREAM || cell.path == PATH_AREA_STREAM) {}
     else if (cell.path == PATH_GENERAL) { cell.tile_w = 64; cell.tile_h = 64; }
     else if (cell.path == PATH_SAMPLE) { cell.tile_w = 256; cell.tile_h = 32; }
     else { cell.tile_w = knobs.tile_w; cell.tile_h = knobs.tile_h; }   // FILL / COPY: tile_w = 256 << n
@@ -422,11 +440,11 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     cell.tile_begin = tiles;
     tiles += nt;
     info.out_pixels += w * h;
-    out->kernel_kind = std::max<int32_t>(out->kernel_kind, (cell.path == PATH_FILL || cell.path == PATH_COPY) ? 0 : (cell.path == PATH_SAMPLE || cell.path == PATH_SAMPLE_LDS || cell.path == PATH_SAMPLE_STREAM) ? 1 : 2);
+    out->kernel_kind = std::max<int32_t>(out->kernel_kind, (cell.path == PATH_FILL || cell.path == PATH_COPY) ? 0 : (cell.path == PATH_SAMPLE || cell.path == PATH_SAMPLE_LDS || cell.path == PATH_SAMPLE_STREAM || cell.path == PATH_AREA_STREAM) ? 1 : 2);
     switch (cell.path) {
       case PATH_FILL: info.tiles_fill += nt; break;
       case PATH_COPY: info.tiles_copy += nt; break;
-      case PATH_SAMPLE: case PATH_SAMPLE_LDS: case PATH_SAMPLE_STREAM: case PATH_SWAP_LDS: info.tiles_sample += nt; break;
+      case PATH_SAMPLE: case PATH_SAMPLE_LDS: case PATH_SAMPLE_STREAM: case PATH_SWAP_LDS: case PATH_AREA_STREAM: info.tiles_sample += nt; break;
       default: info.tiles_general += nt; break;
     }
     for (int k = 0; k < cell.stack_len; ++k) {

@@ -23,6 +23,13 @@ struct ist_ctx {
   void* scratch_png = nullptr; size_t scratch_png_bytes = 0;   // compressing PNG encoder: one slot per 16 KiB chunk + its tables
   void* scratch_file = nullptr; size_t scratch_file_bytes = 0; // device image of a PNG file on its way to the host
   void* scratch_arena = nullptr; size_t scratch_arena_bytes = 0; // file pipeline: bitmaps + JPEG planes + canvas + PNG of one call
+  // file pipeline (ist_stitch_files_png / ist_decode_files_device): one stream + event + Huffman scratch per image, so that
+  // the images' decode chains (upload -> Huffman passes -> reconstruction) overlap each other and the export of the bands
+  // that are already final; grow-only, made on first use
+  std::vector<hipStream_t> img_stream;
+  std::vector<hipEvent_t> img_event;
+  std::vector<void*> img_huff; std::vector<size_t> img_huff_bytes;
+  void* scratch_ent = nullptr; size_t scratch_ent_bytes = 0;   // sparse coefficient entries of host-decoded JPEGs (progressive, restart intervals)
   hipStream_t aux = nullptr;             // second stream of the host-path entry points (PNG slabs travel on it while later ones compress)
   // device blocks of destroyed jobs' tables, re-used by the next job of this context instead of a hipMalloc + hipFree pair
   // per job (a free also synchronises the device); at most kTablePool blocks are kept

@@ -3,6 +3,7 @@
 #define IST_INTERNAL_H_
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,7 @@ enum : int32_t {
   PATH_SAMPLE = 2,    // opaque constant under ONE axis-aligned draw, source x driven by canvas x
   PATH_SAMPLE_LDS = 4, // PATH_SAMPLE (bilinear, moderate scale) with the tile's source footprint staged in LDS
   PATH_SAMPLE_STREAM = 6, // PATH_SAMPLE (bilinear): every wave streams its own rows' source row pairs through a private LDS ring
+  PATH_AREA_STREAM = 7, // ONE axis-aligned draw that shrinks, IST_FILTER_AREA: box sums per output row, streamed (no barrier)
   PATH_SWAP_LDS = 5,   // ONE quarter-turned draw (EXIF 5-8), bilinear: footprint staged TRANSPOSED in LDS
   PATH_GENERAL = 3    // anything else: paint stack evaluated per pixel in canvas order (swap draws, overlaps,
                       // translucent canvas)
@@ -118,8 +120,12 @@ int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, 
 int64_t png_deflate_bound(int64_t w, int64_t h);
 // host_out (pinned, out_cap bytes) + aux stream, both optional: the file also lands in host memory, slab by slab, while
 // later slabs are still being compressed
+// need_rows (optional): called with y before work that reads canvas rows [0, y) is submitted to `stream` - a producer that
+// renders the canvas band by band submits the missing bands to `stream` there.  slab_rows_hint (optional): canvas rows a
+// slab should cover (the producer's band height), so that slab boundaries fall on band boundaries.
 int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* out, int64_t out_cap,
-                              int64_t* out_len, void* stream, uint8_t* host_out, void* aux);
+                              int64_t* out_len, void* stream, uint8_t* host_out, void* aux,
+                              const std::function<int(int64_t)>& need_rows = nullptr, int64_t slab_rows_hint = 0);
 int ctx_png_level(const ist_ctx* ctx);
 int ctx_png_scratch(ist_ctx* ctx, size_t need, void** p);   // the context's grow-only PNG scratch (kept across calls)
 

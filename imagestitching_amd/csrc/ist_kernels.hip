@@ -597,6 +597,138 @@ IST_DEV void tile_sample_stream(const LaunchArgs& A, const DevOp op, uint32_t bg
   }
 }
 
+// ------------------------------------------------------------------------------------------------ AREA, streamed
+// IST_FILTER_AREA on an axis-aligned draw that shrinks: the sample of a canvas pixel is the mean of the source over the
+// pixel's footprint, a box of max(1, |kx|) x max(1, |ky|) source pixels, every source pixel weighted by its overlap (at
+// |k| <= 1 the box is the bilinear pair).  Unlike point-sampled bilinear, this rule needs EVERY source byte, so the bytes
+// the memory system must move anyway (whole 32-byte sectors of the rows a shrink touches) are all useful work.
+// Separable, no workgroup barrier: a wave owns output rows Y0 + wave + 4 j.  For one output row it
+//   1. reads the <= ceil(|ky|) + 1 source rows of the row's box with coalesced 16-byte loads (lane = 4 neighbouring source
+//      pixels) and sums them in registers with the rows' overlap weights (fp32, premultiplied),
+//   2. writes the column sums (one float4 per source pixel) to its private LDS row,
+//   3. lane = canvas pixel: sums the <= ceil(|kx|) + 1 float4 of its box from LDS with the columns' overlap weights,
+//      normalises, composites over the background and stores 256 contiguous bytes per wave.
+// A wave's LDS operations execute in order, so the phases need no barrier; the x taps of a lane are the same for every
+// row of the tile and are computed once (fp64, as the oracle does).
+template <int NP, bool OPAQUE>
+IST_DEV void tile_area_stream(const LaunchArgs& A, const DevOp op, uint32_t bg, int X0, int Y0, int X1, int Y1, uint32_t* lds) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const double bw = fmax(fabs(op.kx), 1.0), bh = fmax(fabs(op.ky), 1.0);
+  // x footprint of the tile (wave-uniform): the boxes of its first and last column bound it
+  const double ca = op.kx * (static_cast<double>(X0) + 0.5) + op.ox, cb = op.kx * (static_cast<double>(X1 - 1) + 0.5) + op.ox;
+  const double fl = fmin(ca, cb) - 0.5 * bw, fh = fmax(ca, cb) + 0.5 * bw;
+  const int fx0 = __builtin_amdgcn_readfirstlane(static_cast<int>(fmin(fmax(floor(fl), -2.0e9), 2.0e9)));
+  const int fx1 = __builtin_amdgcn_readfirstlane(static_cast<int>(fmin(fmax(ceil(fh), -2.0e9), 2.0e9)) - 1);
+  const int wl = (fx1 - fx0 + 1 + 3) & ~3;                  // source pixels per LDS row
+  const int chunks = wl >> 2;
+  float* row = reinterpret_cast<float*>(lds) + static_cast<size_t>(wave) * (4 * wl);
+  const size_t sp = A.pitch[op.image];
+  const uint8_t* src = A.src[op.image];
+  // per lane, once per tile: the box of each of its canvas pixels on the x axis
+  int Xl = X0 + lane;
+  int tx0[NP], tn[NP]; float wf[NP], wb[NP];              // first tap (LDS index), taps, weight of the first / last tap
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const double sxc = op.kx * (static_cast<double>(min(Xl + 64 * p, X1 - 1)) + 0.5) + op.ox;
+    const double xlo = sxc - 0.5 * bw, xhi = sxc + 0.5 * bw;
+    const int ix0 = static_cast<int>(fmin(fmax(floor(xlo), -2.0e9), 2.0e9)), ix1 = static_cast<int>(fmin(fmax(ceil(xhi), -2.0e9), 2.0e9)) - 1;
+    tx0[p] = ix0 - fx0; tn[p] = ix1 - ix0 + 1;
+    wf[p] = static_cast<float>(fmin(static_cast<double>(ix0) + 1.0, xhi) - fmax(static_cast<double>(ix0), xlo));
+    wb[p] = static_cast<float>(fmin(static_cast<double>(ix1) + 1.0, xhi) - fmax(static_cast<double>(ix1), xlo));
+  }
+  const double norm = 1.0 / (bw * bh);
+  uint8_t* d = A.dst + static_cast<size_t>(Xl) * 4;
+  for (int Y = Y0 + wave; Y < Y1; Y += 4) {
+    // the rows of this output row's box (wave-uniform)
+    const double syc = op.ky * (static_cast<double>(Y) + 0.5) + op.oy;
+    const double ylo = syc - 0.5 * bh, yhi = syc + 0.5 * bh;
+    const int iy0 = static_cast<int>(fmin(fmax(floor(ylo), -2.0e9), 2.0e9)), iy1 = static_cast<int>(fmin(fmax(ceil(yhi), -2.0e9), 2.0e9)) - 1;
+    // 1 + 2: column sums of the box's rows -> LDS
+    for (int c0 = 0; c0 < chunks; c0 += 64) {
+      const int c = c0 + lane;
+      if (c < chunks) {
+        const int xx = fx0 + 4 * c;
+        const bool inside = xx >= op.cx0 && xx + 3 <= op.cx1;
+        float acc[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f; }
+        for (int yy = iy0; yy <= iy1; yy += 4) {
+          u32x4 v[4]; float w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int y = yy + u;
+            w[u] = y <= iy1 ? static_cast<float>(fmin(static_cast<double>(y) + 1.0, yhi) - fmax(static_cast<double>(y), ylo)) : 0.f;
+            const uint8_t* g = src + static_cast<size_t>(min(max(min(y, iy1), op.cy0), op.cy1)) * sp;
+            if (inside) v[u] = ld16(g + static_cast<size_t>(xx) * 4);
+            else {
+              v[u].x = ld4(g + static_cast<size_t>(min(max(xx, op.cx0), op.cx1)) * 4);
+              v[u].y = ld4(g + static_cast<size_t>(min(max(xx + 1, op.cx0), op.cx1)) * 4);
+              v[u].z = ld4(g + static_cast<size_t>(min(max(xx + 2, op.cx0), op.cx1)) * 4);
+              v[u].w = ld4(g + static_cast<size_t>(min(max(xx + 3, op.cx0), op.cx1)) * 4);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (w[u] <= 0.f) continue;                       // (wave-uniform)
+            const uint32_t px[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (OPAQUE) {
+                acc[q][0] += w[u] * static_cast<float>(ch(px[q], 0)); acc[q][1] += w[u] * static_cast<float>(ch(px[q], 1));
+                acc[q][2] += w[u] * static_cast<float>(ch(px[q], 2));
+              } else {
+                const float a = static_cast<float>(px[q] >> 24);
+                acc[q][0] += w[u] * (static_cast<float>(ch(px[q], 0)) * a); acc[q][1] += w[u] * (static_cast<float>(ch(px[q], 1)) * a);
+                acc[q][2] += w[u] * (static_cast<float>(ch(px[q], 2)) * a); acc[q][3] += w[u] * a;
+              }
+            }
+          }
+        }
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 t = {acc[q][0], acc[q][1], acc[q][2], acc[q][3]};
+          *reinterpret_cast<f32x4*>(row + 4 * (4 * c + q)) = t;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 3: the box of every canvas pixel along x, from LDS
+    uint8_t* dp = d + static_cast<size_t>(Y) * A.dst_pitch;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4* t = reinterpret_cast<const f32x4*>(row) + tx0[p];
+      f32x4 s = t[0] * wf[p];
+      const int nt = tn[p];
+      for (int k = 1; k < nt - 1; ++k) s += t[k];
+      if (nt > 1) s += t[nt - 1] * wb[p];
+      uint32_t o;
+      if (OPAQUE) {                                         // opaque source: the mean replaces the destination
+        const double r = static_cast<double>(s.x) * norm, g = static_cast<double>(s.y) * norm, b = static_cast<double>(s.z) * norm;
+        o = 0xFF000000u | static_cast<uint32_t>(fmin(fmax(floor(r + 0.5), 0.0), 255.0)) | (static_cast<uint32_t>(fmin(fmax(floor(g + 0.5), 0.0), 255.0)) << 8) |
+            (static_cast<uint32_t>(fmin(fmax(floor(b + 0.5), 0.0), 255.0)) << 16);
+      } else {                                              // the same operations as the per-pixel path (pixel_general) at coverage 1
+        const double Aa = static_cast<double>(s.w) * norm;
+        const double keep = 1.0 - Aa / 255.0;
+        const float accs[3] = {s.x, s.y, s.z};
+        o = 0;
+#pragma unroll
+        for (int c2 = 0; c2 < 3; ++c2) {
+          const double P = static_cast<double>(accs[c2]) * norm / 255.0;
+          const double v2 = floor(P + static_cast<double>(ch(bg, c2)) * keep + 0.5);
+          o |= static_cast<uint32_t>(fmin(fmax(v2, 0.0), 255.0)) << (8 * c2);
+        }
+        const double va = floor(Aa + static_cast<double>(bg >> 24) * keep + 0.5);
+        o |= static_cast<uint32_t>(fmin(fmax(va, 0.0), 255.0)) << 24;
+      }
+      if (Xl + 64 * p < X1) st4(dp + 256 * p, o);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ SWAP via LDS
 // One quarter-turned draw (EXIF 5-8: source x is driven by canvas Y, source y by canvas X), bilinear.  A 64 x th
 // canvas tile needs a (th*|kx|+2)-column x (64*|ky|+2)-row source patch.  The patch is read row by row with coalesced
@@ -878,6 +1010,12 @@ IST_DEV void run_tile(const LaunchArgs& A, int64_t tile, bool fresh) {
     if (c.tile_w == 256) tile_sample_stream<4>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
     else if (c.tile_w == 128) tile_sample_stream<2>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
     else tile_sample_stream<1>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
+  } else if ((PATHS & HAS_SAMPLE) && path == PATH_AREA_STREAM) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const bool opq = (op_.flags & OPF_OPAQUE) != 0;
+    if (c.tile_w == 256) { if (opq) tile_area_stream<4, true>(A, op_, c.bg, X0, Y0, X1, Y1, lds); else tile_area_stream<4, false>(A, op_, c.bg, X0, Y0, X1, Y1, lds); }
+    else if (c.tile_w == 128) { if (opq) tile_area_stream<2, true>(A, op_, c.bg, X0, Y0, X1, Y1, lds); else tile_area_stream<2, false>(A, op_, c.bg, X0, Y0, X1, Y1, lds); }
+    else { if (opq) tile_area_stream<1, true>(A, op_, c.bg, X0, Y0, X1, Y1, lds); else tile_area_stream<1, false>(A, op_, c.bg, X0, Y0, X1, Y1, lds); }
   } else if ((PATHS & HAS_SWAP) && path == PATH_SWAP_LDS) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     if (!tile_swap_lds(A, op_, c.bg, X0, Y0, X1, Y1, lds)) tile_general(A, c, X0, Y0, X1, Y1);

@@ -25,7 +25,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <vector>
 
@@ -475,7 +477,8 @@ int64_t png_deflate_bound(int64_t w, int64_t h) {
 // stream while later slabs are still being compressed on `stream` — the PNG's trip over PCIe (2.6 ms for the 146 MB of a
 // 439 MB photo canvas) then hides behind the encoder (3.3 ms) instead of following it.  Each slab is its own IDAT chunk.
 int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* out, int64_t out_cap,
-                              int64_t* out_len, void* stream_, uint8_t* host_out, void* aux_) {
+                              int64_t* out_len, void* stream_, uint8_t* host_out, void* aux_,
+                              const std::function<int(int64_t)>& need_rows, int64_t slab_rows_hint) {
   const ChunkGrid g = make_grid(w, h);
   if (g.n_chunks > 2147483647ll) return fail(IST_E_OUTPUT_SIZE, "image too large for one PNG launch");
   if (png_deflate_bound(w, h) > out_cap) return fail(IST_E_INVALID, "PNG output buffer too small (see ist_png_bound)");
@@ -494,9 +497,21 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
   auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
   // per-chunk results, five arrays interleaved per SLAB so that a slab's results are one contiguous copy:
   // [len16 | crc | ad_a | ad_b | ad_n] x slab
-  constexpr size_t kSlabChunks = 4096;               // 64 MiB of filtered stream per slab
-  const size_t n_slabs = host_out ? (n + kSlabChunks - 1) / kSlabChunks : 1;
-  const size_t per_slab = host_out ? kSlabChunks : n;
+  // 64 MiB of filtered stream per slab - or, when the producer renders the canvas band by band (need_rows), about one band
+  // (never less than a quarter of the default: a slab is a launch, a layout pass and a copy), so that slab k is complete
+  // when band k is and nothing of band k+1 is waited for
+  size_t slab_chunks = 4096;
+  if (slab_rows_hint > 0) {
+    const int64_t rows_chunks = g.pieces_per_row > 0 ? slab_rows_hint * g.pieces_per_row : (slab_rows_hint + g.rows_per_chunk - 1) / std::max(1, g.rows_per_chunk);
+    slab_chunks = static_cast<size_t>(std::min<int64_t>(4096, std::max<int64_t>(1024, rows_chunks)));
+  }
+  const size_t n_slabs = host_out ? (n + slab_chunks - 1) / slab_chunks : 1;
+  const size_t per_slab = host_out ? slab_chunks : n;
+  // the last canvas row (exclusive) chunks [0, c_end) read
+  auto rows_of = [&](size_t c_end) -> int64_t {
+    const int64_t r = g.pieces_per_row > 0 ? (static_cast<int64_t>(c_end) + g.pieces_per_row - 1) / g.pieces_per_row : static_cast<int64_t>(c_end) * g.rows_per_chunk;
+    return std::min<int64_t>(h, r);
+  };
   const size_t o_T = 0, o_pow = o_T + up(sizeof T), o_slots = o_pow + up(4 * xpow.size()), total_scratch = o_slots + n * SLOT;
   // the context's grow-only scratch: a 439 MB canvas needs 443 MB of slots, and allocating + freeing that per call cost
   // more than the gather kernel (and a free synchronises the device)
@@ -539,6 +554,8 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
   static const long fail_at = (tuning_mode() && std::getenv("IST_PNG_FAIL_AT")) ? std::atol(std::getenv("IST_PNG_FAIL_AT")) : -1;
   auto compress = [&](size_t s) -> int {
     const size_t c0 = s * per_slab, cn = std::min(per_slab, n - c0);
+    // (the Paeth filter of a chunk's first row reads the row above it: that row belongs to an earlier slab, already asked for)
+    if (need_rows) { const int rc = need_rows(rows_of(c0 + cn)); if (rc) return rc; }
     // the kernel writes its per-chunk results straight into the pinned host block (visible to the host behind the event).
     // As small device-to-host COPIES on this stream they shared the copy engine's queue with the slabs' big copies on the
     // aux stream: each big copy then took 0.9 ms instead of 0.4 and the PNG phase 6.8 ms instead of 3.4 (measured)

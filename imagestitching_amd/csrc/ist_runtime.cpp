@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -87,7 +88,8 @@ int ensure_aux(ist_ctx* ctx) {
 // at least ist_png_bound bytes (nullptr: the context's own).  The compressing encoder hands the file over slab by slab
 // while it is still compressing (png_encode_device_deflate); the stored form is encoded whole and copied once.
 // Caller holds ctx->mu.  Synchronises ctx->stream.
-int png_to_host(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* dfile, uint8_t** out_png, int64_t* out_len) {
+int png_to_host(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* dfile, uint8_t** out_png, int64_t* out_len,
+                const std::function<int(int64_t)>& need_rows = nullptr, int64_t slab_rows_hint = 0) {
   const int64_t cap = ist_png_bound(w, h);
   if (!dfile) {
     const int rc = grow_device(&ctx->scratch_file, &ctx->scratch_file_bytes, static_cast<size_t>(cap));
@@ -99,12 +101,14 @@ int png_to_host(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64
     { const int rc = ensure_aux(ctx); if (rc) return rc; }
     uint8_t* host = static_cast<uint8_t*>(pool_take(static_cast<size_t>(cap)));
     if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
-    const int rc = png_encode_device_deflate(ctx, canvas, pitch, w, h, dfile, cap, &len, ctx->stream, host, ctx->aux);
+    const int rc = png_encode_device_deflate(ctx, canvas, pitch, w, h, dfile, cap, &len, ctx->stream, host, ctx->aux, need_rows, slab_rows_hint);
     if (rc) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamSynchronize(ctx->stream); pool_give(host); return rc; }
     *out_png = host; *out_len = len;
     return IST_OK;
   }
-  int rc = ist_png_encode_device(ctx, canvas, pitch, w, h, dfile, cap, &len, ctx->stream);
+  int rc = need_rows ? need_rows(h) : IST_OK;            // (the stored form reads the whole canvas in one pass)
+  if (rc) return rc;
+  rc = ist_png_encode_device(ctx, canvas, pitch, w, h, dfile, cap, &len, ctx->stream);
   if (rc) return rc;
   uint8_t* host = nullptr;
   rc = read_back_pooled(dfile, static_cast<size_t>(len), ctx->stream, &host);
@@ -169,6 +173,10 @@ void ist_ctx_destroy(ist_ctx* ctx) {
   dev_free(ctx->scratch_png);
   dev_free(ctx->scratch_file);
   dev_free(ctx->scratch_arena);
+  dev_free(ctx->scratch_ent);
+  for (hipStream_t st : ctx->img_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  for (hipEvent_t ev : ctx->img_event) if (ev) (void)hipEventDestroy(ev);
+  for (void* q : ctx->img_huff) dev_free(q);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
   for (const ist_ctx::TableBlock& b : ctx->table_pool) dev_free(b.p);
   ctx->stager.reset();
@@ -423,9 +431,11 @@ int ist_stitch_png(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* co
 // ---- JPEG decode: entropy decoding on the host, reconstruction on the GPU (ist_jpeg.cpp / ist_jpeg_kernels.hip) ----------
 extern "C++" {
 namespace {
+// where one image's JPEG stages live on the device: offsets into TWO arenas - `main` (coefficient planes, quantisation
+// tables, sample planes: sized from the frame header alone, so it can be laid out before any file is entropy-decoded) and
+// `ent` (the sparse entries of a host-decoded sequential file: sized by the decode)
 struct JpegDevLayout { size_t coef[3], q[3], plane[3], ent[3], start[3], cnt[3]; };
 
-// device bytes one decoded image needs, carved from the caller's arena at *off (256-byte granules)
 void jpeg_layout(const JpegImage& J, size_t* off, JpegDevLayout* L) {
   auto take = [&](size_t bytes) { const size_t at = *off; *off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
   std::memset(L, 0, sizeof(*L));
@@ -435,12 +445,21 @@ void jpeg_layout(const JpegImage& J, size_t* off, JpegDevLayout* L) {
     L->coef[c] = take(nblk * 128);
     L->q[c] = take(128);
     L->plane[c] = take(nblk * 64);
-    if (C.sparse) { L->ent[c] = take(C.ent.size() * 4 + 4); L->start[c] = take(nblk * 4); L->cnt[c] = take(nblk); }
+  }
+}
+// the `ent` arena part of a host-decoded image (components in sparse form)
+void jpeg_layout_sparse(const JpegImage& J, size_t* off, JpegDevLayout* L) {
+  auto take = [&](size_t bytes) { const size_t at = *off; *off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
+  for (int c = 0; c < J.ncomp; ++c) {
+    const JpegComp& C = J.comp[c];
+    if (!C.sparse) continue;
+    const size_t nblk = static_cast<size_t>(C.blocks_x) * C.blocks_y;
+    L->ent[c] = take(C.ent.size() * 4 + 4); L->start[c] = take(nblk * 4); L->cnt[c] = take(nblk);
   }
 }
 
 // H2D of the coefficients (sparse entries are scattered into a zeroed plane on the GPU) + the reconstruction launches
-int jpeg_enqueue(const JpegImage& J, uint8_t* d, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch, hipStream_t stream, bool coef_on_device = false) {
+int jpeg_enqueue(const JpegImage& J, uint8_t* d, uint8_t* d_ent, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch, hipStream_t stream, bool coef_on_device = false) {
   JpegDeviceJob job;
   job.width = J.width; job.height = J.height; job.ncomp = J.ncomp; job.hmax = J.hmax; job.vmax = J.vmax;
   for (int c = 0; c < 3; ++c) { job.d_coef[c] = nullptr; job.d_q[c] = nullptr; job.d_plane[c] = nullptr; job.h[c] = job.v[c] = 1; job.blocks_x[c] = job.blocks_y[c] = 0; }
@@ -452,10 +471,11 @@ int jpeg_enqueue(const JpegImage& J, uint8_t* d, const JpegDevLayout& L, uint8_t
       // the GPU entropy decoder already filled the plane
     } else if (C.sparse) {
       IST_HIP(hipMemsetAsync(d_coef, 0, nblk * 128, stream));
-      if (!C.ent.empty()) IST_HIP(hipMemcpyAsync(d + L.ent[c], C.ent.data(), C.ent.size() * 4, hipMemcpyHostToDevice, stream));
-      IST_HIP(hipMemcpyAsync(d + L.start[c], C.start.data(), nblk * 4, hipMemcpyHostToDevice, stream));
-      IST_HIP(hipMemcpyAsync(d + L.cnt[c], C.cnt.data(), nblk, hipMemcpyHostToDevice, stream));
-      const int rc = jpeg_launch_scatter(reinterpret_cast<const uint32_t*>(d + L.ent[c]), reinterpret_cast<const uint32_t*>(d + L.start[c]), d + L.cnt[c], d_coef, static_cast<int>(nblk), stream);
+      if (!d_ent) return fail(IST_E_INVALID, "JPEG sparse coefficients without a device arena");
+      if (!C.ent.empty()) IST_HIP(hipMemcpyAsync(d_ent + L.ent[c], C.ent.data(), C.ent.size() * 4, hipMemcpyHostToDevice, stream));
+      IST_HIP(hipMemcpyAsync(d_ent + L.start[c], C.start.data(), nblk * 4, hipMemcpyHostToDevice, stream));
+      IST_HIP(hipMemcpyAsync(d_ent + L.cnt[c], C.cnt.data(), nblk, hipMemcpyHostToDevice, stream));
+      const int rc = jpeg_launch_scatter(reinterpret_cast<const uint32_t*>(d_ent + L.ent[c]), reinterpret_cast<const uint32_t*>(d_ent + L.start[c]), d_ent + L.cnt[c], d_coef, static_cast<int>(nblk), stream);
       if (rc) return rc;
     } else {
       if (C.coef.size() != nblk * 64) return fail(IST_E_DECODE, "JPEG component without coefficients");
@@ -496,13 +516,14 @@ int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
   JpegDevLayout L;
   jpeg_layout(J, &off, &L);
+  jpeg_layout_sparse(J, &off, &L);                      // (one arena holds both parts here)
   const size_t row = static_cast<size_t>(J.width) * 4;
   const size_t o_out = take(row * J.height);
   uint8_t* d = nullptr;
   rc = grow_device(&ctx->scratch_arena, &ctx->scratch_arena_bytes, off);
   if (rc) return rc;
   d = static_cast<uint8_t*>(ctx->scratch_arena);
-  rc = jpeg_enqueue(J, d, L, d + o_out, row, ctx->stream);
+  rc = jpeg_enqueue(J, d, d, L, d + o_out, row, ctx->stream);
   if (rc) return rc;
   std::vector<RowsCopy> down{RowsCopy{d + o_out, nullptr, out, out_pitch, row, static_cast<size_t>(J.height)}};
   rc = stager_of(ctx).download(down, ctx->stream);
@@ -532,11 +553,17 @@ int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8
 }
 
 // ---- files -> bitmaps in HBM: the decode stage shared by ist_stitch_files_png and ist_decode_files_device ------------
+// PIPELINED PER IMAGE (index.js:1441-1520 decodes image after image; :1559-1571 flushes and releases each one).  Every
+// image has a host thread and a device stream of its own: container parse + de-stuffing on the thread, then - baseline
+// JPEG - upload of the scan, the Huffman passes and the reconstruction on its stream, and an event when its bitmap is
+// complete.  The images' chains overlap each other, and (ist_stitch_files_png) the export of the canvas rows that are
+// already final: a vertical strip's band k is final once image k is decoded.  Files the GPU entropy decoder does not take
+// (progressive, restart intervals, PNG / BMP / GIF / WebP) are decoded on their thread and uploaded when the consumer
+// asks for the image.  With phase timing on, the same steps run with a barrier between them (parse all, entropy all,
+// reconstruct all), so that the phase clock means what it says.
 extern "C++" {
 namespace {
 
-// one input file after the host stage: container parsed; for JPEG either the de-stuffed scan (GPU Huffman) or the
-// coefficients (host Huffman); for PNG / BMP / GIF the decoded pixels
 struct Dec { int rc = 0; std::string err; bool jpeg = false; JpegImage J; JpegGpuScan G; int w = 0, h = 0, orient = 0; std::vector<uint8_t> px; };
 
 // phase clock: stderr lines under IST_TIMING=1, numbers for ist_ctx_last_timing when the context asked for them.  Phases
@@ -561,99 +588,230 @@ struct Phases {
   }
 };
 
-// 1. host side of decoding, one thread per image (index.js:1441-1520: the serial part of what the platform decoder does)
-int decode_host_stage(const uint8_t* const* files, const int64_t* lens, int n, std::vector<Dec>* out) {
-  // baseline JPEGs: Huffman decoding on the GPU (ist_jpeg_gpu.hip); IST_JPEG_HOST_HUFFMAN=1 keeps it on the host threads
-  static const bool gpu_huffman = std::getenv("IST_JPEG_HOST_HUFFMAN") == nullptr;
-  std::vector<Dec>& dec = *out;
-  dec.clear(); dec.resize(static_cast<size_t>(n));
-  {
-    std::vector<std::thread> th;
-    for (int i = 0; i < n; ++i) th.emplace_back([&, i]() {
-      Dec& D = dec[static_cast<size_t>(i)];
-      const uint8_t* f = files[i]; const int64_t len = lens[i];
-      D.jpeg = f && len >= 2 && f[0] == 0xFF && f[1] == 0xD8;
-      if (D.jpeg) {
-        D.rc = jpeg_parse_and_entropy_decode(f, len, &D.J, false, gpu_huffman ? &D.G : nullptr);
-        D.w = D.J.width; D.h = D.J.height; D.orient = D.J.orientation;
-      } else {                 // PNG, BMP, GIF: host decoders
-        int32_t w = 0, h = 0, o = 0;
-        D.rc = ist_image_info(f, len, &w, &h, &o);
-        D.orient = o;                                     // WebP carries EXIF in its container
-        if (D.rc == IST_OK) { D.w = w; D.h = h; D.px.resize(static_cast<size_t>(w) * h * 4); D.rc = ist_image_decode_rgba8(nullptr, f, len, D.px.data(), static_cast<size_t>(w) * 4, h); }
-      }
-      if (D.rc != IST_OK) D.err = g_last_error;        // thread-local in the worker: carry it out
-    });
-    for (auto& t : th) t.join();
+constexpr int kImgStreams = 8;           // image i runs on stream i mod kImgStreams
+
+int ensure_image_lanes(ist_ctx* ctx, int n) {
+  const size_t want = static_cast<size_t>(std::min(n, kImgStreams));
+  while (ctx->img_stream.size() < want) {
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipStreamCreate failed"); }
+    ctx->img_stream.push_back(st);
   }
-  for (int i = 0; i < n; ++i)
-    if (dec[static_cast<size_t>(i)].rc != IST_OK)
-      return fail(dec[static_cast<size_t>(i)].rc, "图片" + std::to_string(i) + "解码异常: " + dec[static_cast<size_t>(i)].err);   // index.js:1512-1514
+  while (ctx->img_event.size() < static_cast<size_t>(n)) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipEventCreate failed"); }
+    ctx->img_event.push_back(ev);
+  }
+  if (ctx->img_huff.size() < static_cast<size_t>(n)) { ctx->img_huff.resize(static_cast<size_t>(n), nullptr); ctx->img_huff_bytes.resize(static_cast<size_t>(n), 0); }
   return IST_OK;
 }
 
-// device bytes the JPEG stages of the images need (coefficient planes, tables, sample planes), carved from *off
-void decode_layout(const std::vector<Dec>& dec, size_t* off, std::vector<JpegDevLayout>* jo) {
-  jo->assign(dec.size(), JpegDevLayout());
-  for (size_t i = 0; i < dec.size(); ++i) if (dec[i].jpeg) jpeg_layout(dec[i].J, off, &(*jo)[i]);
-}
+// One call's decode work.  Lifetime: construct -> headers() -> (caller lays out its arena) -> start() -> take(i) for every
+// image the caller consumes, in any order -> finish().  The destructor joins whatever still runs.
+class FileDecoder {
+ public:
+  FileDecoder(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n, Phases* ph)
+      : ctx_(ctx), files_(files), lens_(lens), n_(n), ph_(ph), dec_(static_cast<size_t>(n)), th_(static_cast<size_t>(n)),
+        on_gpu_(static_cast<size_t>(n), 0), taken_(static_cast<size_t>(n), 0), jo_(static_cast<size_t>(n)), huff_ok_(static_cast<size_t>(n), 0) {}
+  ~FileDecoder() { join_all(); for (int i = 0; i < n_; ++i) if (on_gpu_[static_cast<size_t>(i)]) (void)hipStreamSynchronize(stream_of(i)); }
 
-// 2. device side: entropy decoding of the eligible JPEGs on the GPU (an image that fails its validation goes back to the
-// host decoder), reconstruction of every JPEG into img[i] (pitch[i]), upload of the host-decoded bitmaps.  Everything is
-// enqueued on ctx->stream; `d` is the arena decode_layout was sized for.
-int decode_device_stage(ist_ctx* ctx, std::vector<Dec>& dec, const uint8_t* const* files, const int64_t* lens, uint8_t* d,
-                        const std::vector<JpegDevLayout>& jo, uint8_t* const* img, const size_t* pitch, Phases* ph) {
-  const int n = static_cast<int>(dec.size());
-  int rc;
-  {
-    std::vector<JpegGpuItem> items; std::vector<int> who;
-    for (int i = 0; i < n; ++i) {
-      Dec& D = dec[static_cast<size_t>(i)];
-      if (!D.jpeg || !D.G.eligible) continue;
-      JpegGpuItem it; it.J = &D.J; it.S = &D.G;
-      for (int c = 0; c < 3; ++c) it.d_coef[c] = c < D.J.ncomp ? reinterpret_cast<int16_t*>(d + jo[static_cast<size_t>(i)].coef[c]) : nullptr;
-      items.push_back(it); who.push_back(i);
+  // 1. frame headers only (microseconds per file): sizes, sampling, EXIF orientation - what the planner and the arena need
+  int headers() {
+    static const bool gpu_huffman = std::getenv("IST_JPEG_HOST_HUFFMAN") == nullptr;
+    gpu_huffman_ = gpu_huffman;
+    for (int i = 0; i < n_; ++i) {
+      Dec& D = dec_[static_cast<size_t>(i)];
+      const uint8_t* f = files_[i]; const int64_t len = lens_[i];
+      D.jpeg = f && len >= 2 && f[0] == 0xFF && f[1] == 0xD8;
+      int rc;
+      if (D.jpeg) {
+        rc = jpeg_parse_and_entropy_decode(f, len, &D.J, true);
+        D.w = D.J.width; D.h = D.J.height; D.orient = D.J.orientation;
+      } else {
+        int32_t w = 0, h = 0, o = 0;
+        rc = ist_image_info(f, len, &w, &h, &o);
+        D.w = w; D.h = h; D.orient = o;                    // WebP carries EXIF in its container
+      }
+      if (rc != IST_OK) return fail(rc, "图片" + std::to_string(i) + "解码异常: " + g_last_error);   // index.js:1512-1514
     }
-    std::vector<uint8_t> okv;
-    rc = jpeg_gpu_entropy_decode(items, &okv, ctx->stream, &ctx->scratch_huff, &ctx->scratch_huff_bytes);
+    return IST_OK;
+  }
+  const Dec& dec(int i) const { return dec_[static_cast<size_t>(i)]; }
+  // device bytes of the JPEG stages (coefficient planes, tables, sample planes), carved from *off of the caller's arena
+  void layout(size_t* off) { for (int i = 0; i < n_; ++i) if (dec_[static_cast<size_t>(i)].jpeg) jpeg_layout(dec_[static_cast<size_t>(i)].J, off, &jo_[static_cast<size_t>(i)]); }
+
+  // 2. the workers.  arena: what layout() was sized for; img[i] / pitch[i]: where bitmap i goes (device memory)
+  int start(uint8_t* arena, uint8_t* const* img, const size_t* pitch) {
+    arena_ = arena; img_ = img; pitch_ = pitch;
+    int rc = ensure_image_lanes(ctx_, n_);
     if (rc) return rc;
-    for (size_t k = 0; k < who.size(); ++k) {
-      if (okv[k]) continue;
-      Dec& D = dec[static_cast<size_t>(who[k])];
+    serial_ = ph_->on;
+    if (!serial_) {
+      for (int i = 0; i < n_; ++i) th_[static_cast<size_t>(i)] = std::thread([this, i]() { worker(i, 0, 3); });
+      return IST_OK;
+    }
+    // phase timing: the same three steps with a barrier between them
+    run_step(0); rc = first_error(); if (rc) return rc;
+    ph_->lap(IST_PHASE_HOST_DECODE, "decode on host threads", nullptr);
+    run_step(1);
+    for (int i = 0; i < n_; ++i) (void)hipStreamSynchronize(stream_of(i));
+    ph_->lap(IST_PHASE_ENTROPY_GPU, "entropy decode (GPU)", nullptr);
+    run_step(2);
+    for (int i = 0; i < n_; ++i) { rc = take(i, ctx_->stream); if (rc) return rc; }
+    ph_->lap(IST_PHASE_RECONSTRUCT, "H2D + JPEG reconstruct (GPU)", ctx_->stream);
+    return IST_OK;
+  }
+
+  // 3. bitmap i is needed by work that will be submitted to `consumer` next: waits for the image's HOST side, then either
+  // orders `consumer` behind the image's device chain, or - a file the GPU path did not take - uploads / reconstructs it on
+  // `consumer` now.  Idempotent.
+  int take(int i, hipStream_t consumer) {
+    const size_t k = static_cast<size_t>(i);
+    if (taken_[k]) return IST_OK;
+    if (th_[k].joinable()) th_[k].join();
+    Dec& D = dec_[k];
+    if (D.rc != IST_OK) return fail(D.rc, "图片" + std::to_string(i) + "解码异常: " + D.err);          // index.js:1512-1514
+    taken_[k] = 1;
+    if (on_gpu_[k]) {
+      if (hipStreamWaitEvent(consumer, ctx_->img_event[k], 0) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipStreamWaitEvent failed"); }
+      return IST_OK;
+    }
+    const size_t row = static_cast<size_t>(D.w) * 4;
+    if (!D.jpeg) {                                  // PNG / BMP / GIF / WebP: decoded on the thread, uploaded here
+      std::vector<RowsCopy> up;
+      if (pitch_[i] != row) for (int y = 0; y < D.h; ++y) up.push_back(RowsCopy{img_[i] + static_cast<size_t>(y) * pitch_[i], D.px.data() + static_cast<size_t>(y) * row, nullptr, row, row, 1});
+      else up.push_back(RowsCopy{img_[i], D.px.data(), nullptr, row, row, static_cast<size_t>(D.h)});
+      return stager_of(ctx_).upload(up, consumer);
+    }
+    // a JPEG whose coefficients are on the host (progressive, restart intervals, non-interleaved scans, or a file that
+    // failed the GPU decoder's validation and was decoded again by the host decoder)
+    if (D.G.eligible) {
       D.G.eligible = false;
       JpegImage host;
-      rc = jpeg_parse_and_entropy_decode(files[who[k]], lens[who[k]], &host, false, nullptr);
-      if (rc) return fail(rc, "图片" + std::to_string(who[k]) + "解码异常: " + g_last_error);
-      // the arena has no room for sparse entries of this image: upload the dense planes
-      for (int c = 0; c < host.ncomp; ++c) {
-        const std::vector<int16_t> dense = jpeg_dense_coefficients(host.comp[c]);
-        IST_HIP(hipMemcpy(d + jo[static_cast<size_t>(who[k])].coef[c], dense.data(), dense.size() * 2, hipMemcpyHostToDevice));
+      const int rc = jpeg_parse_and_entropy_decode(files_[i], lens_[i], &host, false, nullptr);
+      if (rc) return fail(rc, "图片" + std::to_string(i) + "解码异常: " + g_last_error);
+      D.J = std::move(host);
+    }
+    size_t need = 0;
+    JpegDevLayout L = jo_[k];
+    jpeg_layout_sparse(D.J, &need, &L);
+    if (need > ctx_->scratch_ent_bytes) {             // (an earlier image's scatter may still read the old block)
+      (void)hipStreamSynchronize(consumer);
+      const int rc = grow_device(&ctx_->scratch_ent, &ctx_->scratch_ent_bytes, need + need / 2);
+      if (rc) return rc;
+    } else if (need) (void)hipStreamSynchronize(consumer);   // one block serves the images in turn
+    return jpeg_enqueue(D.J, arena_, static_cast<uint8_t*>(ctx_->scratch_ent), L, img_[i], pitch_[i], consumer, false);
+  }
+
+  // every worker has returned and (GPU path) every image's chain has been waited for by `consumer`
+  int finish(hipStream_t consumer) {
+    for (int i = 0; i < n_; ++i) { const int rc = take(i, consumer); if (rc) { join_all(); return rc; } }
+    return IST_OK;
+  }
+  int gpu_decoded() const { int g = 0; for (char v : on_gpu_) g += v ? 1 : 0; return g; }
+
+ private:
+  hipStream_t stream_of(int i) const { return ctx_->img_stream[static_cast<size_t>(i % kImgStreams) % ctx_->img_stream.size()]; }
+  void join_all() { for (std::thread& t : th_) if (t.joinable()) t.join(); }
+  int first_error() {
+    for (int i = 0; i < n_; ++i) if (dec_[static_cast<size_t>(i)].rc != IST_OK) return fail(dec_[static_cast<size_t>(i)].rc, "图片" + std::to_string(i) + "解码异常: " + dec_[static_cast<size_t>(i)].err);
+    return IST_OK;
+  }
+  void run_step(int step) {
+    for (int i = 0; i < n_; ++i) th_[static_cast<size_t>(i)] = std::thread([this, i, step]() { worker(i, step, step + 1); });
+    join_all();
+  }
+  // steps [from, to): 0 = container + host entropy stage, 1 = GPU Huffman, 2 = reconstruction + the image's event
+  void worker(int i, int from, int to) {
+    const size_t k = static_cast<size_t>(i);
+    Dec& D = dec_[k];
+    DeviceGuard dg(ctx_->device);
+    const uint8_t* f = files_[i]; const int64_t len = lens_[i];
+    auto failed = [&](int rc) { D.rc = rc; D.err = g_last_error; };     // (thread-local message: carry it out)
+    if (from <= 0 && to > 0) {
+      if (D.jpeg) {
+        JpegImage full;
+        const int rc = jpeg_parse_and_entropy_decode(f, len, &full, false, gpu_huffman_ ? &D.G : nullptr);
+        if (rc) { failed(rc); return; }
+        if (full.width != D.w || full.height != D.h || full.ncomp != D.J.ncomp) { g_last_error = "JPEG frame header changed between two reads"; failed(IST_E_DECODE); return; }
+        D.J = std::move(full);
+      } else {
+        D.px.resize(static_cast<size_t>(D.w) * D.h * 4);
+        const int rc = ist_image_decode_rgba8(nullptr, f, len, D.px.data(), static_cast<size_t>(D.w) * 4, D.h);
+        if (rc) { failed(rc); return; }
       }
-      D.G.eligible = true;          // (the planes are on the device now: enqueue skips the upload)
     }
-    if (ph->print) {
-      int good = 0;
-      for (uint8_t v : okv) good += v ? 1 : 0;
-      std::fprintf(stderr, "[ist timing] GPU Huffman: %d of %zu eligible JPEGs decoded on the GPU, %zu went back to the host decoder\n", good, okv.size(), okv.size() - static_cast<size_t>(good));
+    if (D.rc != IST_OK || !D.jpeg || !D.G.eligible) return;
+    hipStream_t st = stream_of(i);
+    if (from <= 1 && to > 1) {
+      JpegGpuItem it; it.J = &D.J; it.S = &D.G;
+      for (int c = 0; c < 3; ++c) it.d_coef[c] = c < D.J.ncomp ? reinterpret_cast<int16_t*>(arena_ + jo_[k].coef[c]) : nullptr;
+      std::vector<uint8_t> okv;
+      const int rc = jpeg_gpu_entropy_decode(std::vector<JpegGpuItem>{it}, &okv, st, &ctx_->img_huff[k], &ctx_->img_huff_bytes[k]);
+      if (rc) { failed(rc); return; }
+      huff_ok_[k] = !okv.empty() && okv[0];
+      if (!huff_ok_[k]) return;                       // take() decodes it on the host
     }
-    ph->lap(IST_PHASE_ENTROPY_GPU, "entropy decode (GPU)", ctx->stream);
+    if (from <= 2 && to > 2 && huff_ok_[k]) {
+      const int rc = jpeg_enqueue(D.J, arena_, nullptr, jo_[k], img_[i], pitch_[i], st, true);
+      if (rc) { failed(rc); return; }
+      if (hipEventRecord(ctx_->img_event[k], st) != hipSuccess) { (void)hipGetLastError(); g_last_error = "hipEventRecord failed"; failed(IST_E_HIP); return; }
+      on_gpu_[k] = 1;
+    }
   }
-  std::vector<RowsCopy> host_px;                  // PNG / BMP / GIF bitmaps decoded on the host
-  for (int i = 0; i < n; ++i) {
-    const Dec& D = dec[static_cast<size_t>(i)];
-    const size_t row = static_cast<size_t>(D.w) * 4;
-    if (!D.jpeg) {
-      if (pitch[i] != row) {                      // the staged copies land on contiguous device rows: copy row by row
-        for (int y = 0; y < D.h; ++y) host_px.push_back(RowsCopy{img[i] + static_cast<size_t>(y) * pitch[i], D.px.data() + static_cast<size_t>(y) * row, nullptr, row, row, 1});
-      } else host_px.push_back(RowsCopy{img[i], D.px.data(), nullptr, row, row, static_cast<size_t>(D.h)});
-      continue;
-    }
-    rc = jpeg_enqueue(D.J, d, jo[static_cast<size_t>(i)], img[i], pitch[i], ctx->stream, D.G.eligible);
-    if (rc) return rc;
+
+  ist_ctx* ctx_; const uint8_t* const* files_; const int64_t* lens_; int n_; Phases* ph_;
+  std::vector<Dec> dec_;
+  std::vector<std::thread> th_;
+  std::vector<char> on_gpu_, taken_;
+  std::vector<JpegDevLayout> jo_;
+  std::vector<char> huff_ok_;
+  uint8_t* arena_ = nullptr; uint8_t* const* img_ = nullptr; const size_t* pitch_ = nullptr;
+  bool serial_ = false, gpu_huffman_ = true;
+};
+
+// One stitch cut into a background launch + one launch per draw (the same cut the device group uses, ist_shard_parts with a
+// slot per image): band k can be rendered - and exported - as soon as image k is decoded.  ok = false when the draws overlap
+// (or there is nothing to cut): the caller then renders the canvas with ONE launch once every image is there.
+struct BandedJobs {
+  bool ok = false;
+  ist_job* bg = nullptr;
+  std::vector<ist_job*> band;            // per part
+  std::vector<ist_part> parts;           // sorted by Y0
+  ~BandedJobs() { if (bg) ist_job_destroy(bg); for (ist_job* j : band) if (j) ist_job_destroy(j); }
+};
+
+int compile_banded(ist_ctx* ctx, int64_t cw, int64_t ch, const uint8_t clear[4], const ist_op* ops, int n_ops, const ist_image_desc* images,
+                   int n_images, int filter, BandedJobs* out) {
+  std::vector<ist_part> cut(static_cast<size_t>(n_ops) + 8);
+  int n_parts = 0;
+  if (ist_shard_parts(ops, n_ops, cw, ch, images, n_images, filter, std::max(1, n_images), IST_SPLIT_IMAGE, cut.data(), static_cast<int>(cut.size()), &n_parts) != IST_OK || n_parts < 2)
+    return IST_OK;                       // overlapping draws (or a single image): not banded, not an error
+  cut.resize(static_cast<size_t>(n_parts));
+  std::stable_sort(cut.begin(), cut.end(), [](const ist_part& a, const ist_part& b) { return a.Y0 < b.Y0; });
+  std::vector<ist_op> bg_ops;
+  int fill_at = -1;
+  for (int k = 0; k < n_ops; ++k) { if (ops[k].kind != IST_OP_DRAW) bg_ops.push_back(ops[k]); if (fill_at < 0 && ops[k].kind == IST_OP_FILL) fill_at = k; }
+  for (const ist_part& p : cut) {
+    ist_op hole;
+    std::memset(&hole, 0, sizeof hole);
+    hole.kind = IST_OP_HOLE; hole.image = -1; hole.m[0] = 1.0; hole.m[3] = 1.0;
+    hole.d[0] = p.X0; hole.d[1] = p.Y0; hole.d[2] = p.X1 - p.X0; hole.d[3] = p.Y1 - p.Y0;
+    bg_ops.push_back(hole);
   }
-  rc = stager_of(ctx).upload(host_px, ctx->stream);
-  if (rc) return rc;
-  ph->lap(IST_PHASE_RECONSTRUCT, "H2D + JPEG reconstruct (GPU)", ctx->stream);
+  out->bg = ist_job_create(ctx, cw, ch, clear, bg_ops.data(), static_cast<int>(bg_ops.size()), images, n_images, filter, nullptr);
+  if (!out->bg) return g_last_code ? g_last_code : IST_E_INVALID;
+  for (const ist_part& p : cut) {
+    ist_op two[2]; int n2 = 0;
+    if (fill_at >= 0 && fill_at < p.op) two[n2++] = ops[fill_at];
+    two[n2++] = ops[p.op];
+    const ist_region clip{p.X0, p.Y0, p.X1 - p.X0, p.Y1 - p.Y0};
+    ist_job* j = ist_job_create(ctx, cw, ch, clear, two, n2, images, n_images, filter, &clip);
+    if (!j) return g_last_code ? g_last_code : IST_E_INVALID;
+    out->band.push_back(j);
+  }
+  out->parts = cut;
+  out->ok = true;
   return IST_OK;
 }
 
@@ -678,16 +836,16 @@ int ist_decode_files_device(ist_ctx* ctx, const uint8_t* const* files, const int
   if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
   if (n_images <= 0) return IST_NOTHING_TO_DO;
   if (!files || !lens || !dst || !dst_pitch || !dst_rows) return fail(IST_E_INVALID, "ist_decode_files_device: NULL argument");
-  std::vector<Dec> dec;
+  if (n_images > kMaxImages) return fail(IST_E_UNSUPPORTED, "more than 128 images in one call");
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   Phases ph(ctx);
-  int rc = decode_host_stage(files, lens, n_images, &dec);
+  FileDecoder fd(ctx, files, lens, n_images, &ph);
+  int rc = fd.headers();
   if (rc) return rc;
-  ph.lap(IST_PHASE_HOST_DECODE, "decode on host threads", nullptr);
   std::vector<uint8_t*> img(static_cast<size_t>(n_images));
   for (int i = 0; i < n_images; ++i) {
-    const Dec& D = dec[static_cast<size_t>(i)];
+    const Dec& D = fd.dec(i);
     // the file's own header is untrusted: the caller states what its buffer holds
     if (!dst[i] || dst_pitch[i] < static_cast<size_t>(D.w) * 4 || (dst_pitch[i] & 3) || dst_rows[i] < D.h || (reinterpret_cast<uintptr_t>(dst[i]) & 3))
       return fail(IST_E_INVALID, "ist_decode_files_device: the buffer of image " + std::to_string(i) + " is too small for " + std::to_string(D.w) + "x" + std::to_string(D.h));
@@ -699,21 +857,24 @@ int ist_decode_files_device(ist_ctx* ctx, const uint8_t* const* files, const int
     }
   }
   size_t off = 0;
-  std::vector<JpegDevLayout> jo;
-  decode_layout(dec, &off, &jo);
+  fd.layout(&off);
   rc = grow_device(&ctx->scratch_dec, &ctx->scratch_dec_bytes, off ? off : 256);
   if (rc) return rc;
   ph.lap(IST_PHASE_PLAN_ARENA, "device arena", nullptr);
-  rc = decode_device_stage(ctx, dec, files, lens, static_cast<uint8_t*>(ctx->scratch_dec), jo, img.data(), dst_pitch, &ph);
+  rc = fd.start(static_cast<uint8_t*>(ctx->scratch_dec), img.data(), dst_pitch);
   if (rc) return rc;
-  IST_HIP(hipStreamSynchronize(ctx->stream));      // the bitmaps are complete; `dec` (host coefficients in flight) may go
+  rc = fd.finish(ctx->stream);
+  if (rc) return rc;
+  IST_HIP(hipStreamSynchronize(ctx->stream));      // the bitmaps are complete; the host coefficients in flight may go
   return IST_OK;
 }
 
 // ---- the whole onStitch for files, device-resident: only file bytes go in and only PNG bytes come out over PCIe -------
-// decode (index.js:1441-1520) -> plan (1251-1386) -> one fused resample+blit launch (1532-1551) -> PNG export (1577-1579).
-// The serial part of decoding (Huffman / inflate) runs on host threads, one per image; JPEG reconstruction, the stitch
-// and the PNG encoder run on the GPU and hand buffers to each other in HBM.
+// decode (index.js:1441-1520) -> plan (1251-1386) -> resample+blit (1532-1551) -> PNG export (1577-1579), PIPELINED: the
+// planner needs only the frame headers, so the canvas is laid out first; then every image decodes on its own thread and
+// stream (FileDecoder), band k of the canvas is rendered as soon as image k is there, and the PNG encoder - which works slab
+// by slab, each slab crossing PCIe while the next one compresses - asks for canvas rows as it reaches them.  The first
+// slabs of the file are on their way to the host while the last images are still in the Huffman decoder.
 int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images, int direction, int mode,
                          double gap, const ist_limits* limits, int filter, ist_plan* out_plan, uint8_t** out_png,
                          int64_t* out_len) {
@@ -728,14 +889,13 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   Phases ph(ctx);
-  std::vector<Dec> dec;
-  int rc = decode_host_stage(files, lens, n, &dec);
+  FileDecoder fd(ctx, files, lens, n, &ph);
+  int rc = fd.headers();
   if (rc) return rc;
-  ph.lap(IST_PHASE_HOST_DECODE, "decode on host threads", nullptr);
   // plan (orientation from the file, like getImageInfo -> index.js:734)
   std::vector<ist_image_desc> descs(static_cast<size_t>(n));
   for (int i = 0; i < n; ++i) {
-    const Dec& D = dec[static_cast<size_t>(i)];
+    const Dec& D = fd.dec(i);
     ist_image_desc& d = descs[static_cast<size_t>(i)];
     std::memset(&d, 0, sizeof d);
     d.width = D.w; d.height = D.h; d.orientation = D.orient ? D.orient : 1; d.opaque = D.jpeg ? 1 : 0; d.file_size = lens[i];
@@ -750,18 +910,16 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   rc = ist_plan_ops(out_plan, descs.data(), n, ops.data(), &n_ops);
   if (rc != IST_OK) return rc;
 
-  // one device arena: bitmaps, JPEG coefficient planes + sample planes, canvas, PNG
+  // one device arena (the context's, grow-only): bitmaps, JPEG coefficient planes + sample planes, canvas, PNG
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
   std::vector<size_t> o_img(static_cast<size_t>(n));
-  for (int i = 0; i < n; ++i) o_img[static_cast<size_t>(i)] = take(static_cast<size_t>(dec[static_cast<size_t>(i)].w) * 4 * dec[static_cast<size_t>(i)].h);
-  std::vector<JpegDevLayout> jo;
-  decode_layout(dec, &off, &jo);
+  for (int i = 0; i < n; ++i) o_img[static_cast<size_t>(i)] = take(static_cast<size_t>(fd.dec(i).w) * 4 * fd.dec(i).h + 16);
+  fd.layout(&off);
   const size_t canvas_pitch = static_cast<size_t>(out_plan->canvas_w) * 4;
   const size_t o_canvas = take(canvas_pitch * static_cast<size_t>(out_plan->canvas_h));
   const int64_t png_cap = ist_png_bound(out_plan->canvas_w, out_plan->canvas_h);
   const size_t o_png = take(static_cast<size_t>(png_cap));
-  // the arena lives in the context (grow-only): no allocation per call once it has seen the largest job
   rc = grow_device(&ctx->scratch_arena, &ctx->scratch_arena_bytes, off);
   if (rc) return rc;
   uint8_t* d = static_cast<uint8_t*>(ctx->scratch_arena);
@@ -772,25 +930,62 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   for (int i = 0; i < n; ++i) {
     img[static_cast<size_t>(i)] = d + o_img[static_cast<size_t>(i)];
     dsrc[static_cast<size_t>(i)] = img[static_cast<size_t>(i)];
-    dpitch[static_cast<size_t>(i)] = static_cast<size_t>(dec[static_cast<size_t>(i)].w) * 4;
+    dpitch[static_cast<size_t>(i)] = static_cast<size_t>(fd.dec(i).w) * 4;
   }
-  rc = decode_device_stage(ctx, dec, files, lens, d, jo, img.data(), dpitch.data(), &ph);
+  rc = fd.start(d, img.data(), dpitch.data());          // the images decode from here on
   if (rc) return rc;
-  // the stitch: one fused launch from the decoded bitmaps (HBM) into the canvas (HBM)
+  // the stitch, cut per image (compiled while the workers parse): background now, band k when image k is there
   static const uint8_t transparent[4] = {0, 0, 0, 0};
-  ist_job* job = ist_job_create(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, descs.data(), n, filter, nullptr);
-  if (!job) return g_last_code ? g_last_code : IST_E_INVALID;
-  struct JobFree { ist_job* j; ~JobFree() { ist_job_destroy(j); } } jf{job};
-  rc = ist_job_launch(job, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, ctx->stream);
+  BandedJobs bj;
+  rc = compile_banded(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, descs.data(), n, filter, &bj);
   if (rc) return rc;
-  ph.lap(IST_PHASE_STITCH, "compile + stitch launch", ctx->stream);
-  // PNG export on the device; the file's slabs cross PCIe (the only D2H of the call) while later slabs compress
+  ist_job* whole = nullptr;
+  struct JobFree { ist_job** j; ~JobFree() { if (*j) ist_job_destroy(*j); } } jf{&whole};
+  if (!bj.ok) {
+    whole = ist_job_create(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, descs.data(), n, filter, nullptr);
+    if (!whole) return g_last_code ? g_last_code : IST_E_INVALID;
+  } else {
+    rc = ist_job_launch(bj.bg, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, ctx->stream);
+    if (rc) return rc;
+  }
+  size_t next_part = 0;
+  bool rendered_whole = false;
+  // canvas rows [0, y_end) are about to be read by work submitted to ctx->stream: render what they need first
+  auto need_rows = [&](int64_t y_end) -> int {
+    if (!bj.ok) {
+      if (rendered_whole) return IST_OK;
+      int rc2 = fd.finish(ctx->stream);
+      if (rc2) return rc2;
+      rendered_whole = true;
+      return ist_job_launch(whole, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, ctx->stream);
+    }
+    while (next_part < bj.parts.size() && bj.parts[next_part].Y0 < y_end) {
+      const ist_part& p = bj.parts[next_part];
+      int rc2 = fd.take(p.image, ctx->stream);
+      if (rc2) return rc2;
+      rc2 = ist_job_launch(bj.band[next_part], dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, ctx->stream);
+      if (rc2) return rc2;
+      ++next_part;
+    }
+    return IST_OK;
+  };
+  if (ph.on) {                                            // phase timing: the whole canvas first, then the export
+    rc = need_rows(out_plan->canvas_h);
+    if (rc) return rc;
+    ph.lap(IST_PHASE_STITCH, "compile + stitch launches", ctx->stream);
+  }
+  // PNG export on the device; the file's slabs cross PCIe (the only D2H of the call) while later slabs compress and -
+  // not timing - while later images decode
   int64_t len = 0;
   uint8_t* host = nullptr;
-  rc = png_to_host(ctx, d + o_canvas, canvas_pitch, out_plan->canvas_w, out_plan->canvas_h, d + o_png, &host, &len);
-  if (rc) return rc;
+  int64_t hint_rows = 0;
+  for (const ist_part& p : bj.parts) hint_rows = std::max<int64_t>(hint_rows, p.Y1 - p.Y0);
+  rc = png_to_host(ctx, d + o_canvas, canvas_pitch, out_plan->canvas_w, out_plan->canvas_h, d + o_png, &host, &len, need_rows, hint_rows);
+  if (rc == IST_OK) rc = fd.finish(ctx->stream);          // (images whose draw is clipped away entirely)
+  if (rc) { if (host) pool_give(host); (void)hipStreamSynchronize(ctx->stream); return rc; }
   ph.lap(IST_PHASE_PNG, "PNG encode (GPU) + D2H, overlapped", ctx->stream);
   ph.lap(IST_PHASE_D2H, "(D2H: inside the PNG phase)", nullptr);
+  if (ph.print) std::fprintf(stderr, "[ist timing] %d of %d images decoded by the GPU entropy decoder\n", fd.gpu_decoded(), n);
   *out_png = host; *out_len = len;
   pg.keep = true;
   return IST_OK;

@@ -329,3 +329,36 @@ def test_decode_files_into_device_memory_matches_pil_and_reports_phases(tmp_path
     small = [torch.zeros((a.shape[0] - 1, a.shape[1], 4), dtype=torch.uint8, device="cuda") for a in want]
     with pytest.raises(ist.StitchError):
         ist.decode_files_device(blobs, out=small)
+
+
+def test_pipelined_and_phase_timed_runs_make_the_same_file(tmp_path):
+    """The file pipeline runs per image (thread + stream each; band k of the canvas is rendered and exported while later
+    images still decode; index.js:1441-1520 / :1559-1571).  With phase timing on the same steps run with barriers in
+    between.  Same file either way, and the same pixels as PIL + the oracle; vertical (bands final one by one), horizontal
+    (every band needed by the first slab), 'original' mode (centred, not full-width) and a mixed set of formats."""
+    rng = np.random.default_rng(77)
+    paths, bitmaps = [], []
+    for k in range(7):
+        h, w = int(rng.integers(300, 700)), int(rng.integers(300, 700))
+        a = _photo(5000 + k, h, w)
+        p = tmp_path / ("p%d" % k)
+        if k == 2:
+            p = p.with_suffix(".png"); Image.fromarray(a).save(p, "PNG")
+        elif k == 4:
+            p = p.with_suffix(".jpg"); Image.fromarray(a).save(p, "JPEG", quality=80, progressive=True)
+        else:
+            p = p.with_suffix(".jpg"); Image.fromarray(a).save(p, "JPEG", quality=85, subsampling=k % 3)
+        paths.append(str(p)); bitmaps.append(np.array(Image.open(p).convert("RGBA")))
+    for direction, opts in (("vertical", {"filter": "bilinear"}), ("horizontal", {"filter": "bilinear", "gap": 3}),
+                            ("vertical", {"filter": "nearest", "mode": "original", "gap": 2})):
+        fast = ist.stitch_files(paths, direction, opts)
+        ist.set_phase_timing(True)
+        try:
+            slow = ist.stitch_files(paths, direction, opts)
+            times = ist.last_phase_times()
+        finally:
+            ist.set_phase_timing(False)
+        assert bytes(fast["png"]) == bytes(slow["png"]), (direction, opts)
+        assert times["entropy_gpu"] > 0 and times["png"] > 0
+        ref, _, _ = U.oracle_stitch(bitmaps, direction, opts)
+        assert U.max_abs_diff(ist.decode_png(fast["png"]), ref) <= (0 if opts["filter"] == "nearest" else 1)

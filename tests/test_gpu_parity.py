@@ -492,3 +492,20 @@ def test_random_op_lists_against_oracle():
         elif soft.any():
             assert d[soft].max() == 0, (case, filt, aa, ops_o)
     assert worst <= 1
+
+
+@pytest.mark.parametrize("opts", [{"platform": "ios", "superSample": 1}, {"platform": "android", "superSample": 1}, {"maxSide": 6804}])
+def test_area_filter_fast_path_on_the_phone_capped_plans_at_full_size(opts):
+    """filter 'area' on the plans the reference really renders (9 x 12 MP shrunk 2.2x on iOS, 6.6x on
+    Android, 4x): the streamed box filter (PATH_AREA_STREAM: no per-pixel general tiles), within 1 LSB of the oracle.  Opaque
+    photos and - one image - translucent pixels (the premultiplied sums)."""
+    px = [U.rand_image(950 + i, 3024, 4032, opaque=(i != 4)) for i in range(9)]
+    o = dict(opts, filter="area", edgeAA=False)
+    imgs = [{"width": 4032, "height": 3024, "data": a, "opaque": i != 4} for i, a in enumerate(px)]
+    st = ist.Stitcher(0)
+    p, job = st.compile(imgs, "vertical", o)
+    assert job.info["tiles_general"] == 0 and job.info["tiles_sample"] > 0, job.info
+    got = ist.stitch(imgs, "vertical", o)
+    ref, _, _ = U.oracle_stitch(px, "vertical", o, threads=16)
+    assert got["data"].shape == ref.shape
+    assert U.max_abs_diff(got["data"], ref) <= 1

@@ -31,6 +31,9 @@ WORKLOADS = [
     ("exif8_scaled", [img(w, h, 8) for w, h in MIXED], "vertical", {"filter": "bilinear"}),
     ("exif3_scaled (half turn)", [img(w, h, 3) for w, h in MIXED], "vertical", {"filter": "bilinear"}),
     ("mixed_horizontal", [img(w, h) for w, h in MIXED], "horizontal", {"filter": "bilinear"}),
+    ("ios_plan_area (box filter: every source byte is used)", [img(w, h) for w, h in UNI], "vertical", {"filter": "area", "platform": "ios", "superSample": 1, "edgeAA": False}),
+    ("android_plan_area", [img(w, h) for w, h in UNI], "vertical", {"filter": "area", "platform": "android", "superSample": 1, "edgeAA": False}),
+    ("shrink_4x_area", [img(w, h) for w, h in UNI], "vertical", {"filter": "area", "maxSide": 6804}),
 ]
 
 
