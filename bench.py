@@ -351,6 +351,13 @@ def single_gpu_regions(st, ist, dev, torch, head, reps=8):
             d.copy_(s, non_blocking=True)
         job.launch(srcs, out)
     t_host = timed(from_host)
+    hout = torch.empty((p.canvas_h, p.canvas_w, 4), dtype=torch.uint8).pin_memory()
+
+    def host_sink():
+        from_host()
+        hout.copy_(out, non_blocking=True)
+    t_sink = timed(host_sink)
+    del hout
     blobs = [photo_jpeg(k, w, h) for k, (w, h) in enumerate(UNIFORM)]
 
     def from_jpeg():
@@ -360,6 +367,8 @@ def single_gpu_regions(st, ist, dev, torch, head, reps=8):
     return {"resident": {"ms_per_step": round(head["ms_per_step"], 4), "MPs": round(head["MPs"], 1), "what": "= value: inputs resident in HBM"},
             "from_pinned_host": {"ms_per_step": round(t_host * 1e3, 3), "MPs": round(mp / t_host, 1), "h2d_bytes": int(sum(w * h * 4 for w, h in UNIFORM)),
                                  "what": "9 x 48.8 MB from pinned host memory over this GPU's PCIe link, then the launch"},
+            "host_in_host_out": {"ms_per_step": round(t_sink * 1e3, 3), "MPs": round(mp / t_sink, 1),
+                                 "what": "pinned host in -> H2D, launch, D2H of the canvas into pinned host memory (the N = 1 point of host_in_host_out/*)"},
             "from_jpeg": {"ms_per_step": round(t_jpeg * 1e3, 3), "MPs": round(mp / t_jpeg, 1), "jpeg_bytes": int(sum(len(b) for b in blobs)),
                           "what": "nine 12 MP photo-like JPEGs (q90, 4:2:0) decoded on the GPU (Huffman + IDCT + colour), then the launch"}}
 
@@ -508,11 +517,27 @@ def run_sharded(args):
             D.run_step(sh, be, dsrc, canvas, dist)
         t_res = timed(resident, args.steps, args.warmup)
         t_host = timed(from_host, max(5, args.steps // 10), 2)
+        # host in, host out with a HOST SINK: no gather - every rank copies its finished bands into pinned host memory over its
+        # own PCIe link (vertical strips: full-width bands are contiguous byte ranges of the host canvas)
+        t_sink = None
+        if sh.root_rows() is not None:
+            hbands = {p.index: torch.empty(p.shape, dtype=torch.uint8).pin_memory() for p in sh.mine if sh.slot != 0}
+            hcanvas = torch.empty((sh.plan.canvas_h, sh.plan.canvas_w, 4), dtype=torch.uint8).pin_memory() if rank == 0 else None
+
+            def host_sink():
+                for i in need:
+                    dsrc[i].tensor.copy_(hsrc[i], non_blocking=True)
+                D.run_step_host_sink(sh, be, dsrc, canvas, hbands, hcanvas)
+            t_sink = timed(host_sink, max(5, args.steps // 10), 2)
+            del hbands, hcanvas
         if split == "image":
             value_sec = t_res
         regions["resident/" + split] = {"ms_per_step": round(t_res * 1e3, 4), "MPs": round(mp / t_res, 1)}
         regions["from_pinned_host/" + split] = {"ms_per_step": round(t_host * 1e3, 4), "MPs": round(mp / t_host, 1),
                                                 "h2d_bytes_this_rank": int(sum(t.numel() for t in hsrc.values()))}
+        if t_sink is not None:
+            regions["host_in_host_out/" + split] = {"ms_per_step": round(t_sink * 1e3, 4), "MPs": round(mp / t_sink, 1),
+                                                    "what": "pinned host in -> each rank's H2D, band launches, D2H of its bands into pinned host memory; no gather"}
         if split == "image":                       # JPEG inputs are whole files: by image only
             blobs = [photo_jpeg(i, *UNIFORM[i]) for i in sorted(need)]
             outs = [dsrc[i].tensor for i in sorted(need)]

@@ -304,6 +304,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
   }
 
   // 4. classify + tile each cell
+  bool has_area = false, has_general = false;
   for (DevCell& cell : out->cells) {
     const bool bg_opaque = (cell.bg >> 24) == 255u;
     const bool partial = cell.tiles_x < 0;
@@ -322,15 +323,28 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
         const DevOp& r = out->ops[cell.op];
         if (!(r.flags & (OPF_SWAP | OPF_FILL | OPF_HOLE)) && (bg_opaque || (r.flags & OPF_OPAQUE)) && r.cx1 >= r.cx0 && r.cy1 >= r.cy0 &&
             std::fabs(r.ky) <= 64.0) {
-          const double bwx = std::max(std::fabs(r.kx), 1.0);
-          for (int tw = 256; tw >= 64; tw >>= 1) {
-            const int64_t wl = (static_cast<int64_t>(std::ceil((tw - 1) * std::fabs(r.kx) + bwx)) + 2 + 3) & ~3LL;   // source pixels per LDS row (>= the kernel's)
-            const int64_t need = 4 * 4 * wl;                  // 32-bit words: 4 waves x float4 per source pixel
-            if (need > 12288) continue;                       // 48 KiB
+          // Tile width: the row sums (most of the work) run in 64-lane passes of 4 source pixels each, so the x footprint of a
+          // tile should fill its passes: of the widest tiles (<= 128 canvas pixels: 2 per lane) whose footprint fits one or two
+          // passes, the one with the most canvas pixels per pass.  LDS: 4 waves x footprint x float4 <= 32 KiB.
+          const double akx = std::fabs(r.kx), bwx = std::max(akx, 1.0);
+          auto foot_px = [&](int w) { return (static_cast<int64_t>(std::ceil((w - 1) * akx + bwx)) + 2 + 3) & ~3LL; };   // >= the kernel's
+          int tw = 0; int64_t wl = 0; double best = 0.0;
+          for (int m = 1; m <= 2; ++m) {
+            const double room = 256.0 * m - 3.0 - bwx;        // ceil(span) + 2 <= 256 m  with  span = (w - 1) |kx| + box
+            if (room < 0.0) continue;
+            const int w = static_cast<int>(std::min(128.0, std::floor(room / std::max(akx, 1e-9)) + 1.0));
+            if (w < 24) continue;
+            const int64_t px = foot_px(w);
+            const double score = static_cast<double>(w) / static_cast<double>((px / 4 + 63) / 64);
+            if (score > best - 1e-9) { best = score; tw = w; wl = px; }
+          }
+          if (!tw && akx <= 200.0)                            // a very strong shrink: narrow tiles
+            for (int w = 16; w >= 1 && !tw; w >>= 1)
+              if (foot_px(w) <= 768) { tw = w; wl = foot_px(w); }
+          if (tw) {
             cell.path = PATH_AREA_STREAM; cell.tile_w = tw; cell.tile_h = 16; cell.sub_h = 0;
-            out->lds_words = std::max<int32_t>(out->lds_words, static_cast<int32_t>(need));
+            out->lds_words = std::max<int32_t>(out->lds_words, static_cast<int32_t>(4 * 4 * wl));
             if (!bg_opaque) cell.bg = 0xFFFFFFFFu;            // never used: the draw is opaque
-            break;
           }
         }
       }
@@ -440,7 +454,8 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     cell.tile_begin = tiles;
     tiles += nt;
     info.out_pixels += w * h;
-    out->kernel_kind = std::max<int32_t>(out->kernel_kind, (cell.path == PATH_FILL || cell.path == PATH_COPY) ? 0 : (cell.path == PATH_SAMPLE || cell.path == PATH_SAMPLE_LDS || cell.path == PATH_SAMPLE_STREAM || cell.path == PATH_AREA_STREAM) ? 1 : 2);
+    out->kernel_kind = std::max<int32_t>(out->kernel_kind, (cell.path == PATH_FILL || cell.path == PATH_COPY) ? 0 : (cell.path == PATH_SAMPLE || cell.path == PATH_SAMPLE_LDS || cell.path == PATH_SAMPLE_STREAM) ? 1 : 2);
+    if (cell.path == PATH_AREA_STREAM) has_area = true; else if (cell.path == PATH_GENERAL || cell.path == PATH_SWAP_LDS) has_general = true;
     switch (cell.path) {
       case PATH_FILL: info.tiles_fill += nt; break;
       case PATH_COPY: info.tiles_copy += nt; break;
@@ -459,6 +474,7 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     }
   }
   if (tiles > 2147483647LL) return fail(IST_E_OUTPUT_SIZE, "canvas needs more than 2^31 tiles");
+  if (has_area) out->kernel_kind = has_general ? 4 : 3;   // 3: fill / copy / resample / streamed box filter; 4: everything
   // launch order of the bands: the expensive tiles (resampling) first, copies next, fills last, so that the workgroups
   // that finish the launch are the short ones (a strip of mixed scales otherwise ends on whatever its last image needs).
   // Stable: bands of one kind keep their canvas order.

@@ -30,6 +30,8 @@ struct ist_ctx {
   std::vector<hipEvent_t> img_event;
   std::vector<void*> img_huff; std::vector<size_t> img_huff_bytes;
   void* scratch_ent = nullptr; size_t scratch_ent_bytes = 0;   // sparse coefficient entries of host-decoded JPEGs (progressive, restart intervals)
+  hipStream_t render = nullptr;          // file pipeline: Huffman batch + per-image reconstruction + band launches, beside the PNG encoder on `stream`
+  hipEvent_t render_done = nullptr;
   hipStream_t aux = nullptr;             // second stream of the host-path entry points (PNG slabs travel on it while later ones compress)
   // device blocks of destroyed jobs' tables, re-used by the next job of this context instead of a hipMalloc + hipFree pair
   // per job (a free also synchronises the device); at most kTablePool blocks are kept

@@ -99,7 +99,9 @@ std::vector<int16_t> jpeg_dense_coefficients(const JpegComp& c);
 // GPU entropy decoding of a batch of eligible images (self-synchronising parallel Huffman decoding).  d_coef[c] are the
 // dense device planes (blocks_x*blocks_y*64 int16 each) the reconstruction kernels read.  ok[i] = 0 when image i failed
 // the end-of-scan validation: the caller then decodes that image on the host.  Synchronises `stream`.
-struct JpegGpuItem { const JpegImage* J; const JpegGpuScan* S; int16_t* d_coef[3]; };
+// d_stream (optional): the de-stuffed scan ALREADY on the device (256-byte aligned, S->stream.size() bytes, uploaded by the
+// caller - e.g. by the image's parse thread while other images are still being parsed); NULL: uploaded here.
+struct JpegGpuItem { const JpegImage* J; const JpegGpuScan* S; int16_t* d_coef[3]; const uint8_t* d_stream = nullptr; };
 // scratch / scratch_bytes (optional): a grow-only device buffer the caller keeps across calls
 int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<uint8_t>* ok, void* stream, void** scratch = nullptr, size_t* scratch_bytes = nullptr);
 

@@ -490,7 +490,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     // the kernels index slot_comp / slot_idx (10 entries, T.81 B.2.3) with the MCU slot: never launch outside that
     if (S.slots < 1 || S.slots > 10) return fail(IST_E_DECODE, "JPEG scan with more than 10 blocks per MCU");
     if (S.stream.size() != static_cast<size_t>(S.bits / 8) + 16) return fail(IST_E_INVALID, "JPEG scan buffer without its padding");
-    o_stream[k] = take(S.stream.size());
+    o_stream[k] = items[k].d_stream ? 0 : take(S.stream.size());
     o_tab[k] = take(sizeof(S.tables));
     DevImg& I = H[k];
     std::memset(&I, 0, sizeof I);
@@ -535,9 +535,9 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   std::vector<uint16_t> half_img(static_cast<size_t>(n_half));           // image of every group of 128 subsequences
   for (size_t k = 0; k < n_img; ++k) {
     const JpegGpuScan& S = *items[k].S;
-    JG_HIP(hipMemcpyAsync(d + o_stream[k], S.stream.data(), S.stream.size(), hipMemcpyHostToDevice, stream));
+    if (!items[k].d_stream) JG_HIP(hipMemcpyAsync(d + o_stream[k], S.stream.data(), S.stream.size(), hipMemcpyHostToDevice, stream));
     JG_HIP(hipMemcpyAsync(d + o_tab[k], S.tables, sizeof(S.tables), hipMemcpyHostToDevice, stream));
-    H[k].stream = d + o_stream[k];
+    H[k].stream = items[k].d_stream ? items[k].d_stream : d + o_stream[k];
     H[k].tables = reinterpret_cast<const JpegHuffTable*>(d + o_tab[k]);
     H[k].err = reinterpret_cast<uint32_t*>(d + o_err) + k;
     for (int i = 0; i < ((H[k].n_sub + 255) & ~255); i += kWriteThreads) half_img[static_cast<size_t>((H[k].first_sub + i) / kWriteThreads)] = static_cast<uint16_t>(k);

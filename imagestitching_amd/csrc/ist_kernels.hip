@@ -604,12 +604,16 @@ IST_DEV void tile_sample_stream(const LaunchArgs& A, const DevOp op, uint32_t bg
 // the memory system must move anyway (whole 32-byte sectors of the rows a shrink touches) are all useful work.
 // Separable, no workgroup barrier: a wave owns output rows Y0 + wave + 4 j.  For one output row it
 //   1. reads the <= ceil(|ky|) + 1 source rows of the row's box with coalesced 16-byte loads (lane = 4 neighbouring source
-//      pixels) and sums them in registers with the rows' overlap weights (fp32, premultiplied),
+//      pixels; up to 8 rows in flight per lane) and sums them in registers with the rows' overlap weights (packed fp32),
 //   2. writes the column sums (one float4 per source pixel) to its private LDS row,
 //   3. lane = canvas pixel: sums the <= ceil(|kx|) + 1 float4 of its box from LDS with the columns' overlap weights,
 //      normalises, composites over the background and stores 256 contiguous bytes per wave.
 // A wave's LDS operations execute in order, so the phases need no barrier; the x taps of a lane are the same for every
-// row of the tile and are computed once (fp64, as the oracle does).
+// row of the tile and are computed once (fp64, as the oracle does).  The host sizes the tile width so that the x footprint
+// is a whole number of 64-lane passes (ist_compile.cpp): a 256-pixel tile at 2.2x left a third of the lanes of step 1 idle.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAreaRows = 4;             // source rows in flight per lane in step 1
+
 template <int NP, bool OPAQUE>
 IST_DEV void tile_area_stream(const LaunchArgs& A, const DevOp op, uint32_t bg, int X0, int Y0, int X1, int Y1, uint32_t* lds) {
   const int lane = threadIdx.x & 63;
@@ -626,69 +630,80 @@ IST_DEV void tile_area_stream(const LaunchArgs& A, const DevOp op, uint32_t bg, 
   const size_t sp = A.pitch[op.image];
   const uint8_t* src = A.src[op.image];
   // per lane, once per tile: the box of each of its canvas pixels on the x axis
-  int Xl = X0 + lane;
-  int tx0[NP], tn[NP]; float wf[NP], wb[NP];              // first tap (LDS index), taps, weight of the first / last tap
+  const int Xl = X0 + lane;
+  int tap[NP]; float wf[NP], wb[NP];                      // (first tap's LDS index << 8) | taps; weight of the first / last tap
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const double sxc = op.kx * (static_cast<double>(min(Xl + 64 * p, X1 - 1)) + 0.5) + op.ox;
     const double xlo = sxc - 0.5 * bw, xhi = sxc + 0.5 * bw;
     const int ix0 = static_cast<int>(fmin(fmax(floor(xlo), -2.0e9), 2.0e9)), ix1 = static_cast<int>(fmin(fmax(ceil(xhi), -2.0e9), 2.0e9)) - 1;
-    tx0[p] = ix0 - fx0; tn[p] = ix1 - ix0 + 1;
+    tap[p] = ((ix0 - fx0) << 8) | min(ix1 - ix0 + 1, 255);
     wf[p] = static_cast<float>(fmin(static_cast<double>(ix0) + 1.0, xhi) - fmax(static_cast<double>(ix0), xlo));
     wb[p] = static_cast<float>(fmin(static_cast<double>(ix1) + 1.0, xhi) - fmax(static_cast<double>(ix1), xlo));
+    __builtin_amdgcn_sched_barrier(0);                      // (one pixel's fp64 temporaries at a time)
   }
-  const double norm = 1.0 / (bw * bh);
+  const float normf = static_cast<float>(1.0 / (bw * bh));
   uint8_t* d = A.dst + static_cast<size_t>(Xl) * 4;
   for (int Y = Y0 + wave; Y < Y1; Y += 4) {
     // the rows of this output row's box (wave-uniform)
     const double syc = op.ky * (static_cast<double>(Y) + 0.5) + op.oy;
     const double ylo = syc - 0.5 * bh, yhi = syc + 0.5 * bh;
-    const int iy0 = static_cast<int>(fmin(fmax(floor(ylo), -2.0e9), 2.0e9)), iy1 = static_cast<int>(fmin(fmax(ceil(yhi), -2.0e9), 2.0e9)) - 1;
+    const int iy0 = __builtin_amdgcn_readfirstlane(static_cast<int>(fmin(fmax(floor(ylo), -2.0e9), 2.0e9)));
+    const int iy1 = __builtin_amdgcn_readfirstlane(static_cast<int>(fmin(fmax(ceil(yhi), -2.0e9), 2.0e9)) - 1);
     // 1 + 2: column sums of the box's rows -> LDS
     for (int c0 = 0; c0 < chunks; c0 += 64) {
       const int c = c0 + lane;
-      if (c < chunks) {
-        const int xx = fx0 + 4 * c;
-        const bool inside = xx >= op.cx0 && xx + 3 <= op.cx1;
-        float acc[4][4];
+      const bool mine = c < chunks;
+      const int xx = fx0 + 4 * min(c, chunks - 1);
+      const bool inside = xx >= op.cx0 && xx + 3 <= op.cx1;
+      f32x2 acc[4][2];                                      // per source pixel: (r, g), (b, a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f; }
-        for (int yy = iy0; yy <= iy1; yy += 4) {
-          u32x4 v[4]; float w[4];
+      for (int q = 0; q < 4; ++q) { acc[q][0] = f32x2{0.f, 0.f}; acc[q][1] = f32x2{0.f, 0.f}; }
+      auto add_px = [&](int q, uint32_t px, f32x2 w2) {
+        f32x2 lo = {static_cast<float>(ch(px, 0)), static_cast<float>(ch(px, 1))};
+        f32x2 hi = {static_cast<float>(ch(px, 2)), static_cast<float>(px >> 24)};
+        if (!OPAQUE) { const f32x2 a2 = {hi.y, hi.y}; lo = lo * a2; hi.x = hi.x * hi.y; }
+        acc[q][0] = __builtin_elementwise_fma(w2, lo, acc[q][0]);
+        acc[q][1] = __builtin_elementwise_fma(w2, hi, acc[q][1]);
+      };
+      auto weight_of = [&](int y) {                         // overlap of source row y with the box (wave-uniform)
+        const float w = static_cast<float>(fmin(static_cast<double>(y) + 1.0, yhi) - fmax(static_cast<double>(y), ylo));
+        const float u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w)));
+        return f32x2{u, u};
+      };
+      if (inside) {
+        for (int yy = iy0; yy <= iy1; yy += kAreaRows) {
+          u32x4 v[kAreaRows];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int y = yy + u;
-            w[u] = y <= iy1 ? static_cast<float>(fmin(static_cast<double>(y) + 1.0, yhi) - fmax(static_cast<double>(y), ylo)) : 0.f;
-            const uint8_t* g = src + static_cast<size_t>(min(max(min(y, iy1), op.cy0), op.cy1)) * sp;
-            if (inside) v[u] = ld16(g + static_cast<size_t>(xx) * 4);
-            else {
-              v[u].x = ld4(g + static_cast<size_t>(min(max(xx, op.cx0), op.cx1)) * 4);
-              v[u].y = ld4(g + static_cast<size_t>(min(max(xx + 1, op.cx0), op.cx1)) * 4);
-              v[u].z = ld4(g + static_cast<size_t>(min(max(xx + 2, op.cx0), op.cx1)) * 4);
-              v[u].w = ld4(g + static_cast<size_t>(min(max(xx + 3, op.cx0), op.cx1)) * 4);
-            }
+          for (int u = 0; u < kAreaRows; ++u) {
+            if (yy + u > iy1) break;                        // (wave-uniform)
+            v[u] = ld16(src + static_cast<size_t>(min(max(yy + u, op.cy0), op.cy1)) * sp + static_cast<size_t>(xx) * 4);
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (w[u] <= 0.f) continue;                       // (wave-uniform)
-            const uint32_t px[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              if (OPAQUE) {
-                acc[q][0] += w[u] * static_cast<float>(ch(px[q], 0)); acc[q][1] += w[u] * static_cast<float>(ch(px[q], 1));
-                acc[q][2] += w[u] * static_cast<float>(ch(px[q], 2));
-              } else {
-                const float a = static_cast<float>(px[q] >> 24);
-                acc[q][0] += w[u] * (static_cast<float>(ch(px[q], 0)) * a); acc[q][1] += w[u] * (static_cast<float>(ch(px[q], 1)) * a);
-                acc[q][2] += w[u] * (static_cast<float>(ch(px[q], 2)) * a); acc[q][3] += w[u] * a;
-              }
-            }
+          for (int u = 0; u < kAreaRows; ++u) {
+            if (yy + u > iy1) break;
+            const f32x2 w2 = weight_of(yy + u);
+            add_px(0, v[u].x, w2); add_px(1, v[u].y, w2); add_px(2, v[u].z, w2); add_px(3, v[u].w, w2);
           }
         }
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
+      } else {                                              // a chunk that straddles the source's edge (rare): pixel by pixel, clamped
+#pragma unroll 1
+        for (int y = iy0; y <= iy1; ++y) {
+          const f32x2 w2 = weight_of(y);
+          const uint8_t* g = src + static_cast<size_t>(min(max(y, op.cy0), op.cy1)) * sp;
+          add_px(0, ld4(g + static_cast<size_t>(min(max(xx, op.cx0), op.cx1)) * 4), w2);
+          __builtin_amdgcn_sched_barrier(0);
+          add_px(1, ld4(g + static_cast<size_t>(min(max(xx + 1, op.cx0), op.cx1)) * 4), w2);
+          __builtin_amdgcn_sched_barrier(0);
+          add_px(2, ld4(g + static_cast<size_t>(min(max(xx + 2, op.cx0), op.cx1)) * 4), w2);
+          __builtin_amdgcn_sched_barrier(0);
+          add_px(3, ld4(g + static_cast<size_t>(min(max(xx + 3, op.cx0), op.cx1)) * 4), w2);
+        }
+      }
+      if (mine) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 t = {acc[q][0], acc[q][1], acc[q][2], acc[q][3]};
+          const f32x4 t = {acc[q][0].x, acc[q][0].y, acc[q][1].x, acc[q][1].y};
           *reinterpret_cast<f32x4*>(row + 4 * (4 * c + q)) = t;
         }
       }
@@ -698,32 +713,25 @@ IST_DEV void tile_area_stream(const LaunchArgs& A, const DevOp op, uint32_t bg, 
     uint8_t* dp = d + static_cast<size_t>(Y) * A.dst_pitch;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      typedef float f32x4 __attribute__((ext_vector_type(4)));
-      const f32x4* t = reinterpret_cast<const f32x4*>(row) + tx0[p];
+      if (X0 + 64 * p >= X1) break;                         // (wave-uniform: the tile is narrower than 64 * NP)
+      const f32x4* t = reinterpret_cast<const f32x4*>(row) + (tap[p] >> 8);
       f32x4 s = t[0] * wf[p];
-      const int nt = tn[p];
+      const int nt = tap[p] & 255;
       for (int k = 1; k < nt - 1; ++k) s += t[k];
       if (nt > 1) s += t[nt - 1] * wb[p];
       uint32_t o;
       if (OPAQUE) {                                         // opaque source: the mean replaces the destination
-        const double r = static_cast<double>(s.x) * norm, g = static_cast<double>(s.y) * norm, b = static_cast<double>(s.z) * norm;
-        o = 0xFF000000u | static_cast<uint32_t>(fmin(fmax(floor(r + 0.5), 0.0), 255.0)) | (static_cast<uint32_t>(fmin(fmax(floor(g + 0.5), 0.0), 255.0)) << 8) |
-            (static_cast<uint32_t>(fmin(fmax(floor(b + 0.5), 0.0), 255.0)) << 16);
-      } else {                                              // the same operations as the per-pixel path (pixel_general) at coverage 1
-        const double Aa = static_cast<double>(s.w) * norm;
-        const double keep = 1.0 - Aa / 255.0;
-        const float accs[3] = {s.x, s.y, s.z};
-        o = 0;
-#pragma unroll
-        for (int c2 = 0; c2 < 3; ++c2) {
-          const double P = static_cast<double>(accs[c2]) * norm / 255.0;
-          const double v2 = floor(P + static_cast<double>(ch(bg, c2)) * keep + 0.5);
-          o |= static_cast<uint32_t>(fmin(fmax(v2, 0.0), 255.0)) << (8 * c2);
-        }
-        const double va = floor(Aa + static_cast<double>(bg >> 24) * keep + 0.5);
-        o |= static_cast<uint32_t>(fmin(fmax(va, 0.0), 255.0)) << 24;
+        o = 0xFF000000u | to_u8(fminf(s.x * normf, 255.f)) | (to_u8(fminf(s.y * normf, 255.f)) << 8) | (to_u8(fminf(s.z * normf, 255.f)) << 16);
+      } else {                                              // premultiplied mean, source-over on the background, one rounding
+        const float Aa = s.w * normf;
+        const float keep = 1.0f - Aa * (1.0f / 255.0f);
+        o = to_u8(fminf(s.x * normf * (1.0f / 255.0f) + static_cast<float>(ch(bg, 0)) * keep, 255.f)) |
+            (to_u8(fminf(s.y * normf * (1.0f / 255.0f) + static_cast<float>(ch(bg, 1)) * keep, 255.f)) << 8) |
+            (to_u8(fminf(s.z * normf * (1.0f / 255.0f) + static_cast<float>(ch(bg, 2)) * keep, 255.f)) << 16) |
+            (to_u8(fminf(Aa + static_cast<float>(bg >> 24) * keep, 255.f)) << 24);
       }
       if (Xl + 64 * p < X1) st4(dp + 256 * p, o);
+      __builtin_amdgcn_sched_barrier(0);                    // (one pixel's taps at a time)
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -957,7 +965,7 @@ IST_DEV void tile_general(const LaunchArgs& A, const DevCell c, int X0, int Y0, 
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
-enum : int { HAS_FILL = 1, HAS_COPY = 2, HAS_SAMPLE = 4, HAS_GENERAL = 8, HAS_SWAP = 16 };
+enum : int { HAS_FILL = 1, HAS_COPY = 2, HAS_SAMPLE = 4, HAS_GENERAL = 8, HAS_SWAP = 16, HAS_AREA = 32 };
 
 template <int PATHS, int V>
 IST_DEV void run_tile(const LaunchArgs& A, int64_t tile, bool fresh) {
@@ -1010,11 +1018,11 @@ IST_DEV void run_tile(const LaunchArgs& A, int64_t tile, bool fresh) {
     if (c.tile_w == 256) tile_sample_stream<4>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
     else if (c.tile_w == 128) tile_sample_stream<2>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
     else tile_sample_stream<1>(A, op_, c.bg, X0, Y0, X1, Y1, c.sub_h, lds, fresh);
-  } else if ((PATHS & HAS_SAMPLE) && path == PATH_AREA_STREAM) {
+  } else if ((PATHS & HAS_AREA) && path == PATH_AREA_STREAM) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const bool opq = (op_.flags & OPF_OPAQUE) != 0;
-    if (c.tile_w == 256) { if (opq) tile_area_stream<4, true>(A, op_, c.bg, X0, Y0, X1, Y1, lds); else tile_area_stream<4, false>(A, op_, c.bg, X0, Y0, X1, Y1, lds); }
-    else if (c.tile_w == 128) { if (opq) tile_area_stream<2, true>(A, op_, c.bg, X0, Y0, X1, Y1, lds); else tile_area_stream<2, false>(A, op_, c.bg, X0, Y0, X1, Y1, lds); }
+    // (tiles are at most 128 canvas pixels wide: every further 64 pixels per lane cost ~15 VGPRs, and at 4 the kernel fell to 3 waves per SIMD)
+    if (c.tile_w > 64) { if (opq) tile_area_stream<2, true>(A, op_, c.bg, X0, Y0, X1, Y1, lds); else tile_area_stream<2, false>(A, op_, c.bg, X0, Y0, X1, Y1, lds); }
     else { if (opq) tile_area_stream<1, true>(A, op_, c.bg, X0, Y0, X1, Y1, lds); else tile_area_stream<1, false>(A, op_, c.bg, X0, Y0, X1, Y1, lds); }
   } else if ((PATHS & HAS_SWAP) && path == PATH_SWAP_LDS) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1038,12 +1046,23 @@ __global__ __launch_bounds__(256) void ist_stitch_kernel(const LaunchArgs A, con
   }
 }
 
+// the instantiation that carries the streamed box filter: held to 5 waves per SIMD (it compiled to 103 VGPRs, one register
+// past that step)
+template <int PATHS, int V, bool PERSIST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void ist_stitch_area_kernel(const LaunchArgs A, const int64_t n_tiles) {
+  if (PERSIST) {
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) run_tile<PATHS, V>(A, t, false);
+  } else {
+    run_tile<PATHS, V>(A, static_cast<int64_t>(blockIdx.x), true);
+  }
+}
 
 template <int PATHS, int V, bool PERSIST>
 static void launch_one(const LaunchArgs& args, int64_t n_tiles, hipStream_t stream, int persist_blocks, unsigned dyn_lds) {
   const unsigned grid = PERSIST ? static_cast<unsigned>(std::min<int64_t>(n_tiles, persist_blocks)) : static_cast<unsigned>(n_tiles);
   const unsigned dyn = std::max(dyn_lds, static_cast<unsigned>(args.lds_words) * 4u);   // dyn_lds: IST_DYN_LDS tuning knob (unused LDS caps the workgroups per CU)
-  hipLaunchKernelGGL((ist_stitch_kernel<PATHS, V, PERSIST>), dim3(grid), dim3(256), dyn, stream, args, n_tiles);
+  if constexpr ((PATHS & HAS_AREA) != 0) hipLaunchKernelGGL((ist_stitch_area_kernel<PATHS, V, PERSIST>), dim3(grid), dim3(256), dyn, stream, args, n_tiles);
+  else hipLaunchKernelGGL((ist_stitch_kernel<PATHS, V, PERSIST>), dim3(grid), dim3(256), dyn, stream, args, n_tiles);
 }
 
 template <int PATHS>
@@ -1071,8 +1090,12 @@ int launch_stitch(const LaunchArgs& args, int64_t n_tiles, int kind, void* strea
   hipStream_t s = static_cast<hipStream_t>(stream);
   // three instantiations of one template, by what the job's cells need: the fewer paths, the fewer registers and the
   // more workgroups per CU (fill/copy: 28 VGPRs; + axis-aligned resampling; + quarter turns and the per-pixel stack)
+  // (the streamed box filter keeps up to 8 source rows per lane in flight: it has its own instantiation so that its register
+  // count does not lower the occupancy of the jobs that never use it)
   if (kind == 0 && !full) launch_variant<HAS_FILL | HAS_COPY>(v, persist, args, n_tiles, s, pb, dl);
   else if (kind == 1 && !full) launch_variant<HAS_FILL | HAS_COPY | HAS_SAMPLE>(v, persist, args, n_tiles, s, pb, dl);
+  else if (kind == 3 && !full) launch_variant<HAS_FILL | HAS_COPY | HAS_SAMPLE | HAS_AREA>(v, persist, args, n_tiles, s, pb, dl);
+  else if (kind == 4 || full) launch_variant<HAS_FILL | HAS_COPY | HAS_SAMPLE | HAS_SWAP | HAS_GENERAL | HAS_AREA>(v, persist, args, n_tiles, s, pb, dl);
   else launch_variant<HAS_FILL | HAS_COPY | HAS_SAMPLE | HAS_SWAP | HAS_GENERAL>(v, persist, args, n_tiles, s, pb, dl);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(IST_E_HIP, std::string("kernel launch failed: ") + hipGetErrorString(e));

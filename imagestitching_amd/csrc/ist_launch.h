@@ -29,8 +29,9 @@ struct LaunchArgs {
   size_t pitch[kMaxImages];
 };
 
-// kind: 0 = the job has only FILL / COPY cells, 1 = + axis-aligned resampling (SAMPLE, SAMPLE_LDS), 2 = anything
-// (quarter turns, paint stacks): the instantiation with just those paths is launched
+// kind: 0 = the job has only FILL / COPY cells, 1 = + axis-aligned resampling (SAMPLE, SAMPLE_LDS, SAMPLE_STREAM), 3 = + the
+// streamed box filter (AREA_STREAM), 2 = quarter turns / paint stacks (no box filter), 4 = everything: the instantiation
+// with just those paths is launched
 int launch_stitch(const LaunchArgs& args, int64_t n_tiles, int kind, void* stream);
 
 }  // namespace ist

@@ -178,6 +178,8 @@ void ist_ctx_destroy(ist_ctx* ctx) {
   for (hipEvent_t ev : ctx->img_event) if (ev) (void)hipEventDestroy(ev);
   for (void* q : ctx->img_huff) dev_free(q);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+  if (ctx->render) { (void)hipStreamSynchronize(ctx->render); (void)hipStreamDestroy(ctx->render); }
+  if (ctx->render_done) (void)hipEventDestroy(ctx->render_done);
   for (const ist_ctx::TableBlock& b : ctx->table_pool) dev_free(b.p);
   ctx->stager.reset();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -553,14 +555,16 @@ int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8
 }
 
 // ---- files -> bitmaps in HBM: the decode stage shared by ist_stitch_files_png and ist_decode_files_device ------------
-// PIPELINED PER IMAGE (index.js:1441-1520 decodes image after image; :1559-1571 flushes and releases each one).  Every
-// image has a host thread and a device stream of its own: container parse + de-stuffing on the thread, then - baseline
-// JPEG - upload of the scan, the Huffman passes and the reconstruction on its stream, and an event when its bitmap is
-// complete.  The images' chains overlap each other, and (ist_stitch_files_png) the export of the canvas rows that are
-// already final: a vertical strip's band k is final once image k is decoded.  Files the GPU entropy decoder does not take
-// (progressive, restart intervals, PNG / BMP / GIF / WebP) are decoded on their thread and uploaded when the consumer
-// asks for the image.  With phase timing on, the same steps run with a barrier between them (parse all, entropy all,
-// reconstruct all), so that the phase clock means what it says.
+// (index.js:1441-1520 decodes image after image; :1559-1571 flushes and releases each one.)  Every image has a host thread:
+// container parse + de-stuffing, and - baseline JPEG - the upload of its scan on a stream of its own, so that the uploads
+// run while other images are still being parsed.  The Huffman passes of ALL eligible images then run as ONE batch on the
+// consumer's stream: the decoder is latency-bound per workgroup (a 12 MP photo is 58 workgroups), so nine images in one
+// launch take as long as one, whereas one chain per image on nine streams took 2x longer than the batch (measured: the
+// runtime multiplexes streams onto four hardware queues, three chains per queue ran back to back).  Behind the batch the
+// images are reconstructed one by one as the consumer asks for them, so (ist_stitch_files_png) band k of the canvas is
+// rendered and exported while the images behind it are still being reconstructed.  Files the GPU entropy decoder does not
+// take (progressive, restart intervals, PNG / BMP / GIF / WebP) are decoded on their thread and uploaded when the consumer
+// asks for the image.  With phase timing on, the same steps run with a stream sync between them.
 extern "C++" {
 namespace {
 
@@ -612,8 +616,8 @@ class FileDecoder {
  public:
   FileDecoder(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n, Phases* ph)
       : ctx_(ctx), files_(files), lens_(lens), n_(n), ph_(ph), dec_(static_cast<size_t>(n)), th_(static_cast<size_t>(n)),
-        on_gpu_(static_cast<size_t>(n), 0), taken_(static_cast<size_t>(n), 0), jo_(static_cast<size_t>(n)), huff_ok_(static_cast<size_t>(n), 0) {}
-  ~FileDecoder() { join_all(); for (int i = 0; i < n_; ++i) if (on_gpu_[static_cast<size_t>(i)]) (void)hipStreamSynchronize(stream_of(i)); }
+        on_gpu_(static_cast<size_t>(n), 0), taken_(static_cast<size_t>(n), 0), uploaded_(static_cast<size_t>(n), 0), jo_(static_cast<size_t>(n)) {}
+  ~FileDecoder() { join_all(); for (int i = 0; i < n_; ++i) if (uploaded_[static_cast<size_t>(i)]) (void)hipStreamSynchronize(stream_of(i)); }
 
   // 1. frame headers only (microseconds per file): sizes, sampling, EXIF orientation - what the planner and the arena need
   int headers() {
@@ -643,39 +647,33 @@ class FileDecoder {
   // 2. the workers.  arena: what layout() was sized for; img[i] / pitch[i]: where bitmap i goes (device memory)
   int start(uint8_t* arena, uint8_t* const* img, const size_t* pitch) {
     arena_ = arena; img_ = img; pitch_ = pitch;
-    int rc = ensure_image_lanes(ctx_, n_);
+    const int rc = ensure_image_lanes(ctx_, n_);
     if (rc) return rc;
-    serial_ = ph_->on;
-    if (!serial_) {
-      for (int i = 0; i < n_; ++i) th_[static_cast<size_t>(i)] = std::thread([this, i]() { worker(i, 0, 3); });
-      return IST_OK;
-    }
-    // phase timing: the same three steps with a barrier between them
-    run_step(0); rc = first_error(); if (rc) return rc;
-    ph_->lap(IST_PHASE_HOST_DECODE, "decode on host threads", nullptr);
-    run_step(1);
-    for (int i = 0; i < n_; ++i) (void)hipStreamSynchronize(stream_of(i));
-    ph_->lap(IST_PHASE_ENTROPY_GPU, "entropy decode (GPU)", nullptr);
-    run_step(2);
-    for (int i = 0; i < n_; ++i) { rc = take(i, ctx_->stream); if (rc) return rc; }
+    for (int i = 0; i < n_; ++i) th_[static_cast<size_t>(i)] = std::thread([this, i]() { worker(i); });
+    if (!ph_->on) return IST_OK;
+    // phase timing: the steps one after the other
+    join_all();
+    int rc2 = first_error(); if (rc2) return rc2;
+    for (int i = 0; i < n_; ++i) if (uploaded_[static_cast<size_t>(i)]) (void)hipStreamSynchronize(stream_of(i));
+    ph_->lap(IST_PHASE_HOST_DECODE, "decode on host threads (+ scan uploads)", nullptr);
+    rc2 = huffman_all(ctx_->stream); if (rc2) return rc2;
+    ph_->lap(IST_PHASE_ENTROPY_GPU, "entropy decode (GPU)", ctx_->stream);
+    for (int i = 0; i < n_; ++i) { rc2 = take(i, ctx_->stream); if (rc2) return rc2; }
     ph_->lap(IST_PHASE_RECONSTRUCT, "H2D + JPEG reconstruct (GPU)", ctx_->stream);
     return IST_OK;
   }
 
-  // 3. bitmap i is needed by work that will be submitted to `consumer` next: waits for the image's HOST side, then either
-  // orders `consumer` behind the image's device chain, or - a file the GPU path did not take - uploads / reconstructs it on
-  // `consumer` now.  Idempotent.
+  // 3. bitmap i is needed by work that will be submitted to `consumer` next.  The first call waits for every image's HOST
+  // side and runs the Huffman batch on `consumer`; then image i is reconstructed (or, a file the GPU path did not take,
+  // uploaded / reconstructed from host coefficients) on `consumer`.  Idempotent per image; one consumer stream per call.
   int take(int i, hipStream_t consumer) {
     const size_t k = static_cast<size_t>(i);
     if (taken_[k]) return IST_OK;
-    if (th_[k].joinable()) th_[k].join();
+    int rc = huffman_all(consumer);
+    if (rc) return rc;
     Dec& D = dec_[k];
-    if (D.rc != IST_OK) return fail(D.rc, "图片" + std::to_string(i) + "解码异常: " + D.err);          // index.js:1512-1514
     taken_[k] = 1;
-    if (on_gpu_[k]) {
-      if (hipStreamWaitEvent(consumer, ctx_->img_event[k], 0) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipStreamWaitEvent failed"); }
-      return IST_OK;
-    }
+    if (on_gpu_[k]) return jpeg_enqueue(D.J, arena_, nullptr, jo_[k], img_[i], pitch_[i], consumer, true);
     const size_t row = static_cast<size_t>(D.w) * 4;
     if (!D.jpeg) {                                  // PNG / BMP / GIF / WebP: decoded on the thread, uploaded here
       std::vector<RowsCopy> up;
@@ -684,26 +682,24 @@ class FileDecoder {
       return stager_of(ctx_).upload(up, consumer);
     }
     // a JPEG whose coefficients are on the host (progressive, restart intervals, non-interleaved scans, or a file that
-    // failed the GPU decoder's validation and was decoded again by the host decoder)
+    // failed the GPU decoder's validation and is decoded again by the host decoder)
     if (D.G.eligible) {
       D.G.eligible = false;
       JpegImage host;
-      const int rc = jpeg_parse_and_entropy_decode(files_[i], lens_[i], &host, false, nullptr);
+      rc = jpeg_parse_and_entropy_decode(files_[i], lens_[i], &host, false, nullptr);
       if (rc) return fail(rc, "图片" + std::to_string(i) + "解码异常: " + g_last_error);
       D.J = std::move(host);
     }
     size_t need = 0;
     JpegDevLayout L = jo_[k];
     jpeg_layout_sparse(D.J, &need, &L);
-    if (need > ctx_->scratch_ent_bytes) {             // (an earlier image's scatter may still read the old block)
+    if (need) {                                      // one block serves the host-decoded images in turn
       (void)hipStreamSynchronize(consumer);
-      const int rc = grow_device(&ctx_->scratch_ent, &ctx_->scratch_ent_bytes, need + need / 2);
-      if (rc) return rc;
-    } else if (need) (void)hipStreamSynchronize(consumer);   // one block serves the images in turn
+      if (need > ctx_->scratch_ent_bytes) { rc = grow_device(&ctx_->scratch_ent, &ctx_->scratch_ent_bytes, need + need / 2); if (rc) return rc; }
+    }
     return jpeg_enqueue(D.J, arena_, static_cast<uint8_t*>(ctx_->scratch_ent), L, img_[i], pitch_[i], consumer, false);
   }
 
-  // every worker has returned and (GPU path) every image's chain has been waited for by `consumer`
   int finish(hipStream_t consumer) {
     for (int i = 0; i < n_; ++i) { const int rc = take(i, consumer); if (rc) { join_all(); return rc; } }
     return IST_OK;
@@ -717,57 +713,71 @@ class FileDecoder {
     for (int i = 0; i < n_; ++i) if (dec_[static_cast<size_t>(i)].rc != IST_OK) return fail(dec_[static_cast<size_t>(i)].rc, "图片" + std::to_string(i) + "解码异常: " + dec_[static_cast<size_t>(i)].err);
     return IST_OK;
   }
-  void run_step(int step) {
-    for (int i = 0; i < n_; ++i) th_[static_cast<size_t>(i)] = std::thread([this, i, step]() { worker(i, step, step + 1); });
+  // every worker has returned; ONE Huffman batch over the eligible images on `consumer`, behind their scan uploads
+  int huffman_all(hipStream_t consumer) {
+    if (huff_done_) return IST_OK;
     join_all();
+    int rc = first_error();
+    if (rc) return rc;
+    huff_done_ = true;
+    std::vector<JpegGpuItem> items; std::vector<int> who;
+    for (int i = 0; i < n_; ++i) {
+      const size_t k = static_cast<size_t>(i);
+      Dec& D = dec_[k];
+      if (!D.jpeg || !D.G.eligible) continue;
+      JpegGpuItem it; it.J = &D.J; it.S = &D.G;
+      for (int c = 0; c < 3; ++c) it.d_coef[c] = c < D.J.ncomp ? reinterpret_cast<int16_t*>(arena_ + jo_[k].coef[c]) : nullptr;
+      if (uploaded_[k]) {
+        it.d_stream = static_cast<const uint8_t*>(ctx_->img_huff[k]);
+        if (hipStreamWaitEvent(consumer, ctx_->img_event[k], 0) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipStreamWaitEvent failed"); }
+      }
+      items.push_back(it); who.push_back(i);
+    }
+    std::vector<uint8_t> okv;
+    rc = jpeg_gpu_entropy_decode(items, &okv, consumer, &ctx_->scratch_huff, &ctx_->scratch_huff_bytes);
+    if (rc) return rc;
+    for (size_t q = 0; q < who.size(); ++q) on_gpu_[static_cast<size_t>(who[q])] = okv[q] ? 1 : 0;
+    return IST_OK;
   }
-  // steps [from, to): 0 = container + host entropy stage, 1 = GPU Huffman, 2 = reconstruction + the image's event
-  void worker(int i, int from, int to) {
+  // container + host entropy stage of image i; a baseline JPEG's de-stuffed scan goes up on the image's own stream
+  void worker(int i) {
     const size_t k = static_cast<size_t>(i);
     Dec& D = dec_[k];
     DeviceGuard dg(ctx_->device);
     const uint8_t* f = files_[i]; const int64_t len = lens_[i];
     auto failed = [&](int rc) { D.rc = rc; D.err = g_last_error; };     // (thread-local message: carry it out)
-    if (from <= 0 && to > 0) {
-      if (D.jpeg) {
-        JpegImage full;
-        const int rc = jpeg_parse_and_entropy_decode(f, len, &full, false, gpu_huffman_ ? &D.G : nullptr);
-        if (rc) { failed(rc); return; }
-        if (full.width != D.w || full.height != D.h || full.ncomp != D.J.ncomp) { g_last_error = "JPEG frame header changed between two reads"; failed(IST_E_DECODE); return; }
-        D.J = std::move(full);
-      } else {
-        D.px.resize(static_cast<size_t>(D.w) * D.h * 4);
-        const int rc = ist_image_decode_rgba8(nullptr, f, len, D.px.data(), static_cast<size_t>(D.w) * 4, D.h);
-        if (rc) { failed(rc); return; }
-      }
+    if (!D.jpeg) {
+      D.px.resize(static_cast<size_t>(D.w) * D.h * 4);
+      const int rc = ist_image_decode_rgba8(nullptr, f, len, D.px.data(), static_cast<size_t>(D.w) * 4, D.h);
+      if (rc) failed(rc);
+      return;
     }
-    if (D.rc != IST_OK || !D.jpeg || !D.G.eligible) return;
+    JpegImage full;
+    const int rc = jpeg_parse_and_entropy_decode(f, len, &full, false, gpu_huffman_ ? &D.G : nullptr);
+    if (rc) { failed(rc); return; }
+    if (full.width != D.w || full.height != D.h || full.ncomp != D.J.ncomp) { g_last_error = "JPEG frame header changed between two reads"; failed(IST_E_DECODE); return; }
+    D.J = std::move(full);
+    if (!D.G.eligible) return;
+    // upload now (the other images are still being parsed); a failure here only means the batch uploads it itself
+    const size_t bytes = D.G.stream.size();
+    if (ctx_->img_huff_bytes[k] < bytes) {
+      dev_free(ctx_->img_huff[k]); ctx_->img_huff[k] = nullptr; ctx_->img_huff_bytes[k] = 0;
+      if (dev_malloc(&ctx_->img_huff[k], bytes + bytes / 4) != 0) { (void)hipGetLastError(); return; }
+      ctx_->img_huff_bytes[k] = bytes + bytes / 4;
+    }
     hipStream_t st = stream_of(i);
-    if (from <= 1 && to > 1) {
-      JpegGpuItem it; it.J = &D.J; it.S = &D.G;
-      for (int c = 0; c < 3; ++c) it.d_coef[c] = c < D.J.ncomp ? reinterpret_cast<int16_t*>(arena_ + jo_[k].coef[c]) : nullptr;
-      std::vector<uint8_t> okv;
-      const int rc = jpeg_gpu_entropy_decode(std::vector<JpegGpuItem>{it}, &okv, st, &ctx_->img_huff[k], &ctx_->img_huff_bytes[k]);
-      if (rc) { failed(rc); return; }
-      huff_ok_[k] = !okv.empty() && okv[0];
-      if (!huff_ok_[k]) return;                       // take() decodes it on the host
-    }
-    if (from <= 2 && to > 2 && huff_ok_[k]) {
-      const int rc = jpeg_enqueue(D.J, arena_, nullptr, jo_[k], img_[i], pitch_[i], st, true);
-      if (rc) { failed(rc); return; }
-      if (hipEventRecord(ctx_->img_event[k], st) != hipSuccess) { (void)hipGetLastError(); g_last_error = "hipEventRecord failed"; failed(IST_E_HIP); return; }
-      on_gpu_[k] = 1;
-    }
+    if (hipMemcpyAsync(ctx_->img_huff[k], D.G.stream.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipEventRecord(ctx_->img_event[k], st) != hipSuccess) { (void)hipGetLastError(); return; }
+    uploaded_[k] = 1;
   }
 
   ist_ctx* ctx_; const uint8_t* const* files_; const int64_t* lens_; int n_; Phases* ph_;
   std::vector<Dec> dec_;
   std::vector<std::thread> th_;
-  std::vector<char> on_gpu_, taken_;
+  std::vector<char> on_gpu_, taken_, uploaded_;
   std::vector<JpegDevLayout> jo_;
-  std::vector<char> huff_ok_;
   uint8_t* arena_ = nullptr; uint8_t* const* img_ = nullptr; const size_t* pitch_ = nullptr;
-  bool serial_ = false, gpu_huffman_ = true;
+  bool gpu_huffman_ = true, huff_done_ = false;
 };
 
 // One stitch cut into a background launch + one launch per draw (the same cut the device group uses, ist_shard_parts with a
@@ -934,6 +944,13 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   }
   rc = fd.start(d, img.data(), dpitch.data());          // the images decode from here on
   if (rc) return rc;
+  // Two streams: RENDER (Huffman batch, then per image: reconstruction + its band of the canvas) and ctx->stream (the PNG
+  // encoder, which waits for band k's event before it compresses the slabs that read it).  On one stream the reconstruction
+  // of image k+1 sat between the slabs of band k and band k+1 and cost its full time; on its own stream it runs beside them.
+  rc = ensure_aux(ctx);
+  if (rc) return rc;
+  if (!ctx->render && hipStreamCreateWithFlags(&ctx->render, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->render = nullptr; return fail(IST_E_HIP, "hipStreamCreate failed"); }
+  hipStream_t render = ph.on ? ctx->stream : ctx->render;
   // the stitch, cut per image (compiled while the workers parse): background now, band k when image k is there
   static const uint8_t transparent[4] = {0, 0, 0, 0};
   BandedJobs bj;
@@ -945,29 +962,38 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
     whole = ist_job_create(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, descs.data(), n, filter, nullptr);
     if (!whole) return g_last_code ? g_last_code : IST_E_INVALID;
   } else {
-    rc = ist_job_launch(bj.bg, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, ctx->stream);
+    rc = ist_job_launch(bj.bg, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, render);
     if (rc) return rc;
   }
   size_t next_part = 0;
   bool rendered_whole = false;
-  // canvas rows [0, y_end) are about to be read by work submitted to ctx->stream: render what they need first
+  // the export is about to read canvas rows [0, y_end) on ctx->stream: render what they need on the render stream and make
+  // ctx->stream wait for it
+  auto ordered = [&]() -> int {
+    if (render == ctx->stream) return IST_OK;
+    if (hipEventRecord(ctx->render_done, render) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->render_done, 0) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "ordering the export behind the render failed"); }
+    return IST_OK;
+  };
+  if (!ctx->render_done && hipEventCreateWithFlags(&ctx->render_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->render_done = nullptr; return fail(IST_E_HIP, "hipEventCreate failed"); }
   auto need_rows = [&](int64_t y_end) -> int {
     if (!bj.ok) {
       if (rendered_whole) return IST_OK;
-      int rc2 = fd.finish(ctx->stream);
+      int rc2 = fd.finish(render);
       if (rc2) return rc2;
       rendered_whole = true;
-      return ist_job_launch(whole, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, ctx->stream);
+      rc2 = ist_job_launch(whole, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, render);
+      return rc2 ? rc2 : ordered();
     }
+    bool any = false;
     while (next_part < bj.parts.size() && bj.parts[next_part].Y0 < y_end) {
       const ist_part& p = bj.parts[next_part];
-      int rc2 = fd.take(p.image, ctx->stream);
+      int rc2 = fd.take(p.image, render);
       if (rc2) return rc2;
-      rc2 = ist_job_launch(bj.band[next_part], dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, ctx->stream);
+      rc2 = ist_job_launch(bj.band[next_part], dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, render);
       if (rc2) return rc2;
-      ++next_part;
+      ++next_part; any = true;
     }
-    return IST_OK;
+    return (any || next_part == 0) ? ordered() : IST_OK;      // (next_part == 0: the background alone)
   };
   if (ph.on) {                                            // phase timing: the whole canvas first, then the export
     rc = need_rows(out_plan->canvas_h);
@@ -981,7 +1007,8 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   int64_t hint_rows = 0;
   for (const ist_part& p : bj.parts) hint_rows = std::max<int64_t>(hint_rows, p.Y1 - p.Y0);
   rc = png_to_host(ctx, d + o_canvas, canvas_pitch, out_plan->canvas_w, out_plan->canvas_h, d + o_png, &host, &len, need_rows, hint_rows);
-  if (rc == IST_OK) rc = fd.finish(ctx->stream);          // (images whose draw is clipped away entirely)
+  if (rc == IST_OK) rc = fd.finish(render);               // (images whose draw is clipped away entirely)
+  (void)hipStreamSynchronize(render);                     // nothing of this call runs on when the arena is handed to the next
   if (rc) { if (host) pool_give(host); (void)hipStreamSynchronize(ctx->stream); return rc; }
   ph.lap(IST_PHASE_PNG, "PNG encode (GPU) + D2H, overlapped", ctx->stream);
   ph.lap(IST_PHASE_D2H, "(D2H: inside the PNG phase)", nullptr);

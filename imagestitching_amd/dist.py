@@ -98,6 +98,22 @@ class ShardedStitch:
             need[p.image] = (min(a, p.sy0), max(b, p.sy1))
         return need
 
+    def root_rows(self):
+        """Host sink (the reference's export is host-destined, index.js:1577-1581): when every remote part spans the canvas
+        width, each rank can DMA its finished bands straight into its byte range of a host canvas; the root then delivers
+        only the canvas rows NO remote part covers.  Returns those row ranges [(y0, y1), ...], or None when some remote part
+        is not full-width (horizontal strips, centred rects: they need the gather)."""
+        if any(not p.in_place for p in self.remote):
+            return None
+        out, y = [], 0
+        for a, b in sorted((p.Y0, p.Y1) for p in self.remote):
+            if a > y:
+                out.append((y, a))
+            y = max(y, b)
+        if y < self.plan.canvas_h:
+            out.append((y, self.plan.canvas_h))
+        return out
+
     # ---- op lists ------------------------------------------------------------------------------------------------
     def band_ops(self, part):
         """ops + clip for rendering a part on its owner: white fill + that draw, clipped to the part's box."""
@@ -210,6 +226,20 @@ class HipBackend:
     def place(self, part, canvas):
         band = self.staging[part.index]
         self.place_jobs[part.index].launch_ptrs([band.data_ptr()], [band.stride(0)], canvas.data_ptr(), canvas.stride(0), self._stream())
+
+
+def run_step_host_sink(sh, backend, srcs, canvas, host_bands, host_canvas):
+    """One sharded stitch whose result is HOST-destined: no exchange at all.  Every rank renders its parts and copies each
+    finished band into `host_bands[part.index]` (pinned; in a deployment: the part's byte range of one shared pinned canvas);
+    the root renders its own launch into `canvas` and copies the rows no remote part covers into `host_canvas`.  Asynchronous
+    on the current stream.  Requires sh.root_rows() is not None."""
+    if sh.slot == 0:
+        backend.render_root(srcs, canvas)
+        for a, b in sh.root_rows():
+            host_canvas[a:b].copy_(canvas[a:b], non_blocking=True)
+        return
+    for p in sh.mine:
+        host_bands[p.index].copy_(backend.render_band(p, srcs), non_blocking=True)
 
 
 def run_step(sh, backend, srcs, canvas, dist):
