@@ -151,6 +151,9 @@ struct CompileKnobs {
   int stream_h = 8;                    // tile height
   double stream_min_k = 2.0;           // stream for |ky| >= this
   int64_t stream_cap = 12288;          // LDS words per workgroup that decide the tile width
+  int area_tile_h = 0;                 // AREA_STREAM: 0 = by the box height (see the cell classification); IST_AREA_TILE_H pins it
+  int area_passes = 1;                 // AREA_STREAM: most 64-lane passes of a tile's x footprint (IST_AREA_PASSES).  Measured (tools/sweep_area.py,
+                                       // 9 x 12 MP): one pass per tile 82 us on the Android plan against 164 us with two; iOS 125 / 124, 4x 86 / 84
 };
 bool tuning_mode() {
   static const bool on = [] { const char* e = std::getenv("IST_TUNING"); return e && *e && std::strcmp(e, "0") != 0; }();
@@ -168,6 +171,8 @@ static CompileKnobs read_knobs() {
   if ((e = std::getenv("IST_LDS_TILE_W")) != nullptr) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) k.lds_tile_w = v; }
   if ((e = std::getenv("IST_STREAM")) != nullptr) k.stream = std::min(8, std::max(0, std::atoi(e)));
   if ((e = std::getenv("IST_STREAM_MIN_K")) != nullptr) k.stream_min_k = std::atof(e);
+  if ((e = std::getenv("IST_AREA_TILE_H")) != nullptr) k.area_tile_h = std::min(64, std::max(0, std::atoi(e)));
+  if ((e = std::getenv("IST_AREA_PASSES")) != nullptr) k.area_passes = std::min(3, std::max(1, std::atoi(e)));
   if ((e = std::getenv("IST_STREAM_CAP")) != nullptr) k.stream_cap = std::max<int64_t>(1024, std::atoll(e) / 4);
   if ((e = std::getenv("IST_STREAM_H")) != nullptr) k.stream_h = std::min(64, std::max(4, std::atoi(e) & ~3));
   k.no_lds = std::getenv("IST_NO_LDS") != nullptr;
@@ -324,12 +329,12 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
         if (!(r.flags & (OPF_SWAP | OPF_FILL | OPF_HOLE)) && (bg_opaque || (r.flags & OPF_OPAQUE)) && r.cx1 >= r.cx0 && r.cy1 >= r.cy0 &&
             std::fabs(r.ky) <= 64.0) {
           // Tile width: the row sums (most of the work) run in 64-lane passes of 4 source pixels each, so the x footprint of a
-          // tile should fill its passes: of the widest tiles (<= 128 canvas pixels: 2 per lane) whose footprint fits one or two
-          // passes, the one with the most canvas pixels per pass.  LDS: 4 waves x footprint x float4 <= 32 KiB.
+          // tile should fill its pass: the widest tile (<= 128 canvas pixels: 2 per lane) whose footprint fits ONE pass of 256
+          // source pixels (two passes: a tuning knob; never faster, 2x slower at 6.6x).  LDS: 4 waves x 256 px x float4 = 16 KiB.
           const double akx = std::fabs(r.kx), bwx = std::max(akx, 1.0);
           auto foot_px = [&](int w) { return (static_cast<int64_t>(std::ceil((w - 1) * akx + bwx)) + 2 + 3) & ~3LL; };   // >= the kernel's
           int tw = 0; int64_t wl = 0; double best = 0.0;
-          for (int m = 1; m <= 2; ++m) {
+          for (int m = 1; m <= knobs.area_passes; ++m) {
             const double room = 256.0 * m - 3.0 - bwx;        // ceil(span) + 2 <= 256 m  with  span = (w - 1) |kx| + box
             if (room < 0.0) continue;
             const int w = static_cast<int>(std::min(128.0, std::floor(room / std::max(akx, 1e-9)) + 1.0));
@@ -342,7 +347,11 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
             for (int w = 16; w >= 1 && !tw; w >>= 1)
               if (foot_px(w) <= 768) { tw = w; wl = foot_px(w); }
           if (tw) {
-            cell.path = PATH_AREA_STREAM; cell.tile_w = tw; cell.tile_h = 16; cell.sub_h = 0;
+            // tile height: a wave owns every fourth row of the tile and reads ceil(|ky|) + 1 source rows per output row, one
+            // dependent round of loads per 4 of them; tall boxes get short tiles (more workgroups, one row per wave)
+            const int box_rows = static_cast<int>(std::ceil(std::max(std::fabs(r.ky), 1.0))) + 1;
+            const int th = knobs.area_tile_h ? knobs.area_tile_h : (box_rows <= 4 ? 16 : box_rows <= 6 ? 8 : 4);
+            cell.path = PATH_AREA_STREAM; cell.tile_w = tw; cell.tile_h = th; cell.sub_h = 0;
             out->lds_words = std::max<int32_t>(out->lds_words, static_cast<int32_t>(4 * 4 * wl));
             if (!bg_opaque) cell.bg = 0xFFFFFFFFu;            // never used: the draw is opaque
           }

@@ -32,6 +32,7 @@
 #include <string>
 #include <vector>
 
+#include "ist_host.h"
 #include "ist_internal.h"
 #include "ist_jpeg.h"
 
@@ -491,7 +492,6 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     if (S.slots < 1 || S.slots > 10) return fail(IST_E_DECODE, "JPEG scan with more than 10 blocks per MCU");
     if (S.stream.size() != static_cast<size_t>(S.bits / 8) + 16) return fail(IST_E_INVALID, "JPEG scan buffer without its padding");
     o_stream[k] = items[k].d_stream ? 0 : take(S.stream.size());
-    o_tab[k] = take(sizeof(S.tables));
     DevImg& I = H[k];
     std::memset(&I, 0, sizeof I);
     I.bits = S.bits;
@@ -512,7 +512,12 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   if (n_sub_total >= (1ll << 31) || n_img > 65535) return fail(IST_E_UNSUPPORTED, "too much JPEG data for one GPU entropy-decode batch");
   const int ns = static_cast<int>(n_sub_total);
   const int n_half = ns / kWriteThreads;            // groups of 128 subsequences (ns is a multiple of 256)
+  // the small inputs (Huffman tables, image records, the group -> image map) are ONE contiguous region, uploaded by ONE copy
+  // from a pinned block: as nine pageable copies of 10 KB each they were blocking staged copies, ~0.2 ms of the call
+  const size_t o_small = off;
+  for (size_t k = 0; k < n_img; ++k) o_tab[k] = take(sizeof(items[k].S->tables));
   const size_t o_img = take(sizeof(DevImg) * n_img), o_sub = take(2 * static_cast<size_t>(n_half));
+  const size_t small_bytes = off - o_small;
   const size_t o_p0 = take(4 * static_cast<size_t>(ns)), o_p1 = take(4 * static_cast<size_t>(ns)), o_cz0 = take(4 * static_cast<size_t>(ns)), o_cz1 = take(4 * static_cast<size_t>(ns));
   const size_t o_sp = take(4 * static_cast<size_t>(ns)), o_scz = take(4 * static_cast<size_t>(ns));
   const size_t o_checks = take(24 * static_cast<size_t>(ns));
@@ -532,11 +537,22 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     if (dev_malloc(reinterpret_cast<void**>(&d), off) != 0) { (void)hipGetLastError(); return fail(IST_E_NOMEM, "out of device memory for the Huffman decoder"); }
     fr.p = d;
   }
-  std::vector<uint16_t> half_img(static_cast<size_t>(n_half));           // image of every group of 128 subsequences
+  // pinned block: [small inputs | results: flag, half totals, error words]
+  const size_t res_bytes = 256 + 16 * static_cast<size_t>(n_half) + 4 * n_img;
+  struct Pin { uint8_t* p; ~Pin() { if (p) pool_give(p); } } pin{static_cast<uint8_t*>(pool_take(small_bytes + res_bytes))};
+  if (!pin.p) return fail(IST_E_NOMEM, "out of pinned host memory for the Huffman decoder");
+  // (every return below leaves the stream idle before `pin` goes back to the pool: the copies into it are waited for)
+  struct Idle { hipStream_t s; ~Idle() { (void)hipStreamSynchronize(s); } } idle{stream};
+  uint8_t* hs = pin.p;                                 // host image of the small-input region
+  volatile uint32_t* h_flag = reinterpret_cast<volatile uint32_t*>(pin.p + small_bytes);
+  uint32_t* h_half = reinterpret_cast<uint32_t*>(pin.p + small_bytes + 256);
+  uint32_t* h_err = h_half + 4 * static_cast<size_t>(n_half);
+  std::memset(hs, 0, small_bytes);
+  uint16_t* half_img = reinterpret_cast<uint16_t*>(hs + (o_sub - o_small));   // image of every group of 128 subsequences
   for (size_t k = 0; k < n_img; ++k) {
     const JpegGpuScan& S = *items[k].S;
     if (!items[k].d_stream) JG_HIP(hipMemcpyAsync(d + o_stream[k], S.stream.data(), S.stream.size(), hipMemcpyHostToDevice, stream));
-    JG_HIP(hipMemcpyAsync(d + o_tab[k], S.tables, sizeof(S.tables), hipMemcpyHostToDevice, stream));
+    std::memcpy(hs + (o_tab[k] - o_small), S.tables, sizeof(S.tables));
     H[k].stream = items[k].d_stream ? items[k].d_stream : d + o_stream[k];
     H[k].tables = reinterpret_cast<const JpegHuffTable*>(d + o_tab[k]);
     H[k].err = reinterpret_cast<uint32_t*>(d + o_err) + k;
@@ -544,8 +560,8 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     // (the writing pass stores every block of the planes whole, DC included: no clearing pass, no DC pass)
   }
   JG_HIP(hipMemsetAsync(d + o_err, 0, 4 * n_img, stream));
-  JG_HIP(hipMemcpyAsync(d + o_img, H.data(), sizeof(DevImg) * n_img, hipMemcpyHostToDevice, stream));
-  JG_HIP(hipMemcpyAsync(d + o_sub, half_img.data(), 2 * static_cast<size_t>(n_half), hipMemcpyHostToDevice, stream));
+  std::memcpy(hs + (o_img - o_small), H.data(), sizeof(DevImg) * n_img);
+  JG_HIP(hipMemcpyAsync(d + o_small, hs, small_bytes, hipMemcpyHostToDevice, stream));
   lap("alloc + uploads");
   const DevImg* d_img = reinterpret_cast<const DevImg*>(d + o_img);
   const uint16_t* d_sub = reinterpret_cast<const uint16_t*>(d + o_sub);
@@ -565,10 +581,10 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     JG_HIP(hipGetLastError());
     cur ^= 1;
     if (pass == 0) continue;                       // (the first launch starts from guesses: a second one always runs)
-    uint32_t flag = 1;
-    JG_HIP(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, stream));
+    *h_flag = 1u;
+    JG_HIP(hipMemcpyAsync(const_cast<uint32_t*>(h_flag), d_flag, 4, hipMemcpyDeviceToHost, stream));
     JG_HIP(hipStreamSynchronize(stream));
-    if (!flag) { converged = true; break; }
+    if (!*h_flag) { converged = true; break; }
   }
   if (timing) std::fprintf(stderr, "[ist timing] GPU Huffman: %d subsequences of %d bits, %s after %d launches\n", ns, kSubBits, converged ? "fixed point" : "NO fixed point", passes_run);
   if (!converged) { JG_HIP(hipStreamSynchronize(stream)); return IST_OK; }      // every ok[] stays 0: the host decodes
@@ -579,9 +595,9 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   JG_HIP(hipGetLastError());
   lap("write");
   // ---- validation: exactly the blocks the frame header promises, and nothing the host decoder would reject
-  std::vector<uint32_t> half(4 * static_cast<size_t>(n_half)), err(n_img);
-  JG_HIP(hipMemcpyAsync(half.data(), d_half, 16 * static_cast<size_t>(n_half), hipMemcpyDeviceToHost, stream));
-  JG_HIP(hipMemcpyAsync(err.data(), d + o_err, 4 * n_img, hipMemcpyDeviceToHost, stream));
+  const uint32_t* half = h_half; const uint32_t* err = h_err;
+  JG_HIP(hipMemcpyAsync(h_half, d_half, 16 * static_cast<size_t>(n_half), hipMemcpyDeviceToHost, stream));
+  JG_HIP(hipMemcpyAsync(h_err, d + o_err, 4 * n_img, hipMemcpyDeviceToHost, stream));
   JG_HIP(hipStreamSynchronize(stream));
   for (size_t k = 0; k < n_img; ++k) {
     const DevImg& I = H[k];

@@ -481,6 +481,10 @@ IST_DEV void tile_sample_lds(const LaunchArgs& A, const DevOp op, uint32_t bg, i
 // loads and stores together), so loads, LDS reads, arithmetic and stores of one wave overlap instead of alternating
 // between a load phase and a compute phase of the whole workgroup.  Adjacent output rows belong to different waves of
 // the workgroup and fetch their shared source row at about the same time: the second request is an L2 hit.
+// ORDERING RULE RELIED ON (MI355X_MICROARCH.md, "Per-instruction cycle constants"): "s_waitcnt vmcnt(N) waits until all but the
+// wave's N youngest vector-memory operations are done.  Loads, stores, atomics and LDS-DMA count together, in issue order
+// (flat_* excepted: out of order)".  Every access below is a global_* instruction (address-space-1 pointers / kernel
+// arguments), never flat_*.
 IST_DEV void wait_vm_upto(int n) {                 // wave-uniform n; waits until at most min(n, 24) operations remain
 #define IST_WAIT_CASE(K) case K: asm volatile("s_waitcnt vmcnt(" #K ")" ::: "memory"); break;
   switch (n) {
@@ -677,7 +681,8 @@ IST_DEV void tile_area_stream(const LaunchArgs& A, const DevOp op, uint32_t bg, 
 #pragma unroll
           for (int u = 0; u < kAreaRows; ++u) {
             if (yy + u > iy1) break;                        // (wave-uniform)
-            v[u] = ld16(src + static_cast<size_t>(min(max(yy + u, op.cy0), op.cy1)) * sp + static_cast<size_t>(xx) * 4);
+            // (plain, not non-temporal: the rows at the ends of the box are read again by the wave that owns the next output row)
+            v[u] = ld16_plain(src + static_cast<size_t>(min(max(yy + u, op.cy0), op.cy1)) * sp + static_cast<size_t>(xx) * 4);
           }
 #pragma unroll
           for (int u = 0; u < kAreaRows; ++u) {

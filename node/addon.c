@@ -572,7 +572,16 @@ static napi_value js_set_png_level(napi_env env, napi_callback_info info) {
   napi_value v; napi_get_undefined(env, &v); return v;
 }
 
+/* environment teardown: nothing of the library may still be in flight when the HIP runtime shuts down (include/imagestitch.h,
+ * ist_ctx_sync); the idle pinned result blocks go back to the system */
+static void on_env_cleanup(void* arg) {
+  (void)arg;
+  if (g_ctx) (void)ist_ctx_sync(g_ctx);
+  ist_pool_trim();
+}
+
 static napi_value init(napi_env env, napi_value exports) {
+  napi_add_env_cleanup_hook(env, on_env_cleanup, NULL);
   napi_property_descriptor props[] = {
       {"plan", NULL, js_plan, NULL, NULL, NULL, napi_default, NULL},
       {"stitch", NULL, js_stitch, NULL, NULL, NULL, napi_default, NULL},
