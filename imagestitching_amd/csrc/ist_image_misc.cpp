@@ -30,7 +30,10 @@ int bmp_header(const uint8_t* f, int64_t n, Bmp* B) {
   B->bpp = int(le16(f + 28)); B->comp = le32(f + 30); B->ncol = le32(f + 46);
   if (B->w < 1 || B->h < 1 || B->w > (1 << 29)) return fail(IST_E_DECODE, "bad BMP size");
   if (!(B->bpp == 1 || B->bpp == 4 || B->bpp == 8 || B->bpp == 16 || B->bpp == 24 || B->bpp == 32)) return fail(IST_E_UNSUPPORTED, "unsupported BMP bit depth");
-  if (B->comp != 0 && B->comp != 3) return fail(IST_E_UNSUPPORTED, "compressed (RLE) BMP is not supported");
+  // BI_RGB, BI_BITFIELDS, and the two run-length forms of palette images (BI_RLE8 on 8 bit, BI_RLE4 on 4 bit; always bottom-up)
+  const bool rle = (B->comp == 1 && B->bpp == 8) || (B->comp == 2 && B->bpp == 4);
+  if (B->comp != 0 && B->comp != 3 && !rle) return fail(IST_E_UNSUPPORTED, "this BMP compression (JPEG / PNG payload, or RLE on the wrong bit depth) is not supported");
+  if (rle && B->top_down) return fail(IST_E_DECODE, "run-length BMP cannot be top-down");
   if (B->comp == 3) {
     const uint8_t* m = f + 14 + 40;            // masks follow a 40-byte header, or live inside V4/V5 headers at the same offset
     if (14 + 40 + 12 > n) return fail(IST_E_DECODE, "truncated BMP masks");
@@ -55,10 +58,52 @@ inline uint8_t field(uint32_t v, uint32_t mask, int shift, int bits) {
   return bits >= 8 ? uint8_t(x >> (bits - 8)) : uint8_t((x * 255 + ((1u << bits) - 1) / 2) / ((1u << bits) - 1));
 }
 
+// BI_RLE8 / BI_RLE4: (count, value) pairs; count 0 escapes: 0 end of line, 1 end of bitmap, 2 delta (dx, dy), n >= 3 a literal
+// run of n pixels padded to 16 bits.  Pixels the stream never sets keep palette entry 0; runs are clipped at the row end.
+int bmp_decode_rle(const uint8_t* f, int64_t n, const Bmp& B, uint8_t* out, size_t pitch) {
+  if (B.off > n) return fail(IST_E_DECODE, "truncated BMP pixel data");
+  const uint8_t* pal = f + 14 + B.dib;
+  const uint32_t ncol = B.ncol ? B.ncol : (1u << B.bpp);
+  if (ncol > 256 || pal + 4 * size_t(ncol) > f + n) return fail(IST_E_DECODE, "truncated BMP palette");
+  if (int64_t(B.w) * B.h > (int64_t(1) << 31)) return fail(IST_E_UNSUPPORTED, "run-length BMP too large");
+  std::vector<uint8_t> idx;
+  try { idx.assign(size_t(B.w) * B.h, 0); } catch (const std::bad_alloc&) { return fail(IST_E_NOMEM, "out of memory for a BMP"); }
+  const uint8_t* p = f + B.off; const uint8_t* e = f + n;
+  int64_t x = 0, y = 0;                              // y counts rows from the BOTTOM
+  auto put = [&](uint32_t v) { if (x < B.w && y < B.h) idx[size_t(B.h - 1 - y) * B.w + size_t(x)] = uint8_t(v); ++x; };
+  bool done = false;
+  while (!done && p + 2 <= e) {
+    const int c = p[0], v = p[1]; p += 2;
+    if (c > 0) {
+      if (B.bpp == 8) for (int k = 0; k < c; ++k) put(uint32_t(v));
+      else for (int k = 0; k < c; ++k) put(uint32_t((k & 1) ? (v & 15) : (v >> 4)));
+    } else if (v == 0) { x = 0; ++y; }
+    else if (v == 1) done = true;
+    else if (v == 2) { if (p + 2 > e) return fail(IST_E_DECODE, "truncated run-length BMP"); x += p[0]; y += p[1]; p += 2; }
+    else {
+      const int64_t bytes = B.bpp == 8 ? v : (v + 1) / 2;
+      if (p + ((bytes + 1) & ~int64_t(1)) > e) return fail(IST_E_DECODE, "truncated run-length BMP");
+      for (int k = 0; k < v; ++k) put(B.bpp == 8 ? uint32_t(p[k]) : uint32_t((k & 1) ? (p[k / 2] & 15) : (p[k / 2] >> 4)));
+      p += (bytes + 1) & ~int64_t(1);
+    }
+    if (y >= B.h && !(c == 0 && v == 1)) { /* rows above the top are dropped; keep parsing until end of bitmap or data */ }
+  }
+  for (int yy = 0; yy < B.h; ++yy) {
+    uint8_t* o = out + size_t(yy) * pitch;
+    for (int xx = 0; xx < B.w; ++xx, o += 4) {
+      const uint32_t i = idx[size_t(yy) * B.w + size_t(xx)];
+      if (i >= ncol) return fail(IST_E_DECODE, "BMP palette index out of range");
+      o[0] = pal[4 * i + 2]; o[1] = pal[4 * i + 1]; o[2] = pal[4 * i]; o[3] = 255;
+    }
+  }
+  return IST_OK;
+}
+
 int bmp_decode(const uint8_t* f, int64_t n, uint8_t* out, size_t pitch) {
   Bmp B;
   int rc = bmp_header(f, n, &B);
   if (rc) return rc;
+  if (B.comp == 1 || B.comp == 2) return bmp_decode_rle(f, n, B, out, pitch);
   const size_t stride = ((size_t(B.w) * B.bpp + 31) / 32) * 4;
   if (int64_t(B.off) + int64_t(stride) * B.h > n) return fail(IST_E_DECODE, "truncated BMP pixel data");
   const uint8_t* pal = f + 14 + B.dib + (B.comp == 3 && B.dib == 40 ? 12 : 0);

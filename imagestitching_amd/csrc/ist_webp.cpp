@@ -9,7 +9,7 @@
 //
 // Host code: the stream is one serial entropy-coded sequence with LZ77 back-references and a colour cache, followed by
 // inverse transforms whose predictor depends on already reconstructed neighbours — like PNG, nothing to parallelise before
-// the pixels exist.  Animated files (ANIM / ANMF) are IST_E_UNSUPPORTED: a still Image shows one frame.
+// the pixels exist.  Animated files (ANIM / ANMF) decode to their FIRST frame on its transparent canvas: a still Image shows one frame.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -429,6 +429,9 @@ struct Riff {
   const uint8_t* alph = nullptr; size_t alph_n = 0;
   int canvas_w = 0, canvas_h = 0, orientation = 0;
   bool animated = false;
+  // an animated file shows its FIRST frame as a still image (what Image.src gives the page, utils/canvas.js:27-121): the
+  // frame's own bitstream chunks are picked up above; it sits at (fx, fy) of the canvas, the rest of which is transparent
+  bool frame = false; int fx = 0, fy = 0, fw = 0, fh = 0;
 };
 
 int parse_riff(const uint8_t* f, int64_t n, Riff* R) {
@@ -448,11 +451,33 @@ int parse_riff(const uint8_t* f, int64_t n, Riff* R) {
       if (len < 10) return fail(IST_E_DECODE, "bad WebP VP8X chunk");
       R->animated = (d[0] & 0x02) != 0;
       R->canvas_w = static_cast<int>(le24(d + 4)) + 1; R->canvas_h = static_cast<int>(le24(d + 7)) + 1;
-    } else if (!std::memcmp(tag, "ANIM", 4) || !std::memcmp(tag, "ANMF", 4)) R->animated = true;
+    } else if (!std::memcmp(tag, "ANIM", 4)) R->animated = true;
+    else if (!std::memcmp(tag, "ANMF", 4)) {
+      R->animated = true;
+      if (!R->frame) {                                        // the first frame: 16 header bytes, then its ALPH / VP8 / VP8L chunks
+        if (len < 16) return fail(IST_E_DECODE, "bad WebP ANMF chunk");
+        R->frame = true;
+        R->fx = 2 * static_cast<int>(le24(d)); R->fy = 2 * static_cast<int>(le24(d + 3));
+        R->fw = static_cast<int>(le24(d + 6)) + 1; R->fh = static_cast<int>(le24(d + 9)) + 1;
+        R->vp8 = R->vp8l = R->alph = nullptr;
+        int64_t q = 16;
+        while (q + 8 <= len) {
+          const uint8_t* t2 = d + q;
+          const int64_t l2 = le32(d + q + 4);
+          if (q + 8 + l2 > len) return fail(IST_E_DECODE, "truncated WebP frame chunk");
+          if (!std::memcmp(t2, "VP8L", 4)) { if (!R->vp8l && !R->vp8) { R->vp8l = t2 + 8; R->vp8l_n = static_cast<size_t>(l2); } }
+          else if (!std::memcmp(t2, "VP8 ", 4)) { if (!R->vp8l && !R->vp8) { R->vp8 = t2 + 8; R->vp8_n = static_cast<size_t>(l2); } }
+          else if (!std::memcmp(t2, "ALPH", 4)) { if (!R->alph) { R->alph = t2 + 8; R->alph_n = static_cast<size_t>(l2); } }
+          q += 8 + l2 + (l2 & 1);
+        }
+      }
+    }
     else if (!std::memcmp(tag, "EXIF", 4)) R->orientation = tiff_orientation(d, static_cast<size_t>(len));
     pos += 8 + len + (len & 1);
   }
-  if (R->animated) return fail(IST_E_UNSUPPORTED, "animated WebP is not supported (a still image has one frame)");
+  if (R->animated && !R->frame) return fail(IST_E_DECODE, "animated WebP without a frame");
+  if (R->frame && (R->canvas_w < 1 || R->canvas_h < 1 || R->fx + R->fw > R->canvas_w || R->fy + R->fh > R->canvas_h))
+    return fail(IST_E_DECODE, "WebP frame outside its canvas");
   if (!R->vp8l && !R->vp8) return fail(IST_E_DECODE, "WebP without image data");
   return IST_OK;
 }
@@ -471,7 +496,10 @@ int webp_info(const uint8_t* f, int64_t n, int32_t* w, int32_t* h, int32_t* orie
     rc = vp8l_decode(R.vp8l, R.vp8l_n, &iw, &ih, &none, true);
   } else rc = vp8_info(R.vp8, R.vp8_n, &iw, &ih);
   if (rc) return rc;
-  if (R.canvas_w && (R.canvas_w != iw || R.canvas_h != ih)) return fail(IST_E_DECODE, "WebP canvas and frame sizes differ");
+  if (R.frame) {
+    if (iw != R.fw || ih != R.fh) return fail(IST_E_DECODE, "WebP frame header and bitstream sizes differ");
+    iw = R.canvas_w; ih = R.canvas_h;
+  } else if (R.canvas_w && (R.canvas_w != iw || R.canvas_h != ih)) return fail(IST_E_DECODE, "WebP canvas and frame sizes differ");
   if (w) *w = iw;
   if (h) *h = ih;
   if (orientation) *orientation = R.orientation;
@@ -482,6 +510,13 @@ static int webp_decode_inner(const uint8_t* f, int64_t n, uint8_t* out, size_t p
   Riff R;
   int rc = parse_riff(f, n, &R);
   if (rc) return rc;
+  if (R.frame) {                                            // first frame of an animation, on its transparent canvas
+    if (!out || pitch < static_cast<size_t>(R.canvas_w) * 4 || out_rows < R.canvas_h) return fail(IST_E_INVALID, "output buffer too small");
+    for (int y = 0; y < R.canvas_h; ++y) std::memset(out + static_cast<size_t>(y) * pitch, 0, static_cast<size_t>(R.canvas_w) * 4);
+    out += static_cast<size_t>(R.fy) * pitch + static_cast<size_t>(R.fx) * 4;
+    out_rows = R.fh;
+    R.canvas_w = R.fw; R.canvas_h = R.fh;                   // below: the frame is the image
+  }
   int w = 0, h = 0;
   if (R.vp8l) {
     std::vector<uint32_t> px;

@@ -258,8 +258,8 @@ IST_API int ist_png_decode_rgba8(const uint8_t* file, int64_t len, uint8_t* out,
  * (0 when absent) - what getImageInfo feeds the planner (index.js:734).  Lossless / arithmetic-coded JPEG: IST_E_UNSUPPORTED. */
 IST_API int ist_jpeg_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation);
 IST_API int ist_jpeg_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch, int64_t out_rows);
-/* by signature: PNG, JPEG, BMP (uncompressed, 1-32 bit), GIF (first frame) or WebP (lossless VP8L and lossy VP8 key frames,
- * with or without an ALPH chunk; orientation from the container's EXIF chunk; animation: IST_E_UNSUPPORTED) - every
+/* by signature: PNG, JPEG, BMP (uncompressed 1-32 bit, bit fields, RLE8 / RLE4), GIF (first frame) or WebP (lossless VP8L and lossy
+ * VP8 key frames, with or without an ALPH chunk; orientation from the container's EXIF chunk; animation: the first frame) - every
  * raster member of SUPPORTED_IMAGE_TYPES (index.js:4).  ctx may be NULL for everything except JPEG (whose reconstruction
  * runs on the GPU). */
 IST_API int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int32_t* height, int32_t* orientation);

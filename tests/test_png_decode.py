@@ -234,3 +234,82 @@ def test_webp_and_garbage_are_named():
     assert e.value.code == -7 and "WebP" in str(e.value)
     with pytest.raises(ist.StitchError):
         ist.decode_image(b"GIF89a" + b"\x00" * 3)
+
+
+def _rle_bmp(idx, bpp, palette, with_delta=False):
+    """a BI_RLE8 / BI_RLE4 file of the index image `idx` (bottom-up rows): encoded runs, literal (absolute) runs with their
+    16-bit padding, end-of-line / end-of-bitmap escapes and - optionally - a delta escape that skips pixels"""
+    import struct
+    h, w = idx.shape
+    body = bytearray()
+    for r, row in enumerate(idx[::-1]):
+        x = 0
+        if with_delta and r == 0:             # bottom row: 5 single pixels, then a delta escape that skips 2 pixels (they stay palette entry 0)
+            for k in range(5):
+                body += bytes([1, int(row[k]) if bpp == 8 else int(row[k]) << 4])
+            body += b"\x00\x02\x02\x00"
+            x = 7
+        while x < w:
+            run = 1
+            while x + run < w and run < 255 and row[x + run] == row[x] and bpp == 8:
+                run += 1
+            if bpp == 4:                      # RLE4 runs alternate two nibbles: use runs of one colour pair
+                run = 1
+                while x + run < w and run < 254 and row[x + run] == row[x + (run & 1)]:
+                    run += 1
+            if run >= 3:
+                v = int(row[x]) if bpp == 8 else (int(row[x]) << 4 | int(row[x + 1] if run > 1 else 0))
+                body += bytes([run, v])
+                x += run
+            else:
+                n = min(w - x, 7)
+                if bpp == 4:
+                    n &= ~1                   # (PIL reads n // 2 bytes of an RLE4 literal run: an odd run is not a usable witness)
+                if n < 3:
+                    n = min(w - x, 2)                     # literal runs hold at least 3 pixels: emit short runs instead
+                    for k in range(n):
+                        body += bytes([1, int(row[x + k]) if bpp == 8 else int(row[x + k]) << 4])
+                else:
+                    body += bytes([0, n])
+                    if bpp == 8:
+                        lit = bytes(int(v) for v in row[x:x + n])
+                    else:
+                        px = [int(v) for v in row[x:x + n]] + [0]
+                        lit = bytes((px[2 * k] << 4) | px[2 * k + 1] for k in range((n + 1) // 2))
+                    body += lit + (b"\x00" if len(lit) & 1 else b"")
+                x += n
+        body += b"\x00\x00"                   # end of line
+    body += b"\x00\x01"                       # end of bitmap
+    ncol = len(palette) // 3
+    pal = b"".join(bytes([palette[3 * i + 2], palette[3 * i + 1], palette[3 * i], 0]) for i in range(ncol))
+    off = 14 + 40 + len(pal)
+    dib = struct.pack("<IiiHHIIiiII", 40, w, h, 1, bpp, 1 if bpp == 8 else 2, len(body), 2835, 2835, ncol, 0)
+    return b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + dib + pal + bytes(body)
+
+
+def test_run_length_bmp_matches_pil():
+    """BI_RLE8 / BI_RLE4 (VERDICT r02 'niche inputs the platform decoder accepts', index.js:4): runs, literal runs, escapes"""
+    for bpp, ncol in ((8, 200), (4, 16)):
+        pal = RNG.integers(0, 256, 3 * ncol, dtype=np.uint8).tolist()
+        flat = np.repeat(RNG.integers(0, ncol, (23, 9), dtype=np.uint8), 5, axis=1)[:, :41]      # runs of 5
+        noisy = RNG.integers(0, ncol, (17, 30), dtype=np.uint8)
+        for idx in (flat, noisy):
+            for delta in (False, True):
+                data = _rle_bmp(idx, bpp, pal, with_delta=delta)
+                ref = np.asarray(Image.open(io.BytesIO(data)).convert("RGBA"))
+                assert ist.image_info(data)[:2] == (idx.shape[1], idx.shape[0])
+                assert np.array_equal(ist.decode_image(data), ref), (bpp, delta)
+    # RLE4 literal runs with an ODD pixel count (padded nibble + 16-bit alignment), against the palette directly
+    import struct
+    pal16 = RNG.integers(0, 256, 48, dtype=np.uint8).tolist()
+    row = [7, 10, 0, 10, 6, 15, 1, 12, 4, 13, 0, 3]
+    body = bytes([0, 7, 0x7A, 0x0A, 0x6F, 0x10, 0, 5, 0xC4, 0xD0, 0x30, 0x00, 0, 0, 0, 1])
+    palb = b"".join(bytes([pal16[3 * i + 2], pal16[3 * i + 1], pal16[3 * i], 0]) for i in range(16))
+    off = 14 + 40 + 64
+    odd = b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + struct.pack("<IiiHHIIiiII", 40, 12, 1, 1, 4, 2, len(body), 2835, 2835, 16, 0) + palb + body
+    want = np.array([[pal16[3 * v:3 * v + 3] + [255] for v in row]], np.uint8)
+    assert np.array_equal(ist.decode_image(odd), want)
+    # truncated in the middle of a literal run
+    data = _rle_bmp(noisy, 8, pal)
+    with pytest.raises(ist.StitchError):
+        ist.decode_image(data[:len(data) - 40] if data[-41] != 0 else data[:len(data) - 39])

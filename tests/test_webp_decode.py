@@ -78,10 +78,10 @@ def test_webp_container_errors():
     a = _pictures()["smooth"]
     buf = _webp(a, "RGBA", lossless=True)
     payload = buf[20:20 + struct.unpack("<I", buf[16:20])[0]]
-    # animated: unsupported, named
+    # animated without any frame: damaged, named
     anim = _riff([(b"VP8X", bytes([0x02, 0, 0, 0]) + struct.pack("<I", a.shape[1] - 1)[:3] + struct.pack("<I", a.shape[0] - 1)[:3]), (b"ANIM", bytes(6)), (b"VP8L", payload)])
     rc, _, _ = _decode(anim)
-    assert rc == -7 and "animated" in L.last_error()
+    assert rc == -6 and "animated" in L.last_error()
     # canvas size in VP8X disagrees with the frame
     lie = _riff([(b"VP8X", bytes([0, 0, 0, 0]) + struct.pack("<I", 9)[:3] + struct.pack("<I", 9)[:3]), (b"VP8L", payload)])
     assert _decode(lie)[0] == -6
@@ -173,3 +173,42 @@ def test_lossy_webp_truncations_and_bit_flips_are_survived():
         for _ in range(int(rng.integers(1, 4))):
             b[int(rng.integers(20, len(b)))] ^= 1 << int(rng.integers(0, 8))
         assert _decode(bytes(b))[0] in (0, -6, -7, -1)
+
+
+def test_animated_webp_shows_its_first_frame():
+    """An animated file given to Image.src shows one frame (utils/canvas.js:27-121; 'webp' in index.js:4): the first ANMF frame on
+    its transparent canvas.  PIL (libwebp's animation decoder) is the witness for whole-canvas frames; a frame placed at an
+    offset is checked against the placement the container prescribes."""
+    pics = _pictures()
+    frames = [pics["smooth"], np.roll(pics["smooth"], 7, axis=1), np.roll(pics["smooth"], 9, axis=0)]
+    for kw in ({"lossless": True}, {"quality": 80}):
+        b = io.BytesIO()
+        Image.fromarray(frames[0], "RGBA").save(b, "WEBP", save_all=True, append_images=[Image.fromarray(f, "RGBA") for f in frames[1:]], duration=50, **kw)
+        buf = b.getvalue()
+        assert b"ANMF" in buf
+        im = Image.open(io.BytesIO(buf))
+        im.seek(0)
+        ref = np.asarray(im.convert("RGBA"))
+        rc, got, _ = _decode(buf)
+        assert rc == 0, L.last_error()
+        assert got.shape == ref.shape
+        if kw.get("lossless"):
+            assert np.array_equal(got, ref)
+        else:                                   # (libwebp's animation decoder blends the frame onto a canvas; alpha 0 pixels lose their colour there)
+            vis = ref[..., 3] > 0
+            assert np.array_equal(got[vis], ref[vis])
+    # a 20 x 10 frame at (6, 4) of a 40 x 30 canvas
+    small = np.ascontiguousarray(pics["noise"][:10, :20])
+    one = _webp(small, "RGBA", lossless=True, exact=True)
+    payload = one[20:20 + struct.unpack("<I", one[16:20])[0]] if one[12:16] == b"VP8L" else one[one.index(b"VP8L") + 8:]
+    p24 = lambda v: struct.pack("<I", v)[:3]      # noqa: E731
+    anmf = p24(3) + p24(2) + p24(19) + p24(9) + p24(100) + b"\x00" + b"VP8L" + struct.pack("<I", len(payload)) + payload + (b"\x00" if len(payload) & 1 else b"")
+    buf = _riff([(b"VP8X", bytes([0x12, 0, 0, 0]) + p24(39) + p24(29)), (b"ANIM", bytes(6)), (b"ANMF", anmf)])
+    rc, got, _ = _decode(buf)
+    assert rc == 0, L.last_error()
+    want = np.zeros((30, 40, 4), np.uint8)
+    want[4:14, 6:26] = small
+    assert np.array_equal(got, want)
+    # a frame that leaves its canvas is refused
+    bad = _riff([(b"VP8X", bytes([0x12, 0, 0, 0]) + p24(20) + p24(29)), (b"ANIM", bytes(6)), (b"ANMF", anmf)])
+    assert _decode(bad)[0] == -6

@@ -6,6 +6,7 @@ LABEL=${2:-"round 2"}
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench.err
 bash tools/profile_round.sh $TAG "$LABEL" > gpurun_out/${TAG}_round.log 2>&1
 bash tools/profile_plans.sh $TAG "$LABEL" > gpurun_out/${TAG}_plans.log 2>&1
+bash tools/profile_file_pipeline.sh $TAG > gpurun_out/${TAG}_file_pipeline.log 2>&1 || echo "file pipeline trace failed (see gpurun_out/${TAG}_file_pipeline.log)"
 python3 - <<PY
 import json
 d = json.loads(open("gpurun_out/${TAG}_bench_line.json").read().strip().splitlines()[-1])
