@@ -32,10 +32,11 @@ struct ist_ctx {
   void* scratch_ent = nullptr; size_t scratch_ent_bytes = 0;   // sparse coefficient entries of host-decoded JPEGs (progressive, restart intervals)
   hipStream_t render = nullptr;          // file pipeline: Huffman batch + per-image reconstruction + band launches, beside the PNG encoder on `stream`
   hipEvent_t render_done = nullptr;
+  hipStream_t png2 = nullptr;            // the compressing PNG encoder alternates its slabs between `stream` and this one
   hipStream_t aux = nullptr;             // second stream of the host-path entry points (PNG slabs travel on it while later ones compress)
   // device blocks of destroyed jobs' tables, re-used by the next job of this context instead of a hipMalloc + hipFree pair
-  // per job (a free also synchronises the device); at most kTablePool blocks are kept
-  static constexpr int kTablePool = 8;
+  // per job (a free also synchronises the device); at most kTablePool blocks are kept (the file pipeline compiles one job per image + one)
+  static constexpr int kTablePool = 32;
   struct TableBlock { uint8_t* p; size_t bytes; };
   std::vector<TableBlock> table_pool;
   std::mutex table_mu;

@@ -120,12 +120,13 @@ int resolve_op(const ist_op& op, int64_t canvas_w, int64_t canvas_h, int img_w, 
 int64_t png_deflate_bound(int64_t w, int64_t h);
 // host_out (pinned, out_cap bytes) + aux stream, both optional: the file also lands in host memory, slab by slab, while
 // later slabs are still being compressed
-// need_rows (optional): called with y before work that reads canvas rows [0, y) is submitted to `stream` - a producer that
-// renders the canvas band by band submits the missing bands to `stream` there.  slab_rows_hint (optional): canvas rows a
-// slab should cover (the producer's band height), so that slab boundaries fall on band boundaries.
+// need_rows (optional): called with (y, s) before work that reads canvas rows [0, y) is submitted to stream s (`stream` or
+// `stream2`) - a producer that renders the canvas band by band submits the missing bands there / orders s behind them.
+// slab_rows_hint (optional): canvas rows a slab should cover (the producer's band height), so that slab boundaries fall on
+// band boundaries.  stream2 (optional, with host_out): slabs alternate between the two streams.
 int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* out, int64_t out_cap,
                               int64_t* out_len, void* stream, uint8_t* host_out, void* aux,
-                              const std::function<int(int64_t)>& need_rows = nullptr, int64_t slab_rows_hint = 0);
+                              const std::function<int(int64_t, void*)>& need_rows = nullptr, int64_t slab_rows_hint = 0, void* stream2 = nullptr);
 int ctx_png_level(const ist_ctx* ctx);
 int ctx_png_scratch(ist_ctx* ctx, size_t need, void** p);   // the context's grow-only PNG scratch (kept across calls)
 

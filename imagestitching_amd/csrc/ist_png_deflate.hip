@@ -124,13 +124,26 @@ __device__ __forceinline__ void flush_run(uint32_t v, int run, int* bits, uint32
   }
 }
 
+// The span lives in REGISTERS (16 dwords): the LDS image of the filtered chunk is dead once every thread holds its span, so
+// the output bit buffer takes its place (one 17 KiB buffer instead of two: 6 workgroups per CU instead of 4 - the kernel's
+// clock is LDS latency, so residency is throughput).  The walk's dword loop has a wave-uniform trip count, which makes the
+// register pick a scalar jump.
+__device__ __forceinline__ uint32_t span_word(const uint32_t (&sp)[16], int d) {
+  switch (d) {
+    case 0: return sp[0]; case 1: return sp[1]; case 2: return sp[2]; case 3: return sp[3];
+    case 4: return sp[4]; case 5: return sp[5]; case 6: return sp[6]; case 7: return sp[7];
+    case 8: return sp[8]; case 9: return sp[9]; case 10: return sp[10]; case 11: return sp[11];
+    case 12: return sp[12]; case 13: return sp[13]; case 14: return sp[14]; default: return sp[15];
+  }
+}
+
 template <int PASS>
-__device__ __forceinline__ int walk_span(const uint8_t* f, int n, uint32_t* hist, const uint32_t* clen, const uint32_t* code, BitWriter* bw) {
+__device__ __forceinline__ int walk_span(const uint32_t (&sp)[16], int n, uint32_t* hist, const uint32_t* clen, const uint32_t* code, BitWriter* bw) {
   int bits = 0, run = 0;
   uint32_t v = 0;
-  const uint32_t* fw = reinterpret_cast<const uint32_t*>(f);
-  for (int d = 0; 4 * d < n; ++d) {
-    const uint32_t w = fw[d];
+#pragma unroll 1
+  for (int d = 0; d < 16; ++d) {
+    const uint32_t w = span_word(sp, d);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (4 * d + k < n) {
@@ -145,8 +158,12 @@ __device__ __forceinline__ int walk_span(const uint8_t* f, int n, uint32_t* hist
 }
 
 __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) {
-  __shared__ __attribute__((aligned(16))) uint8_t filt[PADDED];
-  __shared__ __attribute__((aligned(16))) uint32_t outw[SLOT / 4];
+  // ONE buffer, two lives: the filtered chunk (padded layout) until every thread has taken its span into registers, then the
+  // Huffman scratch and the output bit stream
+  static_assert(PADDED >= SLOT, "the output buffer aliases the filtered chunk");
+  __shared__ __attribute__((aligned(16))) uint32_t buf[PADDED / 4];
+  uint8_t* const filt = reinterpret_cast<uint8_t*>(buf);
+  uint32_t* const outw = buf;
   // one LDS area, two lives: histogram / code lengths / codes / sort keys while the block is built, then the CRC tables
   __shared__ __attribute__((aligned(16))) uint32_t area[3 * 288 + 512];
   uint32_t* const hist = area; uint32_t* const clen = area + 288; uint32_t* const code = area + 576; uint32_t* const keys = area + 864;
@@ -171,7 +188,6 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
   const int rowlen = hasf + 4 * npr;
   const int len = rowlen * nrows;                // <= CH by construction
 
-  for (int i = tid; i < SLOT / 4; i += 256) outw[i] = 0;
   for (int i = tid; i < 288; i += 256) { hist[i] = 0; clen[i] = 0; code[i] = 0; }
   if (P.dbg && tid == 0) P.dbg[chunk * 8 + 0] = wall_clock64();
   // ---- A. load + Paeth filter into LDS
@@ -214,11 +230,25 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
   // ---- B. histogram (+ the end-of-block symbol), Adler partials
   const int base = tid * SPAN;
   const int n = max(0, min(SPAN, len - base));
-  const uint8_t* my = filt + tid * (SPAN + 4);
-  walk_span<0>(my, n, hist, nullptr, nullptr, nullptr);
+  uint32_t sp[16];
+  {
+    const u32x4* mine = reinterpret_cast<const u32x4*>(filt + tid * (SPAN + 4));      // (68-byte pitch: 4-byte aligned)
+    const uint32_t* mw = reinterpret_cast<const uint32_t*>(mine);
+#pragma unroll
+    for (int d = 0; d < 16; ++d) sp[d] = mw[d];
+  }
+  __syncthreads();                                   // every span is in registers: the buffer is free
+  walk_span<0>(sp, n, hist, nullptr, nullptr, nullptr);
   if (tid == 0) atomicAdd(&hist[256], 1u);
   uint32_t a1 = 0, a2 = 0;
-  for (int i = 0; i < n; ++i) { a1 += my[i]; a2 += static_cast<uint32_t>(len - (base + i)) * my[i]; }
+#pragma unroll
+  for (int d = 0; d < 16; ++d)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = 4 * d + k;
+      const uint32_t b = i < n ? (sp[d] >> (8 * k)) & 255u : 0u;
+      a1 += b; a2 += static_cast<uint32_t>(len - (base + i)) * b;
+    }
   a2 %= 65521u;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); }
@@ -346,7 +376,7 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
 
   if (P.dbg && tid == 0) P.dbg[chunk * 8 + 3] = wall_clock64();
   // ---- D. bits per thread, exclusive scan, choice between the Huffman and the stored form
-  const int mybits = skip ? 0 : walk_span<1>(my, n, nullptr, clen, nullptr, nullptr);
+  const int mybits = skip ? 0 : walk_span<1>(sp, n, nullptr, clen, nullptr, nullptr);
   int incl = mybits;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
       or_bits(outw, hb + 17 + 57 + 4 * s, rev_bits(l, 4), 4);
     }
     BitWriter bw; bw.init(outw, my_start);
-    walk_span<2>(my, n, nullptr, clen, code, &bw);
+    walk_span<2>(sp, n, nullptr, clen, code, &bw);
     bw.flush();
     if (tid == 0) or_bits(outw, end_bit - static_cast<int>(clen[256]), code[256], static_cast<int>(clen[256]));
     body_end = (end_bit + 3 + 7) / 8;                 // 3 zero bits: BFINAL 0, BTYPE 00; then to the byte boundary
@@ -392,7 +422,11 @@ __global__ __launch_bounds__(256) void ist_png_deflate_kernel(const DeflArgs P) 
       uint8_t* q = outb + lead;
       q[0] = 0; q[1] = len & 0xFF; q[2] = (len >> 8) & 0xFF; q[3] = (~len) & 0xFF; q[4] = ((~len) >> 8) & 0xFF;
     }
-    for (int i = 0; i < n; ++i) outb[lead + 5 + base + i] = my[i];
+#pragma unroll
+    for (int d = 0; d < 16; ++d)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (4 * d + k < n) outb[lead + 5 + base + 4 * d + k] = static_cast<uint8_t>(sp[d] >> (8 * k));
     body_end = lead + 5 + len;
   }
   __syncthreads();
@@ -478,12 +512,16 @@ int64_t png_deflate_bound(int64_t w, int64_t h) {
 // 439 MB photo canvas) then hides behind the encoder (3.3 ms) instead of following it.  Each slab is its own IDAT chunk.
 int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* out, int64_t out_cap,
                               int64_t* out_len, void* stream_, uint8_t* host_out, void* aux_,
-                              const std::function<int(int64_t)>& need_rows, int64_t slab_rows_hint) {
+                              const std::function<int(int64_t, void*)>& need_rows, int64_t slab_rows_hint, void* stream2_) {
   const ChunkGrid g = make_grid(w, h);
   if (g.n_chunks > 2147483647ll) return fail(IST_E_OUTPUT_SIZE, "image too large for one PNG launch");
   if (png_deflate_bound(w, h) > out_cap) return fail(IST_E_INVALID, "PNG output buffer too small (see ist_png_bound)");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   hipStream_t aux = host_out ? static_cast<hipStream_t>(aux_) : stream;
+  // slabs alternate between two streams (when the caller has a second one): consecutive kernels of ONE stream do not overlap,
+  // so every slab paid its own tail - the last, partly filled round of workgroups - with the rest of the chip idle; on two
+  // streams slab s+1 fills in as slab s drains (a slab is ~3 rounds of workgroups: measured 0.59 ms per 3024-chunk slab alone)
+  hipStream_t stream2 = (host_out && stream2_) ? static_cast<hipStream_t>(stream2_) : stream;
   static CrcTables T;
   static std::vector<uint32_t> xpow;
   static std::once_flag once;
@@ -505,8 +543,17 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
     const int64_t rows_chunks = g.pieces_per_row > 0 ? slab_rows_hint * g.pieces_per_row : (slab_rows_hint + g.rows_per_chunk - 1) / std::max(1, g.rows_per_chunk);
     slab_chunks = static_cast<size_t>(std::min<int64_t>(4096, std::max<int64_t>(1024, rows_chunks)));
   }
-  const size_t n_slabs = host_out ? (n + slab_chunks - 1) / slab_chunks : 1;
-  const size_t per_slab = host_out ? slab_chunks : n;
+  // slab s = chunks [slab_at[s], slab_at[s + 1]).  The FIRST slab is short: nothing crosses PCIe before it has been compressed,
+  // laid out and gathered, so its size is the fill time of the pipeline (0.66 ms with a full first slab sharing the chip with
+  // the second: measured); behind it the copies are back to back
+  std::vector<size_t> slab_at{0};
+  if (host_out) {
+    const size_t first = std::min<size_t>(n, std::min<size_t>(slab_chunks, 768));
+    for (size_t c = first; c < n; c += slab_chunks) slab_at.push_back(c);
+  }
+  slab_at.push_back(n);
+  const size_t n_slabs = slab_at.size() - 1;
+  const size_t per_slab = host_out ? slab_chunks : n;          // the largest slab (sizes the per-slab result arrays)
   // the last canvas row (exclusive) chunks [0, c_end) read
   auto rows_of = [&](size_t c_end) -> int64_t {
     const int64_t r = g.pieces_per_row > 0 ? (static_cast<int64_t>(c_end) + g.pieces_per_row - 1) / g.pieces_per_row : static_cast<int64_t>(c_end) * g.rows_per_chunk;
@@ -525,11 +572,15 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
 #define PNG_HIP(e) do { const hipError_t e_ = (e); if (e_ != hipSuccess) return fail(IST_E_HIP, std::string(#e) + ": " + hipGetErrorString(e_)); } while (0)
   PNG_HIP(hipMemcpyAsync(scratch + o_T, &T, sizeof T, hipMemcpyHostToDevice, stream));
   PNG_HIP(hipMemcpyAsync(scratch + o_pow, xpow.data(), 4 * xpow.size(), hipMemcpyHostToDevice, stream));
+  if (stream2 != stream) PNG_HIP(hipStreamSynchronize(stream));      // (both are blocking staged copies of static data: the tables are in place for either stream)
   // ---- every slab's compression goes out now, each followed by the copy of its per-chunk results and an event
   // (pinned: a device-to-host copy into pageable memory would block this thread until the slab is compressed, and the
   // slabs' launches would no longer run ahead of the host)
   struct Events { std::vector<hipEvent_t> ev; ~Events() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); } } evs;   // (a slab that was never launched has no event: destroying NULL would leave a sticky error for the next launch check)
   evs.ev.assign(n_slabs, nullptr);
+  Events gathered;
+  gathered.ev.assign(n_slabs, nullptr);
+
   struct Pinned { uint8_t* p; ~Pinned() { if (p) pool_give(p); } } res{static_cast<uint8_t*>(pool_take(20 * per_slab * n_slabs))};
   if (!res.p) return fail(IST_E_NOMEM, "out of pinned host memory for the PNG encoder");
   // file offset of every chunk: pinned host memory the gather kernel reads in place (a pageable source would cost one small
@@ -541,21 +592,22 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
   // per-chunk results into `res` and read `dstp` in place, and a block given back to the pool while slab s+1 is still
   // compressing could be handed to another thread's call.  (Declared after the two blocks: destroyed before them.)
   struct Drain {
-    hipStream_t a, b; unsigned long long** dbg; bool armed = true;
+    hipStream_t a, b, c; unsigned long long** dbg; bool armed = true;
     ~Drain() {
-      if (armed) { (void)hipStreamSynchronize(a); if (b != a) (void)hipStreamSynchronize(b); }
+      if (armed) { (void)hipStreamSynchronize(a); if (b != a) (void)hipStreamSynchronize(b); if (c != a && c != b) (void)hipStreamSynchronize(c); }
       if (*dbg) { dev_free(*dbg); *dbg = nullptr; }
     }
-  } drain{stream, aux, &d_dbg};
+  } drain{stream, aux, stream2, &d_dbg};
   static const bool phases = tuning_mode() && std::getenv("IST_PNG_PHASES") != nullptr;      // (IST_TUNING=1 processes only)
   if (phases && dev_malloc(reinterpret_cast<void**>(&d_dbg), 64 * n) != hipSuccess) d_dbg = nullptr;
   // test knob (IST_TUNING=1 IST_PNG_FAIL_AT=<slab>): fail the layout of that slab the way a damaged result would, so that the
   // error path above is exercised with kernels in flight
   static const long fail_at = (tuning_mode() && std::getenv("IST_PNG_FAIL_AT")) ? std::atol(std::getenv("IST_PNG_FAIL_AT")) : -1;
   auto compress = [&](size_t s) -> int {
-    const size_t c0 = s * per_slab, cn = std::min(per_slab, n - c0);
+    const size_t c0 = slab_at[s], cn = slab_at[s + 1] - c0;
     // (the Paeth filter of a chunk's first row reads the row above it: that row belongs to an earlier slab, already asked for)
-    if (need_rows) { const int rc = need_rows(rows_of(c0 + cn)); if (rc) return rc; }
+    hipStream_t st = (s & 1) ? stream2 : stream;
+    if (need_rows) { const int rc = need_rows(rows_of(c0 + cn), st); if (rc) return rc; }
     // the kernel writes its per-chunk results straight into the pinned host block (visible to the host behind the event).
     // As small device-to-host COPIES on this stream they shared the copy engine's queue with the slabs' big copies on the
     // aux stream: each big copy then took 0.9 ms instead of 0.4 and the PNG phase 6.8 ms instead of 3.4 (measured)
@@ -570,10 +622,10 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
     A.rows_per_chunk = g.rows_per_chunk; A.pieces_per_row = g.pieces_per_row; A.piece_px = g.piece_px;
     A.chunk0 = static_cast<int64_t>(c0);
     A.dbg = d_dbg;
-    hipLaunchKernelGGL(ist_png_deflate_kernel, dim3(static_cast<unsigned>(cn)), dim3(256), 0, stream, A);
+    hipLaunchKernelGGL(ist_png_deflate_kernel, dim3(static_cast<unsigned>(cn)), dim3(256), 0, st, A);
     PNG_HIP(hipGetLastError());
     PNG_HIP(hipEventCreateWithFlags(&evs.ev[s], hipEventDisableTiming));
-    PNG_HIP(hipEventRecord(evs.ev[s], stream));
+    PNG_HIP(hipEventRecord(evs.ev[s], st));
     return IST_OK;
   };
   // one slab ahead: slab s+1 is compressing while the host lays out slab s and the aux stream carries it away
@@ -627,7 +679,7 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
     pos += 4;
   };
   for (size_t s = 0; s < n_slabs; ++s) {
-    const size_t c0 = s * per_slab, cn = std::min(per_slab, n - c0);
+    const size_t c0 = slab_at[s], cn = slab_at[s + 1] - c0;
     if (s + 1 < n_slabs) { const int rc = compress(s + 1); if (rc) return rc; }
     PNG_HIP(hipEventSynchronize(evs.ev[s]));
     if (fail_at >= 0 && static_cast<size_t>(fail_at) == s) return fail(IST_E_HIP, "PNG deflate kernel returned an impossible chunk length (forced: IST_PNG_FAIL_AT)");
@@ -669,10 +721,22 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
       pos += 12;
     } else close_idat();
     if (pos > out_cap) return fail(IST_E_INVALID, "PNG output buffer too small (see ist_png_bound)");
-    // the aux stream may start on this slab: its slots and results are complete (the event above has passed)
+    // The gather rides on the stream that compressed the slab (its slots and results are complete: the event above has passed;
+    // the next slab is already compressing on the other stream), and the aux stream carries NOTHING but the slabs' trips over
+    // PCIe, each behind its gather's event.  With gather and copy both on aux every slab cost gather + copy in series (0.1 +
+    // 0.3 ms, nine times: the whole phase was that stream, 4.0 ms for 2.75 ms of PCIe - measured, rocprofv3 timeline).
+    // (Tried and dropped: the gather writing straight into the pinned file image with a small grid, no device image and no
+    // copy - 4-byte-aligned 16-byte stores over PCIe from 128 workgroups were slower than gather + the runtime's copy: the phase
+    // went from 3.66 to 4.23 ms.)
+    hipStream_t gs = host_out ? ((s & 1) ? stream2 : stream) : aux;
     GatherArgs G{scratch + o_slots, static_cast<uint8_t*>(out), dst, reinterpret_cast<const uint32_t*>(res.p + 20 * per_slab * s) - c0, static_cast<int64_t>(c0)};
-    hipLaunchKernelGGL(ist_png_gather_kernel, dim3(static_cast<unsigned>(cn)), dim3(256), 0, aux, G);
+    hipLaunchKernelGGL(ist_png_gather_kernel, dim3(static_cast<unsigned>(cn)), dim3(256), 0, gs, G);
     PNG_HIP(hipGetLastError());
+    if (host_out) {
+      PNG_HIP(hipEventCreateWithFlags(&gathered.ev[s], hipEventDisableTiming));
+      PNG_HIP(hipEventRecord(gathered.ev[s], gs));
+      PNG_HIP(hipStreamWaitEvent(aux, gathered.ev[s], 0));
+    }
     if (!host_out)                                     // (with a host sink the headers are written there, below)
       for (const Patch& pt : patches)
         PNG_HIP(hipMemcpyAsync(static_cast<uint8_t*>(out) + pt.at, pt.b, static_cast<size_t>(pt.n), hipMemcpyHostToDevice, aux));
@@ -685,7 +749,8 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
   }
   PNG_HIP(hipStreamSynchronize(aux));
   if (aux != stream) PNG_HIP(hipStreamSynchronize(stream));
-  drain.armed = false;                                 // both streams are idle
+  if (stream2 != stream) PNG_HIP(hipStreamSynchronize(stream2));
+  drain.armed = false;                                 // the streams are idle
   if (d_dbg) {
     std::vector<unsigned long long> hdbg(8 * n);
     (void)hipMemcpy(hdbg.data(), d_dbg, 64 * n, hipMemcpyDeviceToHost);

@@ -89,7 +89,7 @@ int ensure_aux(ist_ctx* ctx) {
 // while it is still compressing (png_encode_device_deflate); the stored form is encoded whole and copied once.
 // Caller holds ctx->mu.  Synchronises ctx->stream.
 int png_to_host(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64_t h, void* dfile, uint8_t** out_png, int64_t* out_len,
-                const std::function<int(int64_t)>& need_rows = nullptr, int64_t slab_rows_hint = 0) {
+                const std::function<int(int64_t, void*)>& need_rows = nullptr, int64_t slab_rows_hint = 0) {
   const int64_t cap = ist_png_bound(w, h);
   if (!dfile) {
     const int rc = grow_device(&ctx->scratch_file, &ctx->scratch_file_bytes, static_cast<size_t>(cap));
@@ -101,12 +101,13 @@ int png_to_host(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64
     { const int rc = ensure_aux(ctx); if (rc) return rc; }
     uint8_t* host = static_cast<uint8_t*>(pool_take(static_cast<size_t>(cap)));
     if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
-    const int rc = png_encode_device_deflate(ctx, canvas, pitch, w, h, dfile, cap, &len, ctx->stream, host, ctx->aux, need_rows, slab_rows_hint);
-    if (rc) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamSynchronize(ctx->stream); pool_give(host); return rc; }
+    if (!ctx->png2 && hipStreamCreateWithFlags(&ctx->png2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->png2 = nullptr; }   // (without it the slabs share one stream)
+    const int rc = png_encode_device_deflate(ctx, canvas, pitch, w, h, dfile, cap, &len, ctx->stream, host, ctx->aux, need_rows, slab_rows_hint, ctx->png2);
+    if (rc) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamSynchronize(ctx->stream); if (ctx->png2) (void)hipStreamSynchronize(ctx->png2); pool_give(host); return rc; }
     *out_png = host; *out_len = len;
     return IST_OK;
   }
-  int rc = need_rows ? need_rows(h) : IST_OK;            // (the stored form reads the whole canvas in one pass)
+  int rc = need_rows ? need_rows(h, ctx->stream) : IST_OK;   // (the stored form reads the whole canvas in one pass)
   if (rc) return rc;
   rc = ist_png_encode_device(ctx, canvas, pitch, w, h, dfile, cap, &len, ctx->stream);
   if (rc) return rc;
@@ -156,6 +157,8 @@ int ist_ctx_sync(ist_ctx* ctx) {
   DeviceGuard g(ctx->device);
   bool ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
   if (ctx->aux) ok = (hipStreamSynchronize(ctx->aux) == hipSuccess) && ok;
+  if (ctx->render) ok = (hipStreamSynchronize(ctx->render) == hipSuccess) && ok;
+  if (ctx->png2) ok = (hipStreamSynchronize(ctx->png2) == hipSuccess) && ok;
   if (ctx->stager) ok = (ctx->stager->sync() == IST_OK) && ok;
   if (!ok) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipStreamSynchronize failed"); }
   return IST_OK;
@@ -179,6 +182,7 @@ void ist_ctx_destroy(ist_ctx* ctx) {
   for (void* q : ctx->img_huff) dev_free(q);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
   if (ctx->render) { (void)hipStreamSynchronize(ctx->render); (void)hipStreamDestroy(ctx->render); }
+  if (ctx->png2) { (void)hipStreamSynchronize(ctx->png2); (void)hipStreamDestroy(ctx->png2); }
   if (ctx->render_done) (void)hipEventDestroy(ctx->render_done);
   for (const ist_ctx::TableBlock& b : ctx->table_pool) dev_free(b.p);
   ctx->stager.reset();
@@ -461,7 +465,11 @@ void jpeg_layout_sparse(const JpegImage& J, size_t* off, JpegDevLayout* L) {
 }
 
 // H2D of the coefficients (sparse entries are scattered into a zeroed plane on the GPU) + the reconstruction launches
-int jpeg_enqueue(const JpegImage& J, uint8_t* d, uint8_t* d_ent, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch, hipStream_t stream, bool coef_on_device = false) {
+// q_pinned (optional): 3 x 128 bytes of PINNED host memory the quantisation tables are staged in, so that their upload is a real
+// asynchronous copy (from pageable memory every 128-byte table is a blocking staged copy: ~0.7 ms of host time for nine images,
+// measured, which held back everything submitted behind them)
+int jpeg_enqueue(const JpegImage& J, uint8_t* d, uint8_t* d_ent, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch, hipStream_t stream, bool coef_on_device = false,
+                 uint8_t* q_pinned = nullptr) {
   JpegDeviceJob job;
   job.width = J.width; job.height = J.height; job.ncomp = J.ncomp; job.hmax = J.hmax; job.vmax = J.vmax;
   for (int c = 0; c < 3; ++c) { job.d_coef[c] = nullptr; job.d_q[c] = nullptr; job.d_plane[c] = nullptr; job.h[c] = job.v[c] = 1; job.blocks_x[c] = job.blocks_y[c] = 0; }
@@ -483,7 +491,9 @@ int jpeg_enqueue(const JpegImage& J, uint8_t* d, uint8_t* d_ent, const JpegDevLa
       if (C.coef.size() != nblk * 64) return fail(IST_E_DECODE, "JPEG component without coefficients");
       IST_HIP(hipMemcpyAsync(d_coef, C.coef.data(), nblk * 128, hipMemcpyHostToDevice, stream));
     }
-    IST_HIP(hipMemcpyAsync(d + L.q[c], C.q, 128, hipMemcpyHostToDevice, stream));
+    const void* qsrc = C.q;
+    if (q_pinned) { std::memcpy(q_pinned + 128 * c, C.q, 128); qsrc = q_pinned + 128 * c; }
+    IST_HIP(hipMemcpyAsync(d + L.q[c], qsrc, 128, hipMemcpyHostToDevice, stream));
     job.d_coef[c] = d_coef;
     job.d_q[c] = reinterpret_cast<const uint16_t*>(d + L.q[c]);
     job.d_plane[c] = d + L.plane[c];
@@ -617,7 +627,11 @@ class FileDecoder {
   FileDecoder(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n, Phases* ph)
       : ctx_(ctx), files_(files), lens_(lens), n_(n), ph_(ph), dec_(static_cast<size_t>(n)), th_(static_cast<size_t>(n)),
         on_gpu_(static_cast<size_t>(n), 0), taken_(static_cast<size_t>(n), 0), uploaded_(static_cast<size_t>(n), 0), jo_(static_cast<size_t>(n)) {}
-  ~FileDecoder() { join_all(); for (int i = 0; i < n_; ++i) if (uploaded_[static_cast<size_t>(i)]) (void)hipStreamSynchronize(stream_of(i)); }
+  ~FileDecoder() {
+    join_all();
+    for (int i = 0; i < n_; ++i) if (uploaded_[static_cast<size_t>(i)]) (void)hipStreamSynchronize(stream_of(i));
+    if (qpin_) { if (consumer_) (void)hipStreamSynchronize(consumer_); pool_give(qpin_); }     // (its copies have left it)
+  }
 
   // 1. frame headers only (microseconds per file): sizes, sampling, EXIF orientation - what the planner and the arena need
   int headers() {
@@ -669,11 +683,13 @@ class FileDecoder {
   int take(int i, hipStream_t consumer) {
     const size_t k = static_cast<size_t>(i);
     if (taken_[k]) return IST_OK;
+    consumer_ = consumer;
+    if (!qpin_) qpin_ = static_cast<uint8_t*>(pool_take(384 * static_cast<size_t>(n_)));      // (nullptr: the tables go up from pageable memory)
     int rc = huffman_all(consumer);
     if (rc) return rc;
     Dec& D = dec_[k];
     taken_[k] = 1;
-    if (on_gpu_[k]) return jpeg_enqueue(D.J, arena_, nullptr, jo_[k], img_[i], pitch_[i], consumer, true);
+    if (on_gpu_[k]) return jpeg_enqueue(D.J, arena_, nullptr, jo_[k], img_[i], pitch_[i], consumer, true, qpin_ ? qpin_ + 384 * k : nullptr);
     const size_t row = static_cast<size_t>(D.w) * 4;
     if (!D.jpeg) {                                  // PNG / BMP / GIF / WebP: decoded on the thread, uploaded here
       std::vector<RowsCopy> up;
@@ -778,6 +794,7 @@ class FileDecoder {
   std::vector<JpegDevLayout> jo_;
   uint8_t* arena_ = nullptr; uint8_t* const* img_ = nullptr; const size_t* pitch_ = nullptr;
   bool gpu_huffman_ = true, huff_done_ = false;
+  uint8_t* qpin_ = nullptr; hipStream_t consumer_ = nullptr;
 };
 
 // One stitch cut into a background launch + one launch per draw (the same cut the device group uses, ist_shard_parts with a
@@ -949,7 +966,11 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   // of image k+1 sat between the slabs of band k and band k+1 and cost its full time; on its own stream it runs beside them.
   rc = ensure_aux(ctx);
   if (rc) return rc;
-  if (!ctx->render && hipStreamCreateWithFlags(&ctx->render, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->render = nullptr; return fail(IST_E_HIP, "hipStreamCreate failed"); }
+  if (!ctx->render) {                                  // (high priority: its short kernels should not queue behind the encoder's thousands of workgroups)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&ctx->render, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); ctx->render = nullptr; return fail(IST_E_HIP, "hipStreamCreate failed"); }
+  }
   hipStream_t render = ph.on ? ctx->stream : ctx->render;
   // the stitch, cut per image (compiled while the workers parse): background now, band k when image k is there
   static const uint8_t transparent[4] = {0, 0, 0, 0};
@@ -965,38 +986,53 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
     rc = ist_job_launch(bj.bg, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, render);
     if (rc) return rc;
   }
-  size_t next_part = 0;
   bool rendered_whole = false;
-  // the export is about to read canvas rows [0, y_end) on ctx->stream: render what they need on the render stream and make
-  // ctx->stream wait for it
-  auto ordered = [&]() -> int {
-    if (render == ctx->stream) return IST_OK;
-    if (hipEventRecord(ctx->render_done, render) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->render_done, 0) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "ordering the export behind the render failed"); }
+  // the export is about to read canvas rows [0, y_end) on `reader` (one of the encoder's two streams): order it behind the
+  // render of those rows
+  auto ordered = [&](hipStream_t reader, hipEvent_t ev) -> int {
+    if (render == reader) return IST_OK;
+    if (hipStreamWaitEvent(reader, ev, 0) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "ordering the export behind the render failed"); }
     return IST_OK;
   };
   if (!ctx->render_done && hipEventCreateWithFlags(&ctx->render_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->render_done = nullptr; return fail(IST_E_HIP, "hipEventCreate failed"); }
-  auto need_rows = [&](int64_t y_end) -> int {
+  // The FIRST request renders everything: behind the Huffman batch every image is reconstructed and its band rendered on the
+  // render stream, an event per band (the images' upload events are free again by then).  History (rocprofv3 timelines,
+  // profiles/r03_file_pipeline_kernels.txt is the last of them): (1) pulling band k+1 only when slab k+1 was about to be
+  // submitted put its reconstruction in competition with slab k's compression, which fills every CU - the 40 us colour
+  // kernel took 250 us and the slabs ran one after the other at half speed; (2) a render THREAD that submitted the bands while
+  // the encoder's thread submitted slabs was slower still (7.2-7.4 ms against 6.6-7.0): the render kernels then trickled in
+  // between the slabs' workgroups for 4.4 ms instead of 1.0.  The compressing kernel owns the chip while it runs; the only work
+  // that really hides behind it is the file's trip over PCIe.
+  size_t next_part = 0;
+  auto need_rows = [&](int64_t y_end, void* reader_) -> int {
+    hipStream_t reader = static_cast<hipStream_t>(reader_);
     if (!bj.ok) {
-      if (rendered_whole) return IST_OK;
-      int rc2 = fd.finish(render);
-      if (rc2) return rc2;
-      rendered_whole = true;
-      rc2 = ist_job_launch(whole, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, render);
-      return rc2 ? rc2 : ordered();
+      if (!rendered_whole) {
+        int rc2 = fd.finish(render);
+        if (rc2) return rc2;
+        rendered_whole = true;
+        rc2 = ist_job_launch(whole, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, render);
+        if (rc2) return rc2;
+        if (render != ctx->stream && hipEventRecord(ctx->render_done, render) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipEventRecord failed"); }
+      }
+      return ordered(reader, ctx->render_done);
     }
-    bool any = false;
-    while (next_part < bj.parts.size() && bj.parts[next_part].Y0 < y_end) {
+    while (next_part < bj.parts.size()) {
       const ist_part& p = bj.parts[next_part];
       int rc2 = fd.take(p.image, render);
       if (rc2) return rc2;
       rc2 = ist_job_launch(bj.band[next_part], dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, render);
       if (rc2) return rc2;
-      ++next_part; any = true;
+      if (render != ctx->stream && hipEventRecord(ctx->img_event[next_part], render) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipEventRecord failed"); }
+      ++next_part;
     }
-    return (any || next_part == 0) ? ordered() : IST_OK;      // (next_part == 0: the background alone)
+    // the last band that rows [0, y_end) touch (bands are sorted by Y0; the background launch precedes them all)
+    size_t last = 0;
+    for (size_t k = 0; k < bj.parts.size(); ++k) if (bj.parts[k].Y0 < y_end) last = k;
+    return ordered(reader, ctx->img_event[last]);
   };
   if (ph.on) {                                            // phase timing: the whole canvas first, then the export
-    rc = need_rows(out_plan->canvas_h);
+    rc = need_rows(out_plan->canvas_h, ctx->stream);
     if (rc) return rc;
     ph.lap(IST_PHASE_STITCH, "compile + stitch launches", ctx->stream);
   }

@@ -15,12 +15,12 @@ def rows(d, pat):
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     for k in ("ist_jpeg_sync_kernel", "ist_jpeg_write_kernel", "ist_jpeg_idct_kernel", "ist_jpeg_color_kernel", "ist_stitch_kernel",
               "ist_stitch_area_kernel", "ist_png_deflate_kernel", "ist_png_gather_kernel", "ist_jpeg_scatter_kernel"):
         if k in name:
             return k
-    return name[-40:]
+    return name.replace("void ", "").replace("ist::", "")[-40:]
 
 
 def main():
