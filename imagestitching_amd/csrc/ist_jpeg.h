@@ -80,13 +80,13 @@ int jpeg_parse_and_entropy_decode(const uint8_t* file, int64_t len, JpegImage* o
 // With gpu_scan: when the file qualifies (gpu_scan->eligible) the scan is NOT decoded on the host; the components then
 // carry neither dense nor sparse coefficients and jpeg_gpu_entropy_decode fills the device planes.
 
-// GPU stages (ist_jpeg_kernels.hip): coefficient planes (device) -> RGBA8 (device).  d_coef[c] / d_q[c] per component,
+// GPU stages (ist_jpeg_kernels.hip): coefficient planes (device) -> RGBA8 (device).  d_coef[c] / q_host[c] per component,
 // planes = scratch for the reconstructed sample planes.  Asynchronous on `stream`.
 struct JpegDeviceJob {
   int width, height, ncomp, hmax, vmax;
   int h[3], v[3], blocks_x[3], blocks_y[3];
   const int16_t* d_coef[3];
-  const uint16_t* d_q[3];
+  const uint16_t* q_host[3];           // quantisation tables (HOST memory, natural order): passed by value to the kernel
   uint8_t* d_plane[3];                 // blocks_x*8 bytes per row
   uint8_t* out; size_t out_pitch;
 };

@@ -45,7 +45,9 @@ __device__ __forceinline__ void idct8(const int in[8], int out[8], int shift, bo
   out[3] = descale(tmp13 + tmp0, shift); out[4] = descale(tmp13 - tmp0, shift);
 }
 
-struct IdctArgs { const int16_t* coef; const uint16_t* q; uint8_t* plane; int blocks_x, blocks_y; };
+// (the quantisation table travels BY VALUE in the kernel arguments: 128 bytes, read with scalar loads - as a 128-byte upload per
+// component it was three 5 us blit copies in front of every image's reconstruction)
+struct IdctArgs { const int16_t* coef; uint16_t q[64]; uint8_t* plane; int blocks_x, blocks_y; };
 
 // one thread per 8x8 block: 128 B of coefficients in, 64 samples out (plane row pitch = blocks_x * 8)
 __global__ __launch_bounds__(128) void ist_jpeg_idct_kernel(const IdctArgs A) {
@@ -214,7 +216,9 @@ int jpeg_launch_scatter(const uint32_t* d_ent, const uint32_t* d_start, const ui
 int jpeg_launch_reconstruct(const JpegDeviceJob& J, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   for (int c = 0; c < J.ncomp; ++c) {
-    IdctArgs a{J.d_coef[c], J.d_q[c], J.d_plane[c], J.blocks_x[c], J.blocks_y[c]};
+    IdctArgs a;
+    a.coef = J.d_coef[c]; a.plane = J.d_plane[c]; a.blocks_x = J.blocks_x[c]; a.blocks_y = J.blocks_y[c];
+    for (int k = 0; k < 64; ++k) a.q[k] = J.q_host[c] ? J.q_host[c][k] : 1;
     const int nblk = J.blocks_x[c] * J.blocks_y[c];
     hipLaunchKernelGGL(ist_jpeg_idct_kernel, dim3((nblk + 127) / 128), dim3(128), 0, stream, a);
   }

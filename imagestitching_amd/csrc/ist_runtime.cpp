@@ -465,14 +465,11 @@ void jpeg_layout_sparse(const JpegImage& J, size_t* off, JpegDevLayout* L) {
 }
 
 // H2D of the coefficients (sparse entries are scattered into a zeroed plane on the GPU) + the reconstruction launches
-// q_pinned (optional): 3 x 128 bytes of PINNED host memory the quantisation tables are staged in, so that their upload is a real
-// asynchronous copy (from pageable memory every 128-byte table is a blocking staged copy: ~0.7 ms of host time for nine images,
-// measured, which held back everything submitted behind them)
-int jpeg_enqueue(const JpegImage& J, uint8_t* d, uint8_t* d_ent, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch, hipStream_t stream, bool coef_on_device = false,
-                 uint8_t* q_pinned = nullptr) {
+// (the quantisation tables go to the kernels by value: no upload)
+int jpeg_enqueue(const JpegImage& J, uint8_t* d, uint8_t* d_ent, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch, hipStream_t stream, bool coef_on_device = false) {
   JpegDeviceJob job;
   job.width = J.width; job.height = J.height; job.ncomp = J.ncomp; job.hmax = J.hmax; job.vmax = J.vmax;
-  for (int c = 0; c < 3; ++c) { job.d_coef[c] = nullptr; job.d_q[c] = nullptr; job.d_plane[c] = nullptr; job.h[c] = job.v[c] = 1; job.blocks_x[c] = job.blocks_y[c] = 0; }
+  for (int c = 0; c < 3; ++c) { job.d_coef[c] = nullptr; job.q_host[c] = nullptr; job.d_plane[c] = nullptr; job.h[c] = job.v[c] = 1; job.blocks_x[c] = job.blocks_y[c] = 0; }
   for (int c = 0; c < J.ncomp; ++c) {
     const JpegComp& C = J.comp[c];
     const size_t nblk = static_cast<size_t>(C.blocks_x) * C.blocks_y;
@@ -491,11 +488,8 @@ int jpeg_enqueue(const JpegImage& J, uint8_t* d, uint8_t* d_ent, const JpegDevLa
       if (C.coef.size() != nblk * 64) return fail(IST_E_DECODE, "JPEG component without coefficients");
       IST_HIP(hipMemcpyAsync(d_coef, C.coef.data(), nblk * 128, hipMemcpyHostToDevice, stream));
     }
-    const void* qsrc = C.q;
-    if (q_pinned) { std::memcpy(q_pinned + 128 * c, C.q, 128); qsrc = q_pinned + 128 * c; }
-    IST_HIP(hipMemcpyAsync(d + L.q[c], qsrc, 128, hipMemcpyHostToDevice, stream));
     job.d_coef[c] = d_coef;
-    job.d_q[c] = reinterpret_cast<const uint16_t*>(d + L.q[c]);
+    job.q_host[c] = C.q;
     job.d_plane[c] = d + L.plane[c];
     job.h[c] = C.h; job.v[c] = C.v; job.blocks_x[c] = C.blocks_x; job.blocks_y[c] = C.blocks_y;
   }
@@ -630,7 +624,6 @@ class FileDecoder {
   ~FileDecoder() {
     join_all();
     for (int i = 0; i < n_; ++i) if (uploaded_[static_cast<size_t>(i)]) (void)hipStreamSynchronize(stream_of(i));
-    if (qpin_) { if (consumer_) (void)hipStreamSynchronize(consumer_); pool_give(qpin_); }     // (its copies have left it)
   }
 
   // 1. frame headers only (microseconds per file): sizes, sampling, EXIF orientation - what the planner and the arena need
@@ -683,13 +676,11 @@ class FileDecoder {
   int take(int i, hipStream_t consumer) {
     const size_t k = static_cast<size_t>(i);
     if (taken_[k]) return IST_OK;
-    consumer_ = consumer;
-    if (!qpin_) qpin_ = static_cast<uint8_t*>(pool_take(384 * static_cast<size_t>(n_)));      // (nullptr: the tables go up from pageable memory)
     int rc = huffman_all(consumer);
     if (rc) return rc;
     Dec& D = dec_[k];
     taken_[k] = 1;
-    if (on_gpu_[k]) return jpeg_enqueue(D.J, arena_, nullptr, jo_[k], img_[i], pitch_[i], consumer, true, qpin_ ? qpin_ + 384 * k : nullptr);
+    if (on_gpu_[k]) return jpeg_enqueue(D.J, arena_, nullptr, jo_[k], img_[i], pitch_[i], consumer, true);
     const size_t row = static_cast<size_t>(D.w) * 4;
     if (!D.jpeg) {                                  // PNG / BMP / GIF / WebP: decoded on the thread, uploaded here
       std::vector<RowsCopy> up;
@@ -794,7 +785,6 @@ class FileDecoder {
   std::vector<JpegDevLayout> jo_;
   uint8_t* arena_ = nullptr; uint8_t* const* img_ = nullptr; const size_t* pitch_ = nullptr;
   bool gpu_huffman_ = true, huff_done_ = false;
-  uint8_t* qpin_ = nullptr; hipStream_t consumer_ = nullptr;
 };
 
 // One stitch cut into a background launch + one launch per draw (the same cut the device group uses, ist_shard_parts with a
