@@ -40,6 +40,17 @@ def _seeds(d):
         p = os.path.join(d, name)
         img.save(p, fmt, **kw)
         out.append(p)
+    # round 3 parsers: run-length BMP (hand-made: PIL does not write them) and an animated WebP
+    from test_png_decode import _rle_bmp
+    idx8 = np.repeat(rng.integers(0, 200, (20, 8), dtype=np.uint8), 4, axis=1)
+    for name, bpp, idx in (("rle8.bmp", 8, idx8), ("rle4.bmp", 4, (idx8 % 16).astype(np.uint8))):
+        p = os.path.join(d, name)
+        with open(p, "wb") as f:
+            f.write(_rle_bmp(idx, bpp, rng.integers(0, 256, 3 * (200 if bpp == 8 else 16), dtype=np.uint8).tolist(), with_delta=True))
+        out.append(p)
+    p = os.path.join(d, "anim.webp")
+    im.convert("RGBA").save(p, "WEBP", save_all=True, append_images=[im.convert("RGBA").rotate(180)], duration=40, lossless=True)
+    out.append(p)
     return out
 
 

@@ -16,7 +16,8 @@ import imagestitching_amd as ist  # noqa: E402
 MIXED = [(4032, 3024), (3024, 4032), (4000, 3000), (3840, 2160), (4032, 3024), (3024, 4032), (4000, 3000), (3840, 2160), (4032, 3024)]
 UNIFORM = [(4032, 3024)] * 9
 CONFIGS = {"mixed_horizontal": (MIXED, "horizontal"), "mixed_vertical": (MIXED, "vertical"),
-           "uniform_horizontal": (UNIFORM, "horizontal"), "uniform_vertical": (UNIFORM, "vertical")}
+           "uniform_horizontal": (UNIFORM, "horizontal"), "uniform_vertical": (UNIFORM, "vertical"),
+           "exif6_scaled": (MIXED, "vertical"), "exif6_unit": (UNIFORM, "vertical")}     # every image quarter-turned (EXIF 6)
 
 
 def main():
@@ -29,7 +30,12 @@ def main():
     sizes, direction = CONFIGS[args.which]
     dev = torch.device("cuda", 0)
     st = ist.Stitcher(0)
-    imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in sizes]
+    turned = args.which.startswith("exif6")
+    if turned:                              # natural size w x h, stored bitmap h x w (what a phone writes for a portrait shot)
+        imgs = [{"width": w, "height": h, "orientation": 6, "opaque": True, "bmpWidth": h, "bmpHeight": w} for (w, h) in sizes]
+        sizes = [(h, w) for (w, h) in sizes]
+    else:
+        imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in sizes]
     p, job = st.compile(imgs, direction, {"filter": "bilinear"})
     sets = [[torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device=dev) for (w, h) in sizes] for _ in range(args.sets)]
     outs = [torch.empty((p.canvas_h, p.canvas_w, 4), dtype=torch.uint8, device=dev) for _ in range(args.sets)]
