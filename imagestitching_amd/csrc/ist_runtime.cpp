@@ -611,6 +611,7 @@ int ensure_image_lanes(ist_ctx* ctx, int n) {
     ctx->img_event.push_back(ev);
   }
   if (ctx->img_huff.size() < static_cast<size_t>(n)) { ctx->img_huff.resize(static_cast<size_t>(n), nullptr); ctx->img_huff_bytes.resize(static_cast<size_t>(n), 0); }
+  if (ctx->scan_bufs.size() < static_cast<size_t>(n)) ctx->scan_bufs.resize(static_cast<size_t>(n));
   return IST_OK;
 }
 
@@ -624,6 +625,9 @@ class FileDecoder {
   ~FileDecoder() {
     join_all();
     for (int i = 0; i < n_; ++i) if (uploaded_[static_cast<size_t>(i)]) (void)hipStreamSynchronize(stream_of(i));
+    for (int i = 0; i < n_ && static_cast<size_t>(i) < ctx_->scan_bufs.size(); ++i)       // keep the scans' capacity for the next call
+      if (dec_[static_cast<size_t>(i)].G.stream.capacity() > ctx_->scan_bufs[static_cast<size_t>(i)].capacity() && dec_[static_cast<size_t>(i)].G.stream.capacity() <= (8u << 20))
+        ctx_->scan_bufs[static_cast<size_t>(i)].swap(dec_[static_cast<size_t>(i)].G.stream);      // (at most 8 MiB per image is kept)
   }
 
   // 1. frame headers only (microseconds per file): sizes, sampling, EXIF orientation - what the planner and the arena need
@@ -760,6 +764,7 @@ class FileDecoder {
       return;
     }
     JpegImage full;
+    if (k < ctx_->scan_bufs.size()) D.G.stream.swap(ctx_->scan_bufs[k]);            // (a recycled buffer: capacity, no contents)
     const int rc = jpeg_parse_and_entropy_decode(f, len, &full, false, gpu_huffman_ ? &D.G : nullptr);
     if (rc) { failed(rc); return; }
     if (full.width != D.w || full.height != D.h || full.ncomp != D.J.ncomp) { g_last_error = "JPEG frame header changed between two reads"; failed(IST_E_DECODE); return; }
@@ -1003,23 +1008,29 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
         rendered_whole = true;
         rc2 = ist_job_launch(whole, dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, render);
         if (rc2) return rc2;
-        if (render != ctx->stream && hipEventRecord(ctx->render_done, render) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipEventRecord failed"); }
+        if (hipEventRecord(ctx->render_done, render) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipEventRecord failed"); }
       }
       return ordered(reader, ctx->render_done);
     }
-    while (next_part < bj.parts.size()) {
+    // first request (the short first slab): only the bands it reads, so that the file's first bytes are on their way while the
+    // rest is rendered; every later request: everything that is left
+    const bool first_request = next_part == 0;
+    while (next_part < bj.parts.size() && (!first_request || bj.parts[next_part].Y0 < y_end)) {
       const ist_part& p = bj.parts[next_part];
       int rc2 = fd.take(p.image, render);
       if (rc2) return rc2;
       rc2 = ist_job_launch(bj.band[next_part], dsrc.data(), dpitch.data(), n, d + o_canvas, canvas_pitch, render);
       if (rc2) return rc2;
-      if (render != ctx->stream && hipEventRecord(ctx->img_event[next_part], render) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipEventRecord failed"); }
+      if (hipEventRecord(ctx->img_event[next_part], render) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipEventRecord failed"); }
       ++next_part;
     }
-    // the last band that rows [0, y_end) touch (bands are sorted by Y0; the background launch precedes them all)
-    size_t last = 0;
+    // the last band that rows [0, y_end) touch (bands are sorted by Y0; the background launch precedes them all on the render
+    // stream).  Rows that no band touches (a gap at the top) are ordered behind the background launch alone.
+    size_t last = bj.parts.size();
     for (size_t k = 0; k < bj.parts.size(); ++k) if (bj.parts[k].Y0 < y_end) last = k;
-    return ordered(reader, ctx->img_event[last]);
+    if (last < next_part) return ordered(reader, ctx->img_event[last]);
+    if (hipEventRecord(ctx->render_done, render) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipEventRecord failed"); }
+    return ordered(reader, ctx->render_done);
   };
   if (ph.on) {                                            // phase timing: the whole canvas first, then the export
     rc = need_rows(out_plan->canvas_h, ctx->stream);
