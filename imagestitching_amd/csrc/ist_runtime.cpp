@@ -80,6 +80,7 @@ int ensure_aux(ist_ctx* ctx) {
   if (ctx->aux) return IST_OK;
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (tuning_mode() && std::getenv("IST_AUX_PRIORITY")) hi = std::atoi(std::getenv("IST_AUX_PRIORITY")) ? hi : lo;     // A/B knob: 0 = lowest
   if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); ctx->aux = nullptr; return fail(IST_E_HIP, "hipStreamCreate failed"); }
   return IST_OK;
 }
