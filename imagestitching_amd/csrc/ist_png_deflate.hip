@@ -39,6 +39,7 @@ namespace ist {
 
 namespace {
 
+constexpr int kCopyGrid = 0;             // workgroups of the device-to-host copy kernel (0: the runtime's copy); IST_PNG_COPY_GRID overrides in tuning mode
 constexpr int CH = 16384;              // most filtered-stream bytes in one chunk
 constexpr int SPAN = 64;               // bytes per thread
 constexpr int SLOT = CH + 128;         // bytes per chunk in the scratch area (stored form + framing + alignment pads)
@@ -478,6 +479,15 @@ __global__ __launch_bounds__(256) void ist_png_gather_kernel(const GatherArgs G)
     *reinterpret_cast<u32x4_a4*>(d + 16 * static_cast<size_t>(u)) = *reinterpret_cast<const u32x4*>(s + 16 * static_cast<size_t>(u));
 }
 
+// device -> pinned host, 16-byte units, a FIXED small grid striding over the range: the slab's trip over PCIe as a kernel that
+// holds a few dozen workgroup slots, instead of the runtime's device-to-host copy, which runs as a blit kernel of thousands of
+// workgroups parked on PCIe writes beside the compressing kernel (PNG stage 3.5 ms with those copies, 2.4 ms without them -
+// measured with IST_PNG_SKIP_D2H - against 2.6-2.75 ms of PCIe time)
+__global__ __launch_bounds__(256) void ist_png_to_host_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, const int64_t units) {
+  for (int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; u < units; u += static_cast<int64_t>(gridDim.x) * 256)
+    dst[u] = __builtin_nontemporal_load(src + u);
+}
+
 void put32(uint8_t* p, uint32_t v) { p[0] = v >> 24; p[1] = (v >> 16) & 0xFF; p[2] = (v >> 8) & 0xFF; p[3] = v & 0xFF; }
 
 struct ChunkGrid { int64_t n_chunks; int rows_per_chunk, pieces_per_row, piece_px; };
@@ -744,7 +754,13 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
       // 256-byte aligned ends.  The bytes past `pos` in the last 256 are the next slab's: its own copy, ordered behind
       // this one, delivers them
       const int64_t c_lo = slab_begin & ~255ll, c_hi = std::min<int64_t>((pos + 255) & ~255ll, out_cap);
-      PNG_HIP(hipMemcpyAsync(host_out + c_lo, static_cast<const uint8_t*>(out) + c_lo, static_cast<size_t>(c_hi - c_lo), hipMemcpyDeviceToHost, aux));
+      static const bool skip_d2h = tuning_mode() && std::getenv("IST_PNG_SKIP_D2H") != nullptr;      // experiment: what the copies cost the kernel beside them (the file is then NOT delivered)
+      static const int copy_grid = (tuning_mode() && std::getenv("IST_PNG_COPY_GRID")) ? std::atoi(std::getenv("IST_PNG_COPY_GRID")) : kCopyGrid;
+      if (!skip_d2h && copy_grid > 0) {
+        hipLaunchKernelGGL(ist_png_to_host_kernel, dim3(static_cast<unsigned>(copy_grid)), dim3(256), 0, aux, reinterpret_cast<const u32x4*>(static_cast<const uint8_t*>(out) + c_lo),
+                           reinterpret_cast<u32x4*>(host_out + c_lo), (c_hi - c_lo) / 16);
+        PNG_HIP(hipGetLastError());
+      } else if (!skip_d2h) PNG_HIP(hipMemcpyAsync(host_out + c_lo, static_cast<const uint8_t*>(out) + c_lo, static_cast<size_t>(c_hi - c_lo), hipMemcpyDeviceToHost, aux));
     }
   }
   PNG_HIP(hipStreamSynchronize(aux));
