@@ -709,19 +709,28 @@ def finish_line(line, args, n):
         return
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                              "IST_BENCH_CHILD", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--group-leg", str(n), "--steps", str(args.steps)], env=env,
-                           stdout=subprocess.PIPE, stderr=sys.stderr, timeout=args.group_timeout)
-        leg = last_json_line(r.stdout.decode("utf-8", "replace"))
-        line.setdefault("extra", {})["single_process_group"] = leg if leg is not None else {"error": "exit status %d, no JSON" % r.returncode}
-    except subprocess.TimeoutExpired:
-        line.setdefault("extra", {})["single_process_group"] = {"error": "timed out after %d s" % args.group_timeout}
-    except Exception as ex:
-        line.setdefault("extra", {})["single_process_group"] = {"error": repr(ex)}
+    # two children, each with its own time limit: the host-sink legs exchange nothing between GPUs; the device-sink legs gather
+    # over xGMI through RCCL - a problem in one must not cost the other's numbers
+    merged = {"regions": {}}
+    for part in ("host", "resident"):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--group-leg", str(n), "--group-part", part, "--steps", str(args.steps)], env=env,
+                               stdout=subprocess.PIPE, stderr=sys.stderr, timeout=args.group_timeout)
+            leg = last_json_line(r.stdout.decode("utf-8", "replace"))
+            if leg is None:
+                merged["regions"][part + "/error"] = "exit status %d, no JSON" % r.returncode
+            else:
+                merged["regions"].update(leg.pop("regions", {}))
+                merged.update(leg)
+        except subprocess.TimeoutExpired:
+            merged["regions"][part + "/error"] = "timed out after %d s" % args.group_timeout
+        except Exception as ex:
+            merged["regions"][part + "/error"] = repr(ex)
+    line.setdefault("extra", {})["single_process_group"] = merged
 
 
 # ---------------------------------------------------------------------------------------------------- C-ABI device group leg
-def group_leg(n, steps, out):
+def group_leg(n, steps, out, part="all"):
     """ONE process drives GPUs 0..n-1 through the C-ABI device group (ist_group_*; the N-API host's `devices` option).
     Regions, per split:  resident (device pointers per part, canvas on the root, RCCL gather) and host_in_host_out
     (ist_stitch_rgba8_multi: every device uploads only its rows over its own PCIe link and DMAs its finished band straight
@@ -737,30 +746,40 @@ def group_leg(n, steps, out):
     mp = 4032 * 27216 / 1e6
     imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in UNIFORM]
     res = {"devices": devices, "regions": {}}
-    g = ist.StitchGroup(devices)
     reps = max(5, min(50, steps // 4))
-    for split in ("image", "band"):
-        job = g.compile(imgs, "vertical", {"filter": "bilinear", "split": split})
-        srcs = []
-        for p in job.parts:
-            a, b = p["rows"]
-            w = UNIFORM[p["image"]][0]
-            t = torch.empty((b - a + 1, w, 4), dtype=torch.uint8, device="cuda:%d" % p["device"])[:b - a]
-            t.random_(0, 256)
-            srcs.append((t, a))
-        canvas = torch.empty((job.plan.canvas_h, job.plan.canvas_w, 4), dtype=torch.uint8, device="cuda:%d" % devices[0])
-        for _ in range(20):
-            job.launch(srcs, canvas)
-        g.sync()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            job.launch(srcs, canvas)
-        g.sync()
-        dt = (time.perf_counter() - t0) / reps
-        res["regions"]["resident/" + split] = {"ms_per_step": round(dt * 1e3, 4), "MPs": round(mp / dt, 1), "parts": len(job.parts)}
-        job.close()
-        del srcs, canvas
-    g.close()
+    try:                                       # (the device-sink legs need RCCL between distinct GPUs; the host-sink legs below do not)
+        if part == "host":
+            raise StopIteration
+        g = ist.StitchGroup(devices)
+        for split in ("image", "band"):
+            job = g.compile(imgs, "vertical", {"filter": "bilinear", "split": split})
+            srcs = []
+            for p in job.parts:
+                a, b = p["rows"]
+                w = UNIFORM[p["image"]][0]
+                t = torch.empty((b - a + 1, w, 4), dtype=torch.uint8, device="cuda:%d" % p["device"])[:b - a]
+                t.random_(0, 256)
+                srcs.append((t, a))
+            canvas = torch.empty((job.plan.canvas_h, job.plan.canvas_w, 4), dtype=torch.uint8, device="cuda:%d" % devices[0])
+            for _ in range(20):
+                job.launch(srcs, canvas)
+            g.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                job.launch(srcs, canvas)
+            g.sync()
+            dt = (time.perf_counter() - t0) / reps
+            res["regions"]["resident/" + split] = {"ms_per_step": round(dt * 1e3, 4), "MPs": round(mp / dt, 1), "parts": len(job.parts)}
+            job.close()
+            del srcs, canvas
+        g.close()
+    except StopIteration:
+        pass
+    except Exception as ex:
+        res["regions"]["resident/error"] = repr(ex)
+    if part == "resident":
+        out.emit(json.dumps(res))
+        return
     px = [synth_np(k, w, h) for k, (w, h) in enumerate(UNIFORM)]
     himgs = [{"width": w, "height": h, "data": a, "opaque": True} for a, (w, h) in zip(px, UNIFORM)]
     for split in ("image", "band"):
@@ -853,8 +872,9 @@ def main():
     ap.add_argument("--print-kernel-sha", action="store_true")
     ap.add_argument("--dry-launch", action="store_true", help="N ranks on CPU (gloo, stub render): exercises the rank launch and the line, no GPU")
     ap.add_argument("--launch-timeout", type=int, default=900, help="seconds the self-started ranks may take")
-    ap.add_argument("--group-timeout", type=int, default=240, help="seconds the single-process device-group leg may take")
+    ap.add_argument("--group-timeout", type=int, default=150, help="seconds the single-process device-group leg may take")
     ap.add_argument("--group-leg", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--group-part", default="all", choices=["all", "host", "resident"], help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.print_kernel_sha:
         print(kernel_source_sha())
@@ -864,7 +884,7 @@ def main():
     args.out = StdoutGuard()
     have_ranks = "WORLD_SIZE" in os.environ
     if args.group_leg:
-        group_leg(args.group_leg, args.steps, args.out)
+        group_leg(args.group_leg, args.steps, args.out, args.group_part)
     elif args.gpus > 1 and not have_ranks:
         launch_ranks(args)                 # nothing above has imported torch or touched HIP
     elif args.dry_launch:

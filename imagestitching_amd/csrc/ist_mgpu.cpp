@@ -207,13 +207,8 @@ ist_group* ist_group_create(const int* devices, int ndev) {
     if (hipStreamCreateWithFlags(&g->recv_stream, hipStreamNonBlocking) != hipSuccess) { fail(IST_E_HIP, "hipStreamCreate failed"); return nullptr; }
   }
   g->self_send = tuning_mode() && std::getenv("IST_GROUP_SELF_SEND") != nullptr;
-  if (g->devs.size() > 1 || g->self_send) {
-    Rccl* R = rccl();
-    if (!R->error.empty()) { fail(IST_E_NO_DEVICE, "a group of several GPUs needs RCCL: " + R->error); (void)hipStreamDestroy(g->recv_stream); return nullptr; }
-    g->comm.assign(g->devs.size(), nullptr);
-    const int rc = R->CommInitAll(g->comm.data(), static_cast<int>(g->devs.size()), g->devs.data());
-    if (rc != 0) { nccl_fail("ncclCommInitAll", rc); g->comm.clear(); (void)hipStreamDestroy(g->recv_stream); return nullptr; }
-  }
+  // (the RCCL communicators are made on the first launch that gathers over xGMI - ensure_rccl: the host-sink path never
+  // exchanges anything between GPUs, and must not depend on librccl being loadable)
   undo.keep = true;
   return g.release();
 }
@@ -369,11 +364,24 @@ int launch_root(ist_group_job* job, const void* const* src, const size_t* src_pi
   return ist_job_launch(job->root_job, one.data(), src_pitch ? one_pitch.data() : nullptr, job->n_images, dst, dst_pitch, job->g->ctx[0]->stream);
 }
 
+// the communicators of the group (one per distinct device), on first need.  Caller holds g->mu.
+int ensure_rccl(ist_group* g) {
+  if (!g->comm.empty()) return IST_OK;
+  Rccl* R = rccl();
+  if (!R->error.empty()) return fail(IST_E_NO_DEVICE, "gathering bands over xGMI needs RCCL: " + R->error);
+  g->comm.assign(g->devs.size(), nullptr);
+  const int rc = R->CommInitAll(g->comm.data(), static_cast<int>(g->devs.size()), g->devs.data());
+  if (rc != 0) { g->comm.clear(); return nccl_fail("ncclCommInitAll", rc); }
+  return IST_OK;
+}
+
 // device sink: bands + the root's launch + ONE grouped RCCL batch into the root's canvas.  Caller holds g->mu.
 int group_launch_locked(ist_group_job* job, const void* const* src, const size_t* src_pitch, void* dst, size_t dst_pitch) {
   ist_group* g = job->g;
   int rc = ensure_arenas(g, job);
   if (rc) return rc;
+  for (const auto& rt : job->parts)
+    if (rt.part.slot != 0 && !rt.local) { rc = ensure_rccl(g); if (rc) return rc; break; }      // before anything is queued
   bool any_remote = false;
   // 1. every band on its owner's stream
   for (size_t k = 0; k < job->parts.size(); ++k) {
