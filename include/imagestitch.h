@@ -189,6 +189,8 @@ IST_API int ist_job_info_get(const ist_job* job, ist_job_info* out);
  * stream = hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
 IST_API int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch, int n_images,
                            void* dst, size_t dst_pitch, void* stream);
+/* waits for the streams the job was launched on (not for the device: other streams keep running), then recycles its tables.
+ * A job launched on the legacy default stream (NULL) inherits that stream's own implicit synchronisation rules. */
 IST_API void ist_job_destroy(ist_job* job);
 
 /* ---- host path: what stitch(images, direction, opts) binds (host RGBA8 in, host RGBA8 out) ------------------- */
