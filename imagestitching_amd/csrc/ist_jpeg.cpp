@@ -149,6 +149,8 @@ int exif_orientation(const uint8_t* d, size_t n) {
 
 }  // namespace
 
+constexpr uint32_t kMaxGpuIntervals = 2048;
+
 static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool header_only, JpegGpuScan* gs) {
   if (!f || n < 4 || f[0] != 0xFF || f[1] != 0xD8) return fail(IST_E_DECODE, "not a JPEG file");
   Huff dc[4], ac[4];
@@ -248,7 +250,7 @@ static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool head
       // the GPU entropy decoder takes baseline files whose single scan interleaves all components, without restarts
       int mcu_blocks = 0;
       for (int s2 = 0; s2 < ns; ++s2) mcu_blocks += J->comp[ci[s2]].h * J->comp[ci[s2]].v;
-      if (gs && !progressive && J->scans == 0 && ns == J->ncomp && restart_interval == 0 && mcu_blocks <= 10 &&      // (T.81 B.2.3: at most 10 blocks per MCU)
+      if (gs && !progressive && J->scans == 0 && ns == J->ncomp && mcu_blocks <= 10 &&      // (T.81 B.2.3: at most 10 blocks per MCU)
           (f + n) - (d + dl) < (1ll << 28)) {      // (32-bit bit positions on the GPU)
         for (int c = 0; c < J->ncomp; ++c) {
           if (!have_q[J->comp[c].tq]) return fail(IST_E_DECODE, "JPEG component uses an undefined quantisation table");
@@ -273,23 +275,62 @@ static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool head
           }
           std::memcpy(o.vals, h.vals, sizeof o.vals);
         }
-        // de-stuff: FF 00 -> FF; the scan ends at the first real marker
+        // de-stuff: FF 00 -> FF; the scan ends at the first real marker.  With a restart interval (DRI) every RSTn closes an
+        // interval: the entropy coder starts afresh behind it (byte aligned, DC predictors zero), so the intervals are
+        // independent streams for the GPU decoder - each is padded to a 256-byte boundary with at least 16 zero bytes.
+        // A restart marker out of sequence, or one more than the frame has intervals for, leaves this scan to the host
+        // decoder below (which has the resynchronisation rules); too few intervals fail the GPU decoder's block count and
+        // end up there too.
         const uint8_t* q = d + dl; const uint8_t* qe = f + n;
         gs->stream.clear(); gs->stream.reserve(static_cast<size_t>(qe - q) + 16);
-        while (q < qe) {
+        gs->iv.clear();
+        const uint32_t total_mcus = static_cast<uint32_t>(J->mcus_x) * static_cast<uint32_t>(J->mcus_y);
+        const uint32_t ri = static_cast<uint32_t>(restart_interval);
+        const uint32_t n_iv = ri ? (total_mcus + ri - 1) / ri : 0;
+        size_t iv_start = 0; uint32_t next_rst = 0;
+        // (every interval occupies whole workgroups of the GPU decoder - 32 KB of bitstream positions - so a file cut into
+        // thousands of tiny intervals is cheaper on the host)
+        bool in_sequence = n_iv <= kMaxGpuIntervals;
+        auto close_interval = [&]() {
+          const uint32_t k = static_cast<uint32_t>(gs->iv.size());
+          JpegGpuInterval I;
+          I.byte_off = static_cast<uint32_t>(iv_start); I.mcu0 = k * ri; I.n_mcus = std::min(ri, total_mcus - k * ri);
+          I.bits = static_cast<int64_t>(gs->stream.size() - iv_start) * 8;
+          gs->iv.push_back(I);
+          size_t pad = (256 - gs->stream.size() % 256) % 256;
+          if (pad < 16) pad += 256;
+          gs->stream.insert(gs->stream.end(), pad, 0);
+          iv_start = gs->stream.size();
+        };
+        while (in_sequence && q < qe) {
           const uint8_t* ff = static_cast<const uint8_t*>(std::memchr(q, 0xFF, static_cast<size_t>(qe - q)));
           if (!ff) { gs->stream.insert(gs->stream.end(), q, qe); q = qe; break; }
           gs->stream.insert(gs->stream.end(), q, ff);
           if (ff + 1 < qe && ff[1] == 0x00) { gs->stream.push_back(0xFF); q = ff + 2; continue; }
           if (ff + 1 < qe && ff[1] == 0xFF) { q = ff + 1; continue; }            // fill byte
+          if (ff + 1 < qe && ff[1] >= 0xD0 && ff[1] <= 0xD7) {
+            if (!ri || ff[1] != 0xD0 + next_rst || gs->iv.size() + 1 >= n_iv) { in_sequence = false; break; }
+            close_interval();                                                     // RSTn in sequence, and another interval is due
+            next_rst = (next_rst + 1) & 7u;
+            q = ff + 2;
+            continue;
+          }
           q = ff; break;                                                          // a marker (or a lone FF at the end)
         }
-        gs->bits = static_cast<int64_t>(gs->stream.size()) * 8;
-        gs->stream.insert(gs->stream.end(), 16, 0);
-        gs->eligible = true;
-        pos = q - f;
-        J->scans++;
-        continue;
+        if (in_sequence) {
+          if (ri) {
+            close_interval();                                                     // the last interval (ends at the marker that ends the scan)
+            gs->bits = static_cast<int64_t>(gs->stream.size()) * 8;
+          } else {
+            gs->bits = static_cast<int64_t>(gs->stream.size()) * 8;
+            gs->stream.insert(gs->stream.end(), 16, 0);
+          }
+          gs->eligible = true;
+          pos = q - f;
+          J->scans++;
+          continue;
+        }
+        gs->stream.clear(); gs->iv.clear();
       }
       // allocate coefficient planes on first use; copy the quantisation tables in use
       for (int c = 0; c < J->ncomp; ++c) {

@@ -64,8 +64,12 @@ struct alignas(16) JpegHuffTable {     // one Huffman table in the form the GPU 
   uint8_t pad_[8];
   uint8_t vals[256];
 };
+// One restart interval of a scan (T.81 E.1.4: the entropy coder is reset at every RSTn, so an interval decodes on its own):
+// its de-stuffed bytes start at byte_off of JpegGpuScan::stream (a multiple of 256, at least 16 zero bytes behind its last bit).
+struct JpegGpuInterval { uint32_t byte_off, mcu0, n_mcus; int64_t bits; };
 struct JpegGpuScan {
-  bool eligible = false;               // baseline, ONE interleaved scan over all components, no restart interval
+  bool eligible = false;               // baseline, ONE interleaved scan over all components (with or without restart intervals)
+  std::vector<JpegGpuInterval> iv;     // empty: the scan is one stream; otherwise one entry per restart interval, in order
   std::vector<uint8_t> stream;         // entropy-coded bytes with the FF00 stuffing removed, + 16 zero bytes
   int64_t bits = 0;                    // valid bits in stream
   int slots = 0;                       // blocks per MCU

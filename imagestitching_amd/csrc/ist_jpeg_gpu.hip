@@ -58,6 +58,7 @@ struct DevImg {
   const JpegHuffTable* tables;            // 8 per image
   int32_t first_sub, n_sub;
   int32_t slots, total_blocks, mcus_x;
+  int32_t mcu0;                           // the MCU its first block belongs to (non-zero: a later restart interval of a scan)
   uint8_t slot_comp[10], slot_idx[10], dc_tab[3], ac_tab[3];
   int16_t* coef[3];
   int32_t h[3], v[3], blocks_x[3];
@@ -274,7 +275,7 @@ __device__ __forceinline__ void run_write(const WgShared<THREADS>* sh, uint32_t 
     if (wr) {
       if (corrupt) *err = 1u;
       const uint32_t h = static_cast<uint32_t>(I.h[comp]), v = static_cast<uint32_t>(I.v[comp]);
-      const uint32_t mcu = blk / slots;
+      const uint32_t mcu = static_cast<uint32_t>(I.mcu0) + blk / slots;
       const uint32_t mx = mcu % static_cast<uint32_t>(I.mcus_x), my = mcu / static_cast<uint32_t>(I.mcus_x);
       const uint32_t bx = mx * h + si % h, by = my * v + si / h;
       typedef uint32_t V4 __attribute__((ext_vector_type(4)));
@@ -482,46 +483,72 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   // ---- one device arena: streams, tables, image records, per-subsequence state
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~static_cast<size_t>(255); return at; };
-  std::vector<size_t> o_stream(n_img), o_tab(n_img);
-  std::vector<DevImg> H(n_img);
+  // A unit = what the kernels call an image: a whole scan, or ONE RESTART INTERVAL of a scan with DRI (the coder starts
+  // afresh behind every RSTn, so an interval is an independent stream whose blocks start at MCU mcu0 of the same planes).
+  struct Unit { size_t item; uint32_t byte_off; };
+  std::vector<Unit> units;
+  std::vector<size_t> o_stream(n_img), o_tab(n_img), first_unit(n_img + 1);
+  std::vector<DevImg> H;
   int64_t n_sub_total = 0;
   for (size_t k = 0; k < n_img; ++k) {
     const JpegImage& J = *items[k].J; const JpegGpuScan& S = *items[k].S;
     if (S.bits >= (1ll << 32) - 65536) return fail(IST_E_UNSUPPORTED, "JPEG scan too large for the GPU entropy decoder");
     // the kernels index slot_comp / slot_idx (10 entries, T.81 B.2.3) with the MCU slot: never launch outside that
     if (S.slots < 1 || S.slots > 10) return fail(IST_E_DECODE, "JPEG scan with more than 10 blocks per MCU");
-    if (S.stream.size() != static_cast<size_t>(S.bits / 8) + 16) return fail(IST_E_INVALID, "JPEG scan buffer without its padding");
+    if (S.iv.empty() && S.stream.size() != static_cast<size_t>(S.bits / 8) + 16) return fail(IST_E_INVALID, "JPEG scan buffer without its padding");
     o_stream[k] = items[k].d_stream ? 0 : take(S.stream.size());
-    DevImg& I = H[k];
-    std::memset(&I, 0, sizeof I);
-    I.bits = S.bits;
-    I.first_sub = static_cast<int32_t>(n_sub_total);
-    I.n_sub = static_cast<int32_t>((S.bits + kSubBits - 1) / kSubBits);
-    if (I.n_sub < 1) I.n_sub = 1;
-    n_sub_total += (static_cast<int64_t>(I.n_sub) + 255) & ~255LL;        // a workgroup (256 subsequences) never spans two images
-    I.slots = S.slots; I.mcus_x = J.mcus_x;
-    I.total_blocks = J.mcus_x * J.mcus_y * S.slots;
-    std::memcpy(I.slot_comp, S.slot_comp, 10); std::memcpy(I.slot_idx, S.slot_idx, 10);
-    std::memcpy(I.dc_tab, S.dc_tab, 3); std::memcpy(I.ac_tab, S.ac_tab, 3);
-    for (int c = 0; c < J.ncomp; ++c) {
-      I.coef[c] = items[k].d_coef[c];
-      I.h[c] = J.comp[c].h; I.v[c] = J.comp[c].v; I.blocks_x[c] = J.comp[c].blocks_x;
+    first_unit[k] = units.size();
+    const size_t n_units = S.iv.empty() ? 1 : S.iv.size();
+    for (size_t u = 0; u < n_units; ++u) {
+      DevImg I;
+      std::memset(&I, 0, sizeof I);
+      uint32_t byte_off = 0;
+      if (S.iv.empty()) {
+        I.bits = S.bits;
+        I.total_blocks = J.mcus_x * J.mcus_y * S.slots;
+      } else {
+        const JpegGpuInterval& V = S.iv[u];
+        if (V.byte_off % 256 != 0 || V.bits < 0 || V.bits % 8 != 0 || static_cast<size_t>(V.byte_off) + static_cast<size_t>(V.bits / 8) + 16 > S.stream.size() ||
+            static_cast<int64_t>(V.mcu0) + V.n_mcus > static_cast<int64_t>(J.mcus_x) * J.mcus_y)
+          return fail(IST_E_INVALID, "JPEG restart interval outside its scan");
+        byte_off = V.byte_off;
+        I.bits = V.bits;
+        I.total_blocks = static_cast<int32_t>(V.n_mcus) * S.slots;
+        I.mcu0 = static_cast<int32_t>(V.mcu0);
+      }
+      I.first_sub = static_cast<int32_t>(n_sub_total & 0x7fffffff);
+      I.n_sub = static_cast<int32_t>((I.bits + kSubBits - 1) / kSubBits);
+      if (I.n_sub < 1) I.n_sub = 1;
+      n_sub_total += (static_cast<int64_t>(I.n_sub) + 255) & ~255LL;        // a workgroup (256 subsequences) never spans two units
+      I.slots = S.slots; I.mcus_x = J.mcus_x;
+      std::memcpy(I.slot_comp, S.slot_comp, 10); std::memcpy(I.slot_idx, S.slot_idx, 10);
+      std::memcpy(I.dc_tab, S.dc_tab, 3); std::memcpy(I.ac_tab, S.ac_tab, 3);
+      for (int c = 0; c < J.ncomp; ++c) {
+        I.coef[c] = items[k].d_coef[c];
+        I.h[c] = J.comp[c].h; I.v[c] = J.comp[c].v; I.blocks_x[c] = J.comp[c].blocks_x;
+      }
+      for (int c = J.ncomp; c < 3; ++c) I.h[c] = I.v[c] = 1;
+      H.push_back(I);
+      units.push_back(Unit{k, byte_off});
     }
-    for (int c = J.ncomp; c < 3; ++c) I.h[c] = I.v[c] = 1;
   }
-  if (n_sub_total >= (1ll << 31) || n_img > 65535) return fail(IST_E_UNSUPPORTED, "too much JPEG data for one GPU entropy-decode batch");
+  first_unit[n_img] = units.size();
+  const size_t n_unit = units.size();
+  // (the group -> unit map is 16 bits wide: a batch with more restart intervals than that goes to the host decoder)
+  if (n_unit > 65535) return IST_OK;
+  if (n_sub_total >= (1ll << 31)) return fail(IST_E_UNSUPPORTED, "too much JPEG data for one GPU entropy-decode batch");
   const int ns = static_cast<int>(n_sub_total);
   const int n_half = ns / kWriteThreads;            // groups of 128 subsequences (ns is a multiple of 256)
   // the small inputs (Huffman tables, image records, the group -> image map) are ONE contiguous region, uploaded by ONE copy
   // from a pinned block: as nine pageable copies of 10 KB each they were blocking staged copies, ~0.2 ms of the call
   const size_t o_small = off;
   for (size_t k = 0; k < n_img; ++k) o_tab[k] = take(sizeof(items[k].S->tables));
-  const size_t o_img = take(sizeof(DevImg) * n_img), o_sub = take(2 * static_cast<size_t>(n_half));
+  const size_t o_img = take(sizeof(DevImg) * n_unit), o_sub = take(2 * static_cast<size_t>(n_half));
   const size_t small_bytes = off - o_small;
   const size_t o_p0 = take(4 * static_cast<size_t>(ns)), o_p1 = take(4 * static_cast<size_t>(ns)), o_cz0 = take(4 * static_cast<size_t>(ns)), o_cz1 = take(4 * static_cast<size_t>(ns));
   const size_t o_sp = take(4 * static_cast<size_t>(ns)), o_scz = take(4 * static_cast<size_t>(ns));
   const size_t o_checks = take(24 * static_cast<size_t>(ns));
-  const size_t o_tally = take(16 * static_cast<size_t>(ns)), o_half = take(16 * static_cast<size_t>(n_half)), o_flag = take(4), o_err = take(4 * n_img);
+  const size_t o_tally = take(16 * static_cast<size_t>(ns)), o_half = take(16 * static_cast<size_t>(n_half)), o_flag = take(4), o_err = take(4 * n_unit);
   // the caller's grow-only scratch (a context keeps it across calls: no allocation, and no implicit device synchronisation
   // of a free, per call), or a one-off allocation
   uint8_t* d = nullptr;
@@ -538,7 +565,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     fr.p = d;
   }
   // pinned block: [small inputs | results: flag, half totals, error words]
-  const size_t res_bytes = 256 + 16 * static_cast<size_t>(n_half) + 4 * n_img;
+  const size_t res_bytes = 256 + 16 * static_cast<size_t>(n_half) + 4 * n_unit;
   struct Pin { uint8_t* p; ~Pin() { if (p) pool_give(p); } } pin{static_cast<uint8_t*>(pool_take(small_bytes + res_bytes))};
   if (!pin.p) return fail(IST_E_NOMEM, "out of pinned host memory for the Huffman decoder");
   // (every return below leaves the stream idle before `pin` goes back to the pool: the copies into it are waited for)
@@ -548,19 +575,22 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   uint32_t* h_half = reinterpret_cast<uint32_t*>(pin.p + small_bytes + 256);
   uint32_t* h_err = h_half + 4 * static_cast<size_t>(n_half);
   std::memset(hs, 0, small_bytes);
-  uint16_t* half_img = reinterpret_cast<uint16_t*>(hs + (o_sub - o_small));   // image of every group of 128 subsequences
+  uint16_t* half_img = reinterpret_cast<uint16_t*>(hs + (o_sub - o_small));   // unit of every group of 128 subsequences
   for (size_t k = 0; k < n_img; ++k) {
     const JpegGpuScan& S = *items[k].S;
     if (!items[k].d_stream) JG_HIP(hipMemcpyAsync(d + o_stream[k], S.stream.data(), S.stream.size(), hipMemcpyHostToDevice, stream));
     std::memcpy(hs + (o_tab[k] - o_small), S.tables, sizeof(S.tables));
-    H[k].stream = items[k].d_stream ? items[k].d_stream : d + o_stream[k];
-    H[k].tables = reinterpret_cast<const JpegHuffTable*>(d + o_tab[k]);
-    H[k].err = reinterpret_cast<uint32_t*>(d + o_err) + k;
-    for (int i = 0; i < ((H[k].n_sub + 255) & ~255); i += kWriteThreads) half_img[static_cast<size_t>((H[k].first_sub + i) / kWriteThreads)] = static_cast<uint16_t>(k);
+  }
+  for (size_t u = 0; u < n_unit; ++u) {
+    const size_t k = units[u].item;
+    H[u].stream = (items[k].d_stream ? items[k].d_stream : d + o_stream[k]) + units[u].byte_off;
+    H[u].tables = reinterpret_cast<const JpegHuffTable*>(d + o_tab[k]);
+    H[u].err = reinterpret_cast<uint32_t*>(d + o_err) + u;
+    for (int i = 0; i < ((H[u].n_sub + 255) & ~255); i += kWriteThreads) half_img[static_cast<size_t>((H[u].first_sub + i) / kWriteThreads)] = static_cast<uint16_t>(u);
     // (the writing pass stores every block of the planes whole, DC included: no clearing pass, no DC pass)
   }
-  JG_HIP(hipMemsetAsync(d + o_err, 0, 4 * n_img, stream));
-  std::memcpy(hs + (o_img - o_small), H.data(), sizeof(DevImg) * n_img);
+  JG_HIP(hipMemsetAsync(d + o_err, 0, 4 * n_unit, stream));
+  std::memcpy(hs + (o_img - o_small), H.data(), sizeof(DevImg) * n_unit);
   JG_HIP(hipMemcpyAsync(d + o_small, hs, small_bytes, hipMemcpyHostToDevice, stream));
   lap("alloc + uploads");
   const DevImg* d_img = reinterpret_cast<const DevImg*>(d + o_img);
@@ -597,13 +627,17 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   // ---- validation: exactly the blocks the frame header promises, and nothing the host decoder would reject
   const uint32_t* half = h_half; const uint32_t* err = h_err;
   JG_HIP(hipMemcpyAsync(h_half, d_half, 16 * static_cast<size_t>(n_half), hipMemcpyDeviceToHost, stream));
-  JG_HIP(hipMemcpyAsync(h_err, d + o_err, 4 * n_img, hipMemcpyDeviceToHost, stream));
+  JG_HIP(hipMemcpyAsync(h_err, d + o_err, 4 * n_unit, hipMemcpyDeviceToHost, stream));
   JG_HIP(hipStreamSynchronize(stream));
   for (size_t k = 0; k < n_img; ++k) {
-    const DevImg& I = H[k];
-    uint32_t blocks = 0;
-    for (int u = I.first_sub / kWriteThreads; u < (I.first_sub + ((I.n_sub + 255) & ~255)) / kWriteThreads; ++u) blocks += half[4 * static_cast<size_t>(u)];
-    (*ok)[k] = (blocks == static_cast<uint32_t>(I.total_blocks) && err[k] == 0) ? 1 : 0;
+    bool good = true;
+    for (size_t w = first_unit[k]; w < first_unit[k + 1]; ++w) {              // every restart interval holds exactly its MCUs
+      const DevImg& I = H[w];
+      uint32_t blocks = 0;
+      for (int u = I.first_sub / kWriteThreads; u < (I.first_sub + ((I.n_sub + 255) & ~255)) / kWriteThreads; ++u) blocks += half[4 * static_cast<size_t>(u)];
+      good = good && blocks == static_cast<uint32_t>(I.total_blocks) && err[w] == 0;
+    }
+    (*ok)[k] = good ? 1 : 0;
   }
   lap("validation");
 #undef JG_HIP

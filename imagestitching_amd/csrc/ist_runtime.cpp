@@ -39,6 +39,7 @@ int ctx_png_scratch(ist_ctx* ctx, size_t need, void** p) {
 }
 
 static std::atomic<int64_t> g_dev_allocs{0};
+static std::atomic<int64_t> g_gpu_entropy_files{0};
 int dev_malloc(void** p, size_t bytes) {
   g_dev_allocs.fetch_add(1, std::memory_order_relaxed);
   return static_cast<int>(hipMalloc(p, bytes));
@@ -124,6 +125,7 @@ int png_to_host(ist_ctx* ctx, const void* canvas, size_t pitch, int64_t w, int64
 extern "C" {
 
 int64_t ist_debug_device_allocs(void) { return g_dev_allocs.load(std::memory_order_relaxed); }
+int64_t ist_debug_gpu_entropy_files(void) { return g_gpu_entropy_files.load(std::memory_order_relaxed); }
 
 int ist_device_count(void) {
   int n = 0;
@@ -748,7 +750,10 @@ class FileDecoder {
     std::vector<uint8_t> okv;
     rc = jpeg_gpu_entropy_decode(items, &okv, consumer, &ctx_->scratch_huff, &ctx_->scratch_huff_bytes);
     if (rc) return rc;
-    for (size_t q = 0; q < who.size(); ++q) on_gpu_[static_cast<size_t>(who[q])] = okv[q] ? 1 : 0;
+    for (size_t q = 0; q < who.size(); ++q) {
+      on_gpu_[static_cast<size_t>(who[q])] = okv[q] ? 1 : 0;
+      if (okv[q]) g_gpu_entropy_files.fetch_add(1, std::memory_order_relaxed);
+    }
     return IST_OK;
   }
   // container + host entropy stage of image i; a baseline JPEG's de-stuffed scan goes up on the image's own stream

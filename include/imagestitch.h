@@ -131,6 +131,9 @@ IST_API int ist_device_count(void);                                   /* 0 when 
 /* device allocations (hipMalloc calls) the library has made in this process so far.  A measurement aid for hosts and tests:
  * the steady state of every entry point allocates nothing (scratch, arenas and table blocks are kept and re-used). */
 IST_API int64_t ist_debug_device_allocs(void);
+/* JPEG files whose entropy-coded scan the GPU Huffman decoder has decoded AND validated in this process so far (files it
+ * handed back to the host decoder do not count).  Tests use it to tell the GPU path from the silent host fall-back. */
+IST_API int64_t ist_debug_gpu_entropy_files(void);
 
 /* ---- planner: pure CPU, bit-exact to index.js:1211-1216, 1251-1386, 1432-1433, 1522-1554 -------------------- */
 IST_API void ist_limits_default(int platform, ist_limits* out);        /* index.js:126-156 fallback branch */

@@ -145,12 +145,85 @@ def test_gpu_entropy_decoder_full_size_and_mixed_inputs(tmp_path):
     (tmp_path / "a.jpg").write_bytes(base)
     (tmp_path / "b.jpg").write_bytes(prog)
     Image.fromarray(_photo(93, 100, 4032)).save(tmp_path / "c.png")
-    rst = _jpeg(_photo(94, 64, 4032), quality=85, subsampling=2, restart_marker_blocks=7)      # restart intervals: host Huffman
+    rst = _jpeg(_photo(94, 64, 4032), quality=85, subsampling=2, restart_marker_blocks=7)      # restart intervals: each one its own stream on the GPU
     assert b"\xff\xdd" in rst
     (tmp_path / "d.jpg").write_bytes(rst)
     res = ist.stitch_files([str(tmp_path / "a.jpg"), str(tmp_path / "b.jpg"), str(tmp_path / "c.png"), str(tmp_path / "d.jpg")], "vertical", {"filter": "nearest"})
     want = np.concatenate([_pil(base), _pil(prog), np.asarray(Image.open(tmp_path / "c.png").convert("RGBA")), _pil(rst)], 0)
     assert np.array_equal(ist.decode_png(res["png"]), want)
+
+
+def _gpu_files():
+    from imagestitching_amd import _lib as L
+    return L.lib.ist_debug_gpu_entropy_files()
+
+
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+@pytest.mark.parametrize("restart", [{"restart_marker_rows": 1}, {"restart_marker_blocks": 2}, {"restart_marker_blocks": 5}, {"restart_marker_rows": 3}])
+def test_gpu_entropy_decoder_takes_restart_intervals(tmp_path, subsampling, restart):
+    """Files with DRI: every restart interval is an independent stream (T.81 E.1.4: byte aligned, DC predictors reset), so
+    the GPU decoder takes each as a unit of its batch writing into the same planes at the interval's first MCU.  The
+    counter proves the GPU path decoded them (the host fall-back would give the same pixels)."""
+    paths, want = [], []
+    for k, (h, w) in enumerate([(203, 317), (64, 317), (16, 317), (411, 317)]):
+        data = _jpeg(_photo(140 + 5 * k + subsampling, h, w), quality=85, subsampling=subsampling, **restart)
+        assert b"\xff\xdd" in data and (h <= 16 or b"\xff\xd0" in data)
+        p = tmp_path / ("r%d.jpg" % k)
+        p.write_bytes(data)
+        paths.append(str(p))
+        want.append(_pil(data))
+    grey = io.BytesIO()
+    Image.fromarray(_photo(177, 100, 317)).convert("L").save(grey, "JPEG", quality=80, **restart)
+    (tmp_path / "grey.jpg").write_bytes(grey.getvalue())
+    paths.append(str(tmp_path / "grey.jpg"))
+    want.append(_pil(grey.getvalue()))
+    before = _gpu_files()
+    res = ist.stitch_files(paths, "vertical", {"filter": "nearest"})
+    assert np.array_equal(ist.decode_png(res["png"]), np.concatenate(want, 0))
+    assert _gpu_files() - before == len(paths)
+
+
+def test_gpu_entropy_decoder_restart_intervals_full_size_and_too_many(tmp_path):
+    """a 12 MP photo with one interval per MCU row (189 units, 15 000 subsequences) on the GPU; the same photo with an
+    interval per MCU (47 628 of them) is left to the host decoder, and both give PIL's pixels"""
+    a = _photo(191, 3024, 4032)
+    rows = _jpeg(a, quality=88, subsampling=2, restart_marker_rows=1)
+    every = _jpeg(a[:1024], quality=88, subsampling=2, restart_marker_blocks=1)
+    (tmp_path / "rows.jpg").write_bytes(rows)
+    (tmp_path / "every.jpg").write_bytes(every)
+    before = _gpu_files()
+    res = ist.stitch_files([str(tmp_path / "rows.jpg"), str(tmp_path / "every.jpg")], "vertical", {"filter": "nearest"})
+    assert np.array_equal(ist.decode_png(res["png"]), np.concatenate([_pil(rows), _pil(every)], 0))
+    assert _gpu_files() - before == 1
+
+
+def test_gpu_entropy_decoder_damaged_restart_markers_go_to_the_host(tmp_path):
+    """a marker missing, a marker out of sequence, one too many, and a truncated interval: never the GPU path's pixels
+    unless they are the host decoder's too"""
+    good = _jpeg(_photo(195, 120, 160), quality=85, subsampling=2, restart_marker_rows=1)
+    marks = [i for i in range(good.find(b"\xff\xda"), len(good) - 1) if good[i] == 0xFF and 0xD0 <= good[i + 1] <= 0xD7]
+    assert len(marks) == 7
+    cases = {}
+    cases["missing"] = good[:marks[2]] + good[marks[2] + 2:]
+    swapped = bytearray(good); swapped[marks[1] + 1], swapped[marks[2] + 1] = swapped[marks[2] + 1], swapped[marks[1] + 1]
+    cases["out_of_sequence"] = bytes(swapped)
+    cases["one_too_many"] = good[:-2] + b"\xff\xd7" + good[marks[0] + 2:marks[1]] + good[-2:]
+    cases["short_interval"] = good[:marks[3] + 2] + good[marks[3] + 12:]
+    for name, data in cases.items():
+        p = tmp_path / (name + ".jpg")
+        p.write_bytes(data)
+        try:
+            host = ist.decode_image(data)
+        except ist.StitchError:
+            host = None
+        try:
+            res = ist.stitch_files([str(p)], "vertical", {"filter": "nearest"})
+        except ist.StitchError as e:
+            assert host is None, name
+            assert "解码异常" in str(e)
+        else:
+            assert host is not None, name
+            assert np.array_equal(ist.decode_png(res["png"]), host), name
 
 
 def test_gpu_entropy_decoder_hands_damaged_scans_to_the_host_decoder(tmp_path):
