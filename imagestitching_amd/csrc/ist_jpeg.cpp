@@ -250,7 +250,15 @@ static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool head
       // the GPU entropy decoder takes baseline files whose single scan interleaves all components, without restarts
       int mcu_blocks = 0;
       for (int s2 = 0; s2 < ns; ++s2) mcu_blocks += J->comp[ci[s2]].h * J->comp[ci[s2]].v;
-      if (gs && !progressive && J->scans == 0 && ns == J->ncomp && mcu_blocks <= 10 &&      // (T.81 B.2.3: at most 10 blocks per MCU)
+      // ... and names at most two DC and two AC tables (the GPU decoder keeps that many in LDS)
+      int dc_ids[2] = {-1, -1}, ac_ids[2] = {-1, -1}, dc_local[4] = {0, 0, 0, 0}, ac_local[4] = {0, 0, 0, 0};
+      bool two_tables = true;
+      for (int s2 = 0; s2 < ns; ++s2) {
+        auto local = [&](int (&ids)[2], int id) { for (int q = 0; q < 2; ++q) { if (ids[q] == id) return q; if (ids[q] < 0) { ids[q] = id; return q; } } return -1; };
+        dc_local[s2] = local(dc_ids, td[s2]); ac_local[s2] = local(ac_ids, ta[s2]);
+        if (dc_local[s2] < 0 || ac_local[s2] < 0) two_tables = false;
+      }
+      if (gs && !progressive && J->scans == 0 && ns == J->ncomp && two_tables && mcu_blocks <= 10 &&      // (T.81 B.2.3: at most 10 blocks per MCU)
           (f + n) - (d + dl) < (1ll << 28)) {      // (32-bit bit positions on the GPU)
         for (int c = 0; c < J->ncomp; ++c) {
           if (!have_q[J->comp[c].tq]) return fail(IST_E_DECODE, "JPEG component uses an undefined quantisation table");
@@ -260,18 +268,30 @@ static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool head
         for (int s2 = 0; s2 < ns; ++s2) {
           const JpegComp& C = J->comp[ci[s2]];
           for (int k = 0; k < C.h * C.v; ++k) { gs->slot_comp[gs->slots] = static_cast<uint8_t>(ci[s2]); gs->slot_idx[gs->slots] = static_cast<uint8_t>(k); ++gs->slots; }
-          gs->dc_tab[ci[s2]] = static_cast<uint8_t>(td[s2]); gs->ac_tab[ci[s2]] = static_cast<uint8_t>(4 + ta[s2]);
+          gs->dc_tab[ci[s2]] = static_cast<uint8_t>(dc_local[s2]); gs->ac_tab[ci[s2]] = static_cast<uint8_t>(ac_local[s2]);
         }
-        for (int t = 0; t < 8; ++t) {
-          const Huff& h = t < 4 ? dc[t] : ac[t - 4];
-          JpegHuffTable& o = gs->tables[t];
-          std::memset(&o, 0, sizeof o);
-          if (!h.present) continue;                 // (all-zero: every pattern is "no code"; the scan cannot select it anyway)
-          std::memcpy(o.look, h.look, sizeof o.look);
-          for (int k = 0; k < 8; ++k) {               // one past the last code of length 9+k, left-aligned
-            const int l = 9 + k;
-            o.lim[k] = static_cast<uint32_t>(h.mincode[l] + h.bits[l]) << (16 - l);
-            if (k < 7) o.vptr[k] = static_cast<uint8_t>(h.valptr[l + 1]);
+        std::memset(&gs->tables, 0, sizeof gs->tables);      // (a table the scan does not name stays all "no code")
+        for (int t = 0; t < 4; ++t) {
+          const bool is_ac = t >= 2;
+          const int id = is_ac ? ac_ids[t - 2] : dc_ids[t];
+          if (id < 0) continue;
+          const Huff& h = is_ac ? ac[id] : dc[id];
+          const int look_bits = is_ac ? kJpegAcLookBits : kJpegDcLookBits;
+          uint16_t* look = is_ac ? gs->tables.look_ac[t - 2] : gs->tables.look_dc[t];
+          int code = 0, k = 0;
+          for (int l = 1; l <= look_bits; ++l) {              // canonical codes in order of length (T.81 C.2)
+            for (int i = 0; i < h.bits[l]; ++i, ++k, ++code) {
+              const uint16_t e = static_cast<uint16_t>((l << 8) | h.vals[k]);
+              uint16_t* at = look + (static_cast<size_t>(code) << (look_bits - l));
+              std::fill(at, at + (size_t{1} << (look_bits - l)), e);
+            }
+            code <<= 1;
+          }
+          JpegHuffTail& o = gs->tables.tail[t];
+          for (int q = 0; q < 8; ++q) {                       // one past the last code of length 9+q, left-aligned
+            const int l = 9 + q;
+            o.lim[q] = static_cast<uint32_t>(h.mincode[l] + h.bits[l]) << (16 - l);
+            if (q < 7) o.vptr[q] = static_cast<uint8_t>(h.valptr[l + 1]);
           }
           std::memcpy(o.vals, h.vals, sizeof o.vals);
         }

@@ -54,15 +54,29 @@ struct JpegImage {
 };
 
 // ---- what the GPU entropy decoder (ist_jpeg_gpu.hip) needs from the container: the de-stuffed scan and its tables ----
-struct alignas(16) JpegHuffTable {     // one Huffman table in the form the GPU decoder uses (LDS resident, 1328 bytes)
-  uint16_t look[512];                  // 9-bit look-ahead: (length << 8) | symbol, 0 = longer than 9 bits
-  // codes of 10..16 bits, branch-free: lim[k] = the first code of length 10+k, left-aligned to 16 bits (= one past the
-  // last code of length 9+k; canonical codes make it monotonic), lim[7] = one past the last 16-bit code.  With v = the
-  // next 16 bits: length = 10 + #{k in 1..6 : v >= lim[k]}, symbol = vals[vptr[length-10] + ((v - lim[length-10]) >> (16-length))]
+// One Huffman table's codes BEHIND its look-ahead table, branch-free: lim[k] = the first code of length 10+k, left-aligned to
+// 16 bits (= one past the last code of length 9+k; canonical codes make it monotonic), lim[7] = one past the last 16-bit code.
+// With v = the next 16 bits: length = 10 + #{k in 1..6 : v >= lim[k]}, symbol = vals[vptr[length-10] + ((v - lim[length-10]) >> (16-length))]
+struct alignas(16) JpegHuffTail {
   uint32_t lim[8];
   uint8_t vptr[8];                     // index in vals of the first symbol of length 10+k
   uint8_t pad_[8];
   uint8_t vals[256];
+};
+// The tables of one scan in the form the GPU decoder keeps in LDS (5 312 bytes): at most two DC and two AC tables (what
+// every encoder in the field writes; a scan that names more stays on the host).  Look-ahead entries: (length << 8) | symbol,
+// 0 = the code is longer than the look-ahead.  (measured, nine 12 MP photos: an 11-bit look-ahead for the AC tables - the codes
+// behind a miss cost four dependent LDS reads - changed nothing, 1.19-1.25 vs 1.19-1.24 ms for the sync launches: what
+// paces them is the chain of subsequences that hand a wrong state on, one decode time per link.  9 bits keep the writing
+// kernel at four workgroups per CU.)
+#ifndef IST_AC_LOOK_BITS
+#define IST_AC_LOOK_BITS 9
+#endif
+constexpr int kJpegDcLookBits = 9, kJpegAcLookBits = IST_AC_LOOK_BITS;
+struct alignas(16) JpegGpuTables {
+  uint16_t look_dc[2][1 << kJpegDcLookBits];
+  uint16_t look_ac[2][1 << kJpegAcLookBits];
+  JpegHuffTail tail[4];                // 0-1: the DC tables, 2-3: the AC tables
 };
 // One restart interval of a scan (T.81 E.1.4: the entropy coder is reset at every RSTn, so an interval decodes on its own):
 // its de-stuffed bytes start at byte_off of JpegGpuScan::stream (a multiple of 256, at least 16 zero bytes behind its last bit).
@@ -74,8 +88,8 @@ struct JpegGpuScan {
   int64_t bits = 0;                    // valid bits in stream
   int slots = 0;                       // blocks per MCU
   uint8_t slot_comp[10], slot_idx[10]; // per MCU slot: component, block index inside the component's h x v group
-  uint8_t dc_tab[3], ac_tab[3];        // per component: index into tables[] (0-3 DC, 4-7 AC)
-  JpegHuffTable tables[8];
+  uint8_t dc_tab[3], ac_tab[3];        // per component: which of the scan's two DC / two AC tables (0 or 1)
+  JpegGpuTables tables;
 };
 
 // container parsing + Huffman decoding (host).  header_only stops after the frame header (size, sampling, orientation

@@ -43,7 +43,10 @@ namespace {
 // bits per subsequence (compile-time: it sizes the LDS staging area).  Whole call on nine 12 MP photos, round 2 kernels:
 // 1024 bits 4.5 ms, 2048 bits 4.3 ms, 4096 bits 5.4 ms.  With the bitstream staged in LDS the decode is no longer paced
 // by global-memory latency, and the shorter subsequence gives every SIMD two waves instead of one.
-constexpr int kSubBits = 1024;
+#ifndef IST_SUB_BITS
+#define IST_SUB_BITS 1024
+#endif
+constexpr int kSubBits = IST_SUB_BITS;
 constexpr int kSyncThreads = 256;       // subsequences per workgroup of the synchronisation kernel
 constexpr int kWriteThreads = 128;      // ... of the writing kernel (it also holds one 8x8 block per thread in LDS)
 constexpr int kMarginWords = 64;        // staged behind a workgroup's own bits: a block can run 64 x 27 bits past its start
@@ -55,7 +58,7 @@ __constant__ uint8_t kZig[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 1
 
 struct DevImg {
   const uint8_t* stream; int64_t bits;
-  const JpegHuffTable* tables;            // 8 per image
+  const JpegGpuTables* tables;            // the scan's two DC + two AC tables
   int32_t first_sub, n_sub;
   int32_t slots, total_blocks, mcus_x;
   int32_t mcu0;                           // the MCU its first block belongs to (non-zero: a later restart interval of a scan)
@@ -74,7 +77,7 @@ typedef const __attribute__((address_space(1))) uint32_t* GlobalWords;
 typedef __attribute__((address_space(1))) int16_t* GlobalI16;
 typedef __attribute__((address_space(1))) uint32_t* GlobalU32;
 
-// What a workgroup keeps in LDS: the eight Huffman tables and the record of its image (a workgroup never spans two
+// What a workgroup keeps in LDS: the scan's Huffman tables and the record of its image (a workgroup never spans two
 // images: the host pads every image's subsequences to a multiple of 256) and ITS PART OF THE BITSTREAM, byte-swapped
 // into big-endian words, plus a margin.  The decoding loop then touches global memory only to store finished blocks.
 // (Round 2's first version kept all of this in global memory.  What paced it was not the dependent look-ups but the
@@ -82,7 +85,7 @@ typedef __attribute__((address_space(1))) uint32_t* GlobalU32;
 // waited for somebody's global load — 1.8 us per symbol step with one wave per SIMD, measured.)
 template <int THREADS>
 struct WgShared {
-  JpegHuffTable tab[8];
+  JpegGpuTables tab;
   uint32_t bits[THREADS * (kSubBits / 32) + kMarginWords];
   DevImg img;
   uint32_t slot_tabs[12];               // per MCU slot: (component << 16) | (AC table << 8) | DC table
@@ -92,22 +95,22 @@ struct WgShared {
 // (THREADS = the subsequences whose bits are staged; the loops stride by the real workgroup size)
 template <int THREADS>
 __device__ __forceinline__ void load_record(WgShared<THREADS>* sh, const DevImg* img) {
-  static_assert(sizeof(DevImg) % 4 == 0 && sizeof(JpegHuffTable) % 4 == 0, "word copies");
+  static_assert(sizeof(DevImg) % 4 == 0 && sizeof(JpegGpuTables) % 4 == 0, "word copies");
   const uint32_t* gi = reinterpret_cast<const uint32_t*>(img);
   uint32_t* li = reinterpret_cast<uint32_t*>(&sh->img);
   for (uint32_t k = threadIdx.x; k < sizeof(DevImg) / 4; k += blockDim.x) li[k] = gi[k];
   if (threadIdx.x < 64) sh->zig[threadIdx.x] = kZig[threadIdx.x];
   if (threadIdx.x < 10) {
     const uint32_t comp = img->slot_comp[threadIdx.x] < 3 ? img->slot_comp[threadIdx.x] : 0u;
-    sh->slot_tabs[threadIdx.x] = (img->dc_tab[comp] & 7u) | (static_cast<uint32_t>(img->ac_tab[comp] & 7u) << 8) | (comp << 16);
+    sh->slot_tabs[threadIdx.x] = (img->dc_tab[comp] & 1u) | (static_cast<uint32_t>(img->ac_tab[comp] & 1u) << 8) | (comp << 16);
   }
   __syncthreads();
 }
 template <int THREADS>
 __device__ __forceinline__ void load_stream(WgShared<THREADS>* sh, const DevImg* img, uint32_t first_bit) {
   const uint32_t* gt = reinterpret_cast<const uint32_t*>(img->tables);
-  uint32_t* lt = reinterpret_cast<uint32_t*>(sh->tab);
-  for (uint32_t k = threadIdx.x; k < 8 * sizeof(JpegHuffTable) / 4; k += blockDim.x) lt[k] = gt[k];
+  uint32_t* lt = reinterpret_cast<uint32_t*>(&sh->tab);
+  for (uint32_t k = threadIdx.x; k < sizeof(JpegGpuTables) / 4; k += blockDim.x) lt[k] = gt[k];
   // the stream is 256-byte aligned on the device and carries 16 bytes of zero padding behind its last bit; first_bit
   // is a multiple of kSubBits, so these are aligned word loads.  Words past the padding read as zero.
   const uint32_t words_in_stream = static_cast<uint32_t>((img->bits >> 3) + 16) >> 2;
@@ -130,10 +133,16 @@ __device__ __forceinline__ uint64_t window(const WgShared<THREADS>* sh, uint32_t
 }
 
 // symbol + its length; a bit pattern that is no code (only ever met on a speculative, out-of-phase path, or in a corrupt
-// file) consumes one bit.  Codes longer than 9 bits take three dependent LDS reads instead of a loop over the lengths.
-__device__ __forceinline__ int huff(const JpegHuffTable& h, uint32_t v16, uint32_t* len) {
-  const uint32_t e = h.look[v16 >> 7];
+// file) consumes one bit.  tab = which of the scan's two tables of its class.  Codes behind the look-ahead (9 bits DC,
+// 11 bits AC: ist_jpeg.h) take three dependent LDS reads instead of a loop over the lengths.
+__device__ __forceinline__ int huff(const JpegGpuTables& T, bool isdc, uint32_t tab, uint32_t v16, uint32_t* len) {
+  const uint16_t* look = reinterpret_cast<const uint16_t*>(&T);      // (look_dc and look_ac are adjacent: one base, two index rules)
+  static_assert(offsetof(JpegGpuTables, look_dc) == 0 && offsetof(JpegGpuTables, look_ac) == sizeof(uint16_t) * 2 * (1 << kJpegDcLookBits), "flat look-ahead index");
+  const uint32_t at = isdc ? (tab << kJpegDcLookBits) + (v16 >> (16 - kJpegDcLookBits))
+                           : (2u << kJpegDcLookBits) + (tab << kJpegAcLookBits) + (v16 >> (16 - kJpegAcLookBits));
+  const uint32_t e = look[at];
   if (e) { *len = e >> 8; return static_cast<int>(e & 0xFF); }
+  const JpegHuffTail& h = T.tail[isdc ? tab : 2u + tab];
   const uint4 a = *reinterpret_cast<const uint4*>(&h.lim[0]), b = *reinterpret_cast<const uint4*>(&h.lim[4]);
   if (v16 >= b.w) { *len = 1; return -1; }
   const uint32_t k = (v16 >= a.y) + (v16 >= a.z) + (v16 >= a.w) + (v16 >= b.x) + (v16 >= b.y) + (v16 >= b.z);
@@ -152,7 +161,7 @@ __device__ __forceinline__ void symbol(const WgShared<THREADS>* sh, uint32_t fir
   const bool isdc = S.z == 0;
   uint32_t len;
   const uint64_t w = window(sh, first_bit, S.p);
-  const int rs = huff(sh->tab[(isdc ? tabs : (tabs >> 8)) & 7u], static_cast<uint32_t>(w >> 48), &len);
+  const int rs = huff(sh->tab, isdc, (isdc ? tabs : (tabs >> 8)) & 1u, static_cast<uint32_t>(w >> 48), &len);
   S.p += len;
   *stored = false; *bad = false;
   if (rs < 0 && !isdc) { *bad = true; return; }
@@ -313,15 +322,24 @@ struct SyncArgs {
 // host-synchronised pass.  Across workgroups the first thread starts from the exit state its left neighbour reached in
 // the PREVIOUS launch; a launch in which no workgroup's last exit state changed is the global fixed point.  (The
 // "overflow" idea of the published scheme, restated for a barrier-synchronised workgroup.)
-constexpr int kInnerPasses = 48;
+#ifndef IST_INNER_PASSES
+#define IST_INNER_PASSES 48
+#endif
+constexpr int kInnerPasses = IST_INNER_PASSES;
 // GHOST LANES.  In the first launch the first thread of a workgroup has no left neighbour to take its start state from
 // (that neighbour belongs to the previous workgroup), so the whole workgroup used to settle on a guess, and the second
 // launch — whose only news is the previous workgroup's true exit state — re-decoded thread 0 of nearly EVERY workgroup:
-// a full subsequence time for the launch, since a pass costs as much as its slowest lane.  Now a fifth wave carries two
-// ghost lanes that decode the two subsequences in front of the workgroup (from a guess, then from each other), and
-// thread 0 starts from the second ghost's exit: after two subsequences the decoder is in step almost surely, so the
-// second launch finds nothing to redo and returns before it stages anything (0.35 -> 0.05 ms, measured).
-constexpr int kGhosts = 2;
+// a full subsequence time for the launch, since a pass costs as much as its slowest lane.  Now a fifth wave carries
+// ghost lanes that decode the subsequences in front of the workgroup (from a guess, then from each other), and thread 0
+// starts from the last ghost's exit.  How many: a decoder falls into step with the code boundaries within a few symbols,
+// but with the MCU SLOT (which table set applies) only by chance, about once in three MCUs - a subsequence in four
+// hands a wrong state on.  With 2 ghosts some of a call's 531 workgroups therefore still started wrong and the second
+// launch cost 0.24 ms; with 6 or more it finds nothing to redo and returns in 7 us (nine 12 MP photos, kernel trace:
+// sync launches 0.89 + 0.24 ms -> 0.94-1.09 + 0.007 ms; both launches timed on the host 1.19-1.25 -> 0.99-1.00 ms).
+#ifndef IST_GHOSTS
+#define IST_GHOSTS 8
+#endif
+constexpr int kGhosts = IST_GHOSTS;
 constexpr int kSyncBlock = kSyncThreads + 64;
 
 __global__ __launch_bounds__(kSyncBlock) void ist_jpeg_sync_kernel(const SyncArgs A) {
@@ -420,7 +438,16 @@ struct WriteArgs { const DevImg* imgs; const uint16_t* sub_img; const uint32_t* 
 __global__ __launch_bounds__(kWriteThreads) void ist_jpeg_write_kernel(const WriteArgs A) {
   __shared__ WgShared<kWriteThreads> sh;
   __shared__ uint32_t slots[kWriteThreads * 33];                 // one 8x8 block per thread, 33-word pitch (bank-conflict free)
-  __shared__ uint32_t sc[4][kWriteThreads];
+  // (the scan of the tallies borrows the first 2 KB of the slots, which are cleared again once it is done: 39 KB of LDS per
+  // workgroup = FOUR per CU.  The 1017 workgroups of nine 12 MP photos then run side by side; with three per CU (768
+  // places) a quarter of them ran as a second round behind the others, and the launch took two decode times instead of one.)
+#ifdef IST_NO_ALIAS
+  __shared__ uint32_t sc_own[4][kWriteThreads];
+  uint32_t (*sc)[kWriteThreads] = sc_own;
+#else
+  uint32_t (*sc)[kWriteThreads] = reinterpret_cast<uint32_t (*)[kWriteThreads]>(slots);
+#endif
+  static_assert(4 * kWriteThreads <= kWriteThreads * 33, "the scan arrays fit in the slots");
   __shared__ uint32_t base[4];
   const int tid = threadIdx.x;
   const int g0 = blockIdx.x * kWriteThreads, g = g0 + tid;
@@ -453,9 +480,14 @@ __global__ __launch_bounds__(kWriteThreads) void ist_jpeg_write_kernel(const Wri
     for (int c = 0; c < 4; ++c) sc[c][tid] += t[c];
     __syncthreads();
   }
-  if (!live) return;
   uint32_t ex[4];
   for (int c = 0; c < 4; ++c) ex[c] = base[c] + sc[c][tid] - mine[c];
+#ifndef IST_NO_ALIAS
+  __syncthreads();                                               // every thread has its sums: the borrowed words are slots again
+  for (int k = tid; k < 4 * kWriteThreads; k += kWriteThreads) slots[k] = 0u;
+  __syncthreads();
+#endif
+  if (!live) return;
   State S;
   if (i == 0) { S.p = 0; S.c = 0; S.z = 0; } else { S.p = A.p[g - 1]; S.c = A.cz[g - 1] >> 8; S.z = A.cz[g - 1] & 255u; }
   const uint64_t end = static_cast<uint64_t>(i + 1) * static_cast<uint64_t>(kSubBits);
@@ -579,12 +611,12 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   for (size_t k = 0; k < n_img; ++k) {
     const JpegGpuScan& S = *items[k].S;
     if (!items[k].d_stream) JG_HIP(hipMemcpyAsync(d + o_stream[k], S.stream.data(), S.stream.size(), hipMemcpyHostToDevice, stream));
-    std::memcpy(hs + (o_tab[k] - o_small), S.tables, sizeof(S.tables));
+    std::memcpy(hs + (o_tab[k] - o_small), &S.tables, sizeof(S.tables));
   }
   for (size_t u = 0; u < n_unit; ++u) {
     const size_t k = units[u].item;
     H[u].stream = (items[k].d_stream ? items[k].d_stream : d + o_stream[k]) + units[u].byte_off;
-    H[u].tables = reinterpret_cast<const JpegHuffTable*>(d + o_tab[k]);
+    H[u].tables = reinterpret_cast<const JpegGpuTables*>(d + o_tab[k]);
     H[u].err = reinterpret_cast<uint32_t*>(d + o_err) + u;
     for (int i = 0; i < ((H[u].n_sub + 255) & ~255); i += kWriteThreads) half_img[static_cast<size_t>((H[u].first_sub + i) / kWriteThreads)] = static_cast<uint16_t>(u);
     // (the writing pass stores every block of the planes whole, DC included: no clearing pass, no DC pass)
