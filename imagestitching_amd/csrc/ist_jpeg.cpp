@@ -20,6 +20,8 @@
 #include "ist_internal.h"
 #include "ist_jpeg.h"
 
+#include <emmintrin.h>
+
 namespace ist {
 
 namespace {
@@ -302,49 +304,67 @@ static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool head
         // decoder below (which has the resynchronisation rules); too few intervals fail the GPU decoder's block count and
         // end up there too.
         const uint8_t* q = d + dl; const uint8_t* qe = f + n;
-        gs->stream.clear(); gs->stream.reserve(static_cast<size_t>(qe - q) + 16);
         gs->iv.clear();
         const uint32_t total_mcus = static_cast<uint32_t>(J->mcus_x) * static_cast<uint32_t>(J->mcus_y);
         const uint32_t ri = static_cast<uint32_t>(restart_interval);
         const uint32_t n_iv = ri ? (total_mcus + ri - 1) / ri : 0;
-        size_t iv_start = 0; uint32_t next_rst = 0;
         // (every interval occupies whole workgroups of the GPU decoder - 32 KB of bitstream positions - so a file cut into
         // thousands of tiny intervals is cheaper on the host)
         bool in_sequence = n_iv <= kMaxGpuIntervals;
+        // the output never overtakes the input; every interval adds at most 271 bytes of padding; 32 bytes of slack for the
+        // 16-byte stores of the copy loop and the 16 zero bytes behind the last bit
+        gs->stream.clear();
+        if (in_sequence && !gs->stream.reserve(static_cast<size_t>(qe - q) + static_cast<size_t>(n_iv) * 272 + 32)) return fail(IST_E_NOMEM, "out of memory for the JPEG scan");
+        uint8_t* const base = gs->stream.data();
+        uint8_t* out = base;
+        size_t iv_start = 0; uint32_t next_rst = 0;
         auto close_interval = [&]() {
           const uint32_t k = static_cast<uint32_t>(gs->iv.size());
+          const size_t at = static_cast<size_t>(out - base);
           JpegGpuInterval I;
           I.byte_off = static_cast<uint32_t>(iv_start); I.mcu0 = k * ri; I.n_mcus = std::min(ri, total_mcus - k * ri);
-          I.bits = static_cast<int64_t>(gs->stream.size() - iv_start) * 8;
+          I.bits = static_cast<int64_t>(at - iv_start) * 8;
           gs->iv.push_back(I);
-          size_t pad = (256 - gs->stream.size() % 256) % 256;
+          size_t pad = (256 - at % 256) % 256;
           if (pad < 16) pad += 256;
-          gs->stream.insert(gs->stream.end(), pad, 0);
-          iv_start = gs->stream.size();
+          std::memset(out, 0, pad);
+          out += pad;
+          iv_start = at + pad;
         };
+        const __m128i all_ff = _mm_set1_epi8(static_cast<char>(0xFF));
         while (in_sequence && q < qe) {
-          const uint8_t* ff = static_cast<const uint8_t*>(std::memchr(q, 0xFF, static_cast<size_t>(qe - q)));
-          if (!ff) { gs->stream.insert(gs->stream.end(), q, qe); q = qe; break; }
-          gs->stream.insert(gs->stream.end(), q, ff);
-          if (ff + 1 < qe && ff[1] == 0x00) { gs->stream.push_back(0xFF); q = ff + 2; continue; }
-          if (ff + 1 < qe && ff[1] == 0xFF) { q = ff + 1; continue; }            // fill byte
-          if (ff + 1 < qe && ff[1] >= 0xD0 && ff[1] <= 0xD7) {
-            if (!ri || ff[1] != 0xD0 + next_rst || gs->iv.size() + 1 >= n_iv) { in_sequence = false; break; }
+          // 16 bytes at a time while none of them is FF (a photo's scan has one FF in ~256 bytes): the copy runs ahead of
+          // the test, the bytes behind an FF are simply overwritten by the next round
+          while (q + 16 <= qe) {
+            const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(q));
+            _mm_storeu_si128(reinterpret_cast<__m128i*>(out), v);
+            const int m = _mm_movemask_epi8(_mm_cmpeq_epi8(v, all_ff));
+            if (m) { const int k = __builtin_ctz(static_cast<unsigned>(m)); q += k; out += k; break; }
+            q += 16; out += 16;
+          }
+          if (q >= qe) break;
+          if (*q != 0xFF) { *out++ = *q++; continue; }                            // (the last 15 bytes of the file, one by one)
+          if (q + 1 < qe && q[1] == 0x00) { *out++ = 0xFF; q += 2; continue; }
+          if (q + 1 < qe && q[1] == 0xFF) { q += 1; continue; }                   // fill byte
+          if (q + 1 < qe && q[1] >= 0xD0 && q[1] <= 0xD7) {
+            if (!ri || q[1] != 0xD0 + next_rst || gs->iv.size() + 1 >= n_iv) { in_sequence = false; break; }
             close_interval();                                                     // RSTn in sequence, and another interval is due
             next_rst = (next_rst + 1) & 7u;
-            q = ff + 2;
+            q += 2;
             continue;
           }
-          q = ff; break;                                                          // a marker (or a lone FF at the end)
+          break;                                                                  // a marker (or a lone FF at the end)
         }
         if (in_sequence) {
           if (ri) {
             close_interval();                                                     // the last interval (ends at the marker that ends the scan)
-            gs->bits = static_cast<int64_t>(gs->stream.size()) * 8;
+            gs->bits = static_cast<int64_t>(out - base) * 8;
           } else {
-            gs->bits = static_cast<int64_t>(gs->stream.size()) * 8;
-            gs->stream.insert(gs->stream.end(), 16, 0);
+            gs->bits = static_cast<int64_t>(out - base) * 8;
+            std::memset(out, 0, 16);
+            out += 16;
           }
+          gs->stream.set_size(static_cast<size_t>(out - base));
           gs->eligible = true;
           pos = q - f;
           J->scans++;

@@ -28,7 +28,11 @@ static void one(const std::vector<uint8_t>& f, long* ok, long* bad) {
     if (rc == IST_OK) {                                        // the container walk that feeds the GPU entropy decoder (de-stuffing, tables)
       ist::JpegImage J2; ist::JpegGpuScan G;
       (void)ist::jpeg_parse_and_entropy_decode(p, n, &J2, false, &G);
-      if (G.eligible && (G.slots < 1 || G.slots > 10 || G.bits < 0 || G.stream.size() < size_t(G.bits / 8) + 16)) abort();
+      if (G.eligible && (G.slots < 1 || G.slots > 10 || G.bits < 0 || G.stream.size() > G.stream.capacity())) abort();
+      if (G.eligible && G.iv.empty() && G.stream.size() != size_t(G.bits / 8) + 16) abort();
+      for (const ist::JpegGpuInterval& V : G.iv)                 // restart intervals: aligned, inside the scan, 16 zero bytes behind each
+        if (V.byte_off % 256 || V.bits < 0 || V.bits % 8 || size_t(V.byte_off) + size_t(V.bits / 8) + 16 > G.stream.size() ||
+            int64_t(V.mcu0) + V.n_mcus > int64_t(J2.mcus_x) * J2.mcus_y) abort();
     }
   } else if (ist::is_webp(p, n)) {
     rc = ist::webp_info(p, n, &w, &h, &o);
