@@ -6,6 +6,8 @@
 // the IJG / libjpeg-turbo decoders use by default, so that the pixels agree with the witness the tests have (PIL).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "ist_internal.h"
 #include "ist_jpeg.h"
 
@@ -47,12 +49,18 @@ __device__ __forceinline__ void idct8(const int in[8], int out[8], int shift, bo
 
 // (the quantisation table travels BY VALUE in the kernel arguments: 128 bytes, read with scalar loads - as a 128-byte upload per
 // component it was three 5 us blit copies in front of every image's reconstruction)
-struct IdctArgs { const int16_t* coef; uint16_t q[64]; uint8_t* plane; int blocks_x, blocks_y; };
+// ALL components of an image in ONE launch (a workgroup belongs to one component: wg0[c] = its first workgroup): as a launch
+// per component the reconstruction of nine photos was 27 launches on the file pipeline's critical submission path.
+struct IdctComp { const int16_t* coef; uint8_t* plane; int blocks_x, n_blocks; uint16_t q[64]; };
+struct IdctArgs { IdctComp comp[3]; int wg0[3]; };
 
 // one thread per 8x8 block: 128 B of coefficients in, 64 samples out (plane row pitch = blocks_x * 8)
-__global__ __launch_bounds__(128) void ist_jpeg_idct_kernel(const IdctArgs A) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= A.blocks_x * A.blocks_y) return;
+__global__ __launch_bounds__(128) void ist_jpeg_idct_kernel(const IdctArgs P) {
+  const int wg = static_cast<int>(blockIdx.x);
+  const int ci = wg >= P.wg0[2] ? 2 : (wg >= P.wg0[1] ? 1 : 0);             // (workgroup-uniform)
+  const IdctComp& A = P.comp[ci];
+  const int b = (wg - P.wg0[ci]) * static_cast<int>(blockDim.x) + static_cast<int>(threadIdx.x);
+  if (b >= A.n_blocks) return;
   const int by = b / A.blocks_x, bx = b - by * A.blocks_x;
   const int16_t* c = A.coef + static_cast<size_t>(b) * 64;
   int ws[64];
@@ -215,12 +223,19 @@ int jpeg_launch_scatter(const uint32_t* d_ent, const uint32_t* d_start, const ui
 
 int jpeg_launch_reconstruct(const JpegDeviceJob& J, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  for (int c = 0; c < J.ncomp; ++c) {
+  {
     IdctArgs a;
-    a.coef = J.d_coef[c]; a.plane = J.d_plane[c]; a.blocks_x = J.blocks_x[c]; a.blocks_y = J.blocks_y[c];
-    for (int k = 0; k < 64; ++k) a.q[k] = J.q_host[c] ? J.q_host[c][k] : 1;
-    const int nblk = J.blocks_x[c] * J.blocks_y[c];
-    hipLaunchKernelGGL(ist_jpeg_idct_kernel, dim3((nblk + 127) / 128), dim3(128), 0, stream, a);
+    std::memset(&a, 0, sizeof a);
+    int wgs = 0;
+    for (int c = 0; c < 3; ++c) {
+      a.wg0[c] = wgs;                                  // (a component the image does not have: no workgroups, never selected)
+      if (c >= J.ncomp) { a.wg0[c] = 0x7fffffff; continue; }
+      IdctComp& C = a.comp[c];
+      C.coef = J.d_coef[c]; C.plane = J.d_plane[c]; C.blocks_x = J.blocks_x[c]; C.n_blocks = J.blocks_x[c] * J.blocks_y[c];
+      for (int k = 0; k < 64; ++k) C.q[k] = J.q_host[c] ? J.q_host[c][k] : 1;
+      wgs += (C.n_blocks + 127) / 128;
+    }
+    if (wgs > 0) hipLaunchKernelGGL(ist_jpeg_idct_kernel, dim3(static_cast<unsigned>(wgs)), dim3(128), 0, stream, a);
   }
   ColorArgs ca;
   ca.Y = J.d_plane[0]; ca.Cb = J.ncomp == 3 ? J.d_plane[1] : nullptr; ca.Cr = J.ncomp == 3 ? J.d_plane[2] : nullptr;
