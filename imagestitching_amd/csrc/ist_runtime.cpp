@@ -176,7 +176,7 @@ void ist_ctx_destroy(ist_ctx* ctx) {
   dev_free(ctx->scratch_dst);
   dev_free(ctx->scratch_dec);
   dev_free(ctx->scratch_huff);
-  if (ctx->scan_pin) { (void)hipHostUnregister(ctx->scan_pin); std::free(ctx->scan_pin); }
+  if (ctx->scan_pin) (void)hipHostFree(ctx->scan_pin);
   dev_free(ctx->scratch_png);
   dev_free(ctx->scratch_file);
   dev_free(ctx->scratch_arena);
@@ -674,14 +674,9 @@ class FileDecoder {
         total += pin_cap_[k];
       }
       if (total > ctx_->scan_pin_bytes) {
-        // (ordinary write-back memory, page-locked afterwards: the parse threads write it 16 bytes at a time)
-        if (ctx_->scan_pin) { (void)hipHostUnregister(ctx_->scan_pin); std::free(ctx_->scan_pin); ctx_->scan_pin = nullptr; ctx_->scan_pin_bytes = 0; }
-        const size_t want = (total + total / 4 + 4095) & ~static_cast<size_t>(4095);
-        void* block = nullptr;
-        if (posix_memalign(&block, 4096, want) == 0) {
-          if (hipHostRegister(block, want, hipHostRegisterPortable) == hipSuccess) { ctx_->scan_pin = block; ctx_->scan_pin_bytes = want; }
-          else { (void)hipGetLastError(); std::free(block); }
-        }
+        if (ctx_->scan_pin) { (void)hipHostFree(ctx_->scan_pin); ctx_->scan_pin = nullptr; ctx_->scan_pin_bytes = 0; }
+        if (hipHostMalloc(&ctx_->scan_pin, total + total / 4, hipHostMallocPortable) == hipSuccess) ctx_->scan_pin_bytes = total + total / 4;
+        else { (void)hipGetLastError(); ctx_->scan_pin = nullptr; }
       }
       if (!ctx_->scan_pin) std::fill(pin_cap_.begin(), pin_cap_.end(), size_t{0});
     }
