@@ -43,7 +43,7 @@ namespace {
 // bits per subsequence (compile-time: it sizes the LDS staging area).  Whole call on nine 12 MP photos, round 2 kernels:
 // 1024 bits 4.5 ms, 2048 bits 4.3 ms, 4096 bits 5.4 ms.  With the bitstream staged in LDS the decode is no longer paced
 // by global-memory latency, and the shorter subsequence gives every SIMD two waves instead of one.
-#ifndef IST_SUB_BITS
+#ifndef IST_SUB_BITS          // (compile-time experiment switches: -DIST_SUB_BITS=512, -DIST_GHOSTS=2, -DIST_AC_LOOK_BITS=11 rebuild the variants DESIGN.md quotes)
 #define IST_SUB_BITS 1024
 #endif
 constexpr int kSubBits = IST_SUB_BITS;
@@ -322,10 +322,7 @@ struct SyncArgs {
 // host-synchronised pass.  Across workgroups the first thread starts from the exit state its left neighbour reached in
 // the PREVIOUS launch; a launch in which no workgroup's last exit state changed is the global fixed point.  (The
 // "overflow" idea of the published scheme, restated for a barrier-synchronised workgroup.)
-#ifndef IST_INNER_PASSES
-#define IST_INNER_PASSES 48
-#endif
-constexpr int kInnerPasses = IST_INNER_PASSES;
+constexpr int kInnerPasses = 48;
 // GHOST LANES.  In the first launch the first thread of a workgroup has no left neighbour to take its start state from
 // (that neighbour belongs to the previous workgroup), so the whole workgroup used to settle on a guess, and the second
 // launch — whose only news is the previous workgroup's true exit state — re-decoded thread 0 of nearly EVERY workgroup:
@@ -441,12 +438,7 @@ __global__ __launch_bounds__(kWriteThreads) void ist_jpeg_write_kernel(const Wri
   // (the scan of the tallies borrows the first 2 KB of the slots, which are cleared again once it is done: 39 KB of LDS per
   // workgroup = FOUR per CU.  The 1017 workgroups of nine 12 MP photos then run side by side; with three per CU (768
   // places) a quarter of them ran as a second round behind the others, and the launch took two decode times instead of one.)
-#ifdef IST_NO_ALIAS
-  __shared__ uint32_t sc_own[4][kWriteThreads];
-  uint32_t (*sc)[kWriteThreads] = sc_own;
-#else
   uint32_t (*sc)[kWriteThreads] = reinterpret_cast<uint32_t (*)[kWriteThreads]>(slots);
-#endif
   static_assert(4 * kWriteThreads <= kWriteThreads * 33, "the scan arrays fit in the slots");
   __shared__ uint32_t base[4];
   const int tid = threadIdx.x;
@@ -482,11 +474,9 @@ __global__ __launch_bounds__(kWriteThreads) void ist_jpeg_write_kernel(const Wri
   }
   uint32_t ex[4];
   for (int c = 0; c < 4; ++c) ex[c] = base[c] + sc[c][tid] - mine[c];
-#ifndef IST_NO_ALIAS
   __syncthreads();                                               // every thread has its sums: the borrowed words are slots again
   for (int k = tid; k < 4 * kWriteThreads; k += kWriteThreads) slots[k] = 0u;
   __syncthreads();
-#endif
   if (!live) return;
   State S;
   if (i == 0) { S.p = 0; S.c = 0; S.z = 0; } else { S.p = A.p[g - 1]; S.c = A.cz[g - 1] >> 8; S.z = A.cz[g - 1] & 255u; }

@@ -118,9 +118,10 @@ __device__ __forceinline__ void flush_run(uint32_t v, int run, int* bits, uint32
   else if (PASS == 1) { *bits += lits * static_cast<int>(clen[v]); if (mlen) *bits += static_cast<int>(clen[msym]) + meb + 1; }
   else {
     // the literal that starts the run, then the match (distance 1: one zero bit), then the 1-2 left-over literals
-    const uint32_t cv = code[v]; const int lv = static_cast<int>(clen[v]);
+    // (code[] carries the length in its upper half: one LDS read per token instead of two)
+    const uint32_t pv = code[v]; const uint32_t cv = pv & 0xFFFFu; const int lv = static_cast<int>(pv >> 16);
     bw->put(cv, lv);
-    if (mlen) { bw->put(code[msym], static_cast<int>(clen[msym])); if (meb) bw->put(static_cast<uint32_t>(mev), meb); bw->put(0u, 1); }
+    if (mlen) { const uint32_t pm = code[msym]; bw->put(pm & 0xFFFFu, static_cast<int>(pm >> 16)); if (meb) bw->put(static_cast<uint32_t>(mev), meb); bw->put(0u, 1); }
     for (int k = 1; k < lits; ++k) bw->put(cv, lv);
   }
 }
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void i
         const int sy = 64 * q + lane;
         if (sy < NSYM) {
           clen[sy] = static_cast<uint32_t>(ln[q]);
-          code[sy] = ln[q] ? rev_bits(static_cast<uint32_t>(cdq[q]), ln[q]) : 0u;
+          code[sy] = ln[q] ? (rev_bits(static_cast<uint32_t>(cdq[q]), ln[q]) | (static_cast<uint32_t>(ln[q]) << 16)) : 0u;
         }
       }
     }
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void i
     BitWriter bw; bw.init(outw, my_start);
     walk_span<2>(sp, n, nullptr, clen, code, &bw);
     bw.flush();
-    if (tid == 0) or_bits(outw, end_bit - static_cast<int>(clen[256]), code[256], static_cast<int>(clen[256]));
+    if (tid == 0) or_bits(outw, end_bit - static_cast<int>(clen[256]), code[256] & 0xFFFFu, static_cast<int>(clen[256]));
     body_end = (end_bit + 3 + 7) / 8;                 // 3 zero bits: BFINAL 0, BTYPE 00; then to the byte boundary
     __syncthreads();
     if (tid == 0) { outb[body_end + 2] = 0xFF; outb[body_end + 3] = 0xFF; }      // LEN 0000, NLEN FFFF

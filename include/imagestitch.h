@@ -271,7 +271,7 @@ IST_API int ist_image_info(const uint8_t* file, int64_t len, int32_t* width, int
 IST_API int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8_t* out, size_t out_pitch, int64_t out_rows);
 
 /* files -> decoded bitmaps in CALLER-OWNED DEVICE memory (the Image.src step ending in HBM): baseline JPEG entropy decoding
- * and reconstruction on the GPU, progressive JPEG / PNG / BMP / GIF entropy stages on host threads.  dst[i] must hold
+ * (one interleaved scan, at most two DC + two AC tables, with or without restart intervals) and reconstruction on the GPU, progressive JPEG / PNG / BMP / GIF entropy stages on host threads.  dst[i] must hold
  * dst_rows[i] rows of dst_pitch[i] bytes (sizes from ist_image_info); out_descs (optional) receives what the planner needs
  * (size, EXIF orientation, opaque).  Returns when the bitmaps are complete.
  * Ordering: the library writes dst[i] from its OWN streams.  Whatever the caller has queued on those buffers (a launch
