@@ -263,6 +263,36 @@ def test_compressed_png_code_longer_than_15_bits_is_limited():
     assert len(png) < 0.5 * a.nbytes
 
 
+def test_compressed_png_codes_complete_on_adversarial_histograms():
+    """The encoder's code lengths are Shannon lengths with the Kraft slack handed back until the code is COMPLETE
+    (ist_png_deflate.hip, phase C; tools/sim_code_lengths.py restates the rule).  Histograms that stress it: two symbols
+    (one very rare), powers of two, one dominant symbol + many singletons, every literal once, uniform over a few values.
+    zlib (through PIL) refuses an over-subscribed or incomplete code, so decoding IS the check."""
+    rng = np.random.default_rng(77)
+
+    def row_image(res):
+        res = np.asarray(res, np.uint8)
+        res = np.concatenate([res, np.full((-len(res)) % 4, res[0], np.uint8)])
+        return np.ascontiguousarray(np.cumsum(res.reshape(-1, 4).astype(np.int64), axis=0).astype(np.uint8)[None, :, :]).copy()      # h = 1: Paeth = Sub
+
+    cases = []
+    cases.append(np.where(np.arange(16000) == 7777, 9, 200))                                   # 15999 : 1
+    cases.append(np.repeat(np.arange(14) * 3 + 1, 2 ** np.arange(14))[:16000])                 # counts 1, 2, 4, ... 8192
+    cases.append(np.concatenate([np.full(15000, 33), np.arange(250)]))                         # one dominant + 250 singletons
+    cases.append(np.arange(256).repeat(2))                                                     # every literal twice
+    cases.append(rng.choice(np.array([5, 6, 7], np.uint8), 12000))                             # three values, equal
+    cases.append(np.concatenate([np.full(3, 1), np.full(3, 2), np.full(16000, 3)]))           # two rare, one common
+    for k in range(6):                                                                          # random power-law shapes
+        ns = int(rng.integers(2, 256))
+        c = np.maximum(1, (2.0 ** rng.uniform(0, 12, ns)).astype(int))
+        c = (c * min(1.0, 15000 / c.sum())).astype(int).clip(1)
+        cases.append(np.repeat(rng.permutation(256)[:ns], c))
+    for res in cases:
+        res = np.asarray(res).copy()
+        rng.shuffle(res)
+        _check_compressed(row_image(res))
+
+
 def test_compressed_png_many_random_shapes_and_contents():
     rng = np.random.default_rng(2024)
     for case in range(40):
