@@ -329,8 +329,8 @@ constexpr int kInnerPasses = 48;
 // a full subsequence time for the launch, since a pass costs as much as its slowest lane.  Now a fifth wave carries
 // ghost lanes that decode the subsequences in front of the workgroup (from a guess, then from each other), and thread 0
 // starts from the last ghost's exit.  How many: a decoder falls into step with the code boundaries within a few symbols,
-// but with the MCU SLOT (which table set applies) only by chance, about once in three MCUs - a subsequence in four
-// hands a wrong state on.  With 2 ghosts some of a call's 531 workgroups therefore still started wrong and the second
+// but with the MCU SLOT (which table set applies) only by chance: of the subsequences entered in a wrong state 38 % hand a
+// wrong state on (tools/sim_slot_sync.cpp replays the rule on the CPU: 62 % exit true, 12 % with only the slot wrong, 26 % elsewhere).  With 2 ghosts some of a call's 531 workgroups therefore still started wrong and the second
 // launch cost 0.24 ms; with 6 or more it finds nothing to redo and returns in 7 us (nine 12 MP photos, kernel trace:
 // sync launches 0.89 + 0.24 ms -> 0.94-1.09 + 0.007 ms; both launches timed on the host 1.19-1.25 -> 0.99-1.00 ms).
 #ifndef IST_GHOSTS
