@@ -106,26 +106,6 @@ __device__ __forceinline__ void or_bits(uint32_t* w, int bitpos, uint32_t v, int
 
 __device__ __forceinline__ uint32_t rev_bits(uint32_t code, int len) { return __brev(code) >> (32 - len); }
 
-// One pass of a thread over its span.  PASS 0: histogram; 1: count bits; 2: emit.  The span is read as 16 dwords (the
-// padded layout keeps every span 4-byte aligned) and walked as a stream: a run is flushed when the byte changes.
-template <int PASS>
-__device__ __forceinline__ void flush_run(uint32_t v, int run, int* bits, uint32_t* hist, const uint32_t* clen, const uint32_t* code, BitWriter* bw) {
-  int lits = 1, rem = run - 1;
-  int msym = 0, meb = 0, mev = 0, mlen = 0;
-  if (rem >= 3) { mlen = rem; len_code(mlen, &msym, &meb, &mev); rem = 0; }     // a span is 64 bytes: one match covers the run
-  lits += rem;
-  if (PASS == 0) { atomicAdd(&hist[v], static_cast<uint32_t>(lits)); if (mlen) atomicAdd(&hist[msym], 1u); }
-  else if (PASS == 1) { *bits += lits * static_cast<int>(clen[v]); if (mlen) *bits += static_cast<int>(clen[msym]) + meb + 1; }
-  else {
-    // the literal that starts the run, then the match (distance 1: one zero bit), then the 1-2 left-over literals
-    // (code[] carries the length in its upper half: one LDS read per token instead of two)
-    const uint32_t pv = code[v]; const uint32_t cv = pv & 0xFFFFu; const int lv = static_cast<int>(pv >> 16);
-    bw->put(cv, lv);
-    if (mlen) { const uint32_t pm = code[msym]; bw->put(pm & 0xFFFFu, static_cast<int>(pm >> 16)); if (meb) bw->put(static_cast<uint32_t>(mev), meb); bw->put(0u, 1); }
-    for (int k = 1; k < lits; ++k) bw->put(cv, lv);
-  }
-}
-
 // The span lives in REGISTERS (16 dwords): the LDS image of the filtered chunk is dead once every thread holds its span, so
 // the output bit buffer takes its place (one 17 KiB buffer instead of two: 6 workgroups per CU instead of 4 - the kernel's
 // clock is LDS latency, so residency is throughput).  The walk's dword loop has a wave-uniform trip count, which makes the
@@ -139,23 +119,80 @@ __device__ __forceinline__ uint32_t span_word(const uint32_t (&sp)[16], int d) {
   }
 }
 
+// Which bytes of a span are literals and where its matches start, as 64-bit masks - computed once per walk, so that the walk
+// itself carries no run state from byte to byte (the stateful walk cost ~23 instructions per byte in each of the three
+// passes; this one ~6).  eq bit i: byte i equals byte i-1.  A run of R >= 4 equal bytes is its first byte as a literal + ONE
+// match of R - 1 bytes at distance 1, shorter runs are literals: `covered` = the bytes inside matches = every eq position that
+// belongs to three consecutive eq bits; a match starts where a covered stretch starts and is as long as the stretch.
+struct SpanMasks { unsigned long long lit, mstart, covered; };
+__device__ __forceinline__ SpanMasks span_masks(const uint32_t (&sp)[16], int n) {
+  unsigned long long eq = 0;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) {
+    const uint32_t w = sp[d];
+    const uint32_t prev = d ? (sp[d ? d - 1 : 0] >> 24) : (~w & 0xFFu);            // (byte 0 has no predecessor: never equal)
+    const uint32_t x = w ^ ((w << 8) | prev);                                      // a zero byte where a byte equals the one before it
+    const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;     // 0x80 in every NON-zero byte (exact)
+    const uint32_t z = (nz ^ 0x80808080u) >> 7;                                    // bit 0 / 8 / 16 / 24: the byte is zero
+    const uint32_t nib = ((z * 0x00204081u) >> 21) & 15u;                          // those four bits side by side
+    eq |= static_cast<unsigned long long>(nib) << (4 * d);
+  }
+  const unsigned long long valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+  eq &= valid & ~1ull;
+  const unsigned long long t = eq & (eq >> 1) & (eq >> 2);                         // bit i: bytes i-1 .. i+2 are equal
+  SpanMasks m;
+  m.covered = (t | (t << 1) | (t << 2)) & valid;
+  m.lit = valid & ~m.covered;
+  m.mstart = m.covered & ~(m.covered << 1);
+  return m;
+}
+
+// One pass of a thread over its span.  PASS 0: histogram; 1: count bits; 2: emit.  The span is read as 16 dwords (the
+// padded layout keeps every span 4-byte aligned); the dword loop has a wave-uniform trip count, which makes the register
+// pick a scalar jump.
 template <int PASS>
-__device__ __forceinline__ int walk_span(const uint32_t (&sp)[16], int n, uint32_t* hist, const uint32_t* clen, const uint32_t* code, BitWriter* bw) {
-  int bits = 0, run = 0;
-  uint32_t v = 0;
+__device__ __forceinline__ int walk_span(const uint32_t (&sp)[16], int n, const SpanMasks& M, uint32_t* hist, const uint32_t* clen, const uint32_t* code, BitWriter* bw) {
+  int bits = 0;
+  if (PASS != 2) {                                   // matches in any order: a loop over the (few) places where one starts
+    unsigned long long ms = M.mstart;
+    while (ms) {
+      const int i = __ffsll(static_cast<long long>(ms)) - 1;
+      ms &= ms - 1ull;
+      const unsigned long long rest = ~(M.covered >> i);
+      const int mlen = rest ? __ffsll(static_cast<long long>(rest)) - 1 : 64 - i;       // 3 .. 63 covered bytes in a row
+      int msym, meb, mev;
+      len_code(mlen, &msym, &meb, &mev);
+      if (PASS == 0) atomicAdd(&hist[msym], 1u);
+      else bits += static_cast<int>(clen[msym]) + meb + 1;
+    }
+  }
 #pragma unroll 1
   for (int d = 0; d < 16; ++d) {
+    if (4 * d >= n) break;                           // (wave-uniform only in full chunks; a scalar branch there)
     const uint32_t w = span_word(sp, d);
+    const uint32_t lit4 = static_cast<uint32_t>(M.lit >> (4 * d)) & 15u;
+    const uint32_t ms4 = PASS == 2 ? static_cast<uint32_t>(M.mstart >> (4 * d)) & 15u : 0u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (4 * d + k < n) {
-        const uint32_t b = (w >> (8 * k)) & 255u;
-        if (run > 0 && b == v) ++run;
-        else { if (run > 0) flush_run<PASS>(v, run, &bits, hist, clen, code, bw); v = b; run = 1; }
+      const uint32_t b = (w >> (8 * k)) & 255u;
+      if (lit4 & (1u << k)) {
+        if (PASS == 0) atomicAdd(&hist[b], 1u);
+        else if (PASS == 1) bits += static_cast<int>(clen[b]);
+        else { const uint32_t pv = code[b]; bw->put(pv & 0xFFFFu, static_cast<int>(pv >> 16)); }      // (code[] carries the length in its upper half)
+      }
+      if (PASS == 2 && (ms4 & (1u << k))) {          // the match behind a run's first byte (distance 1: one zero bit)
+        const int i = 4 * d + k;
+        const unsigned long long rest = ~(M.covered >> i);
+        const int mlen = rest ? __ffsll(static_cast<long long>(rest)) - 1 : 64 - i;
+        int msym, meb, mev;
+        len_code(mlen, &msym, &meb, &mev);
+        const uint32_t pm = code[msym];
+        bw->put(pm & 0xFFFFu, static_cast<int>(pm >> 16));
+        if (meb) bw->put(static_cast<uint32_t>(mev), meb);
+        bw->put(0u, 1);
       }
     }
   }
-  if (run > 0) flush_run<PASS>(v, run, &bits, hist, clen, code, bw);
   return bits;
 }
 
@@ -238,7 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void i
     for (int d = 0; d < 16; ++d) sp[d] = mw[d];
   }
   __syncthreads();                                   // every span is in registers: the buffer is free
-  walk_span<0>(sp, n, hist, nullptr, nullptr, nullptr);
+  walk_span<0>(sp, n, span_masks(sp, n), hist, nullptr, nullptr, nullptr);
   if (tid == 0) atomicAdd(&hist[256], 1u);
   uint32_t a1 = 0, a2 = 0;
 #pragma unroll
@@ -361,7 +398,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void i
 
   if (P.dbg && tid == 0) P.dbg[chunk * 8 + 3] = wall_clock64();
   // ---- D. bits per thread, exclusive scan, choice between the Huffman and the stored form
-  const int mybits = skip ? 0 : walk_span<1>(sp, n, nullptr, clen, nullptr, nullptr);
+  const SpanMasks masks = span_masks(sp, n);         // (for the bit count and the emission: kept across the scan between them)
+  const int mybits = skip ? 0 : walk_span<1>(sp, n, masks, nullptr, clen, nullptr, nullptr);
   int incl = mybits;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
@@ -394,7 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void i
       or_bits(outw, hb + 17 + 57 + 4 * s, rev_bits(l, 4), 4);
     }
     BitWriter bw; bw.init(outw, my_start);
-    walk_span<2>(sp, n, nullptr, clen, code, &bw);
+    walk_span<2>(sp, n, masks, nullptr, clen, code, &bw);
     bw.flush();
     if (tid == 0) or_bits(outw, end_bit - static_cast<int>(clen[256]), code[256] & 0xFFFFu, static_cast<int>(clen[256]));
     body_end = (end_bit + 3 + 7) / 8;                 // 3 zero bits: BFINAL 0, BTYPE 00; then to the byte boundary
