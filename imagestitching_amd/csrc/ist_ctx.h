@@ -10,6 +10,8 @@
 #include <mutex>
 #include <vector>
 
+#include "ist_jpeg.h"
+
 #include "ist_host.h"
 #include "ist_internal.h"
 
@@ -29,7 +31,7 @@ struct ist_ctx {
   std::vector<hipStream_t> img_stream;
   std::vector<hipEvent_t> img_event;
   std::vector<void*> img_huff; std::vector<size_t> img_huff_bytes;
-  void* scan_pin = nullptr; size_t scan_pin_bytes = 0;   // pinned host block the parse threads de-stuff the scans of a call into (grow-only): written once, DMAed from in place
+  std::vector<ist::ScanBuf> scan_bufs;        // de-stuffed scans of the last call: their memory is reused (a fresh 1.8 MB block per image and call is 450 page faults on its parse thread)
   void* scratch_ent = nullptr; size_t scratch_ent_bytes = 0;   // sparse coefficient entries of host-decoded JPEGs (progressive, restart intervals)
   hipStream_t render = nullptr;          // file pipeline: Huffman batch + per-image reconstruction + band launches, beside the PNG encoder on `stream`
   hipEvent_t render_done = nullptr;

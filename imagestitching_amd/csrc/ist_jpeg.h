@@ -81,20 +81,17 @@ struct alignas(16) JpegGpuTables {
 // One restart interval of a scan (T.81 E.1.4: the entropy coder is reset at every RSTn, so an interval decodes on its own):
 // its de-stuffed bytes start at byte_off of JpegGpuScan::stream (a multiple of 256, at least 16 zero bytes behind its last bit).
 struct JpegGpuInterval { uint32_t byte_off, mcu0, n_mcus; int64_t bits; };
-// The de-stuffed scan's bytes: heap memory of its own, or a block the caller lends (page-locked host memory: the scan is then
-// written once and DMAed from where it lies).  A lent block that turns out too small is left alone and the scan moves to
-// the heap (lent() then says so).
+// The de-stuffed scan's bytes: a heap block that keeps its memory when it is cleared and can be handed from call to call
+// (swap), written through data() by the de-stuffing loop.
 class ScanBuf {
  public:
   ScanBuf() = default;
-  ~ScanBuf() { if (own_) std::free(p_); }
+  ~ScanBuf() { std::free(p_); }
   ScanBuf(const ScanBuf&) = delete;
   ScanBuf& operator=(const ScanBuf&) = delete;
   ScanBuf(ScanBuf&& o) noexcept { swap(o); }
   ScanBuf& operator=(ScanBuf&& o) noexcept { swap(o); return *this; }
-  void swap(ScanBuf& o) noexcept { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); std::swap(own_, o.own_); }
-  void lend(uint8_t* block, size_t cap) { if (own_) std::free(p_); p_ = block; cap_ = cap; n_ = 0; own_ = false; }
-  bool lent() const { return !own_ && p_ != nullptr; }
+  void swap(ScanBuf& o) noexcept { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); }
   const uint8_t* data() const { return p_; }
   uint8_t* data() { return p_; }
   size_t size() const { return n_; }
@@ -104,13 +101,12 @@ class ScanBuf {
   void set_size(size_t n) { n_ = n; }                   // (n <= capacity: the writer filled data()[0, n))
   bool reserve(size_t want) {                           // contents are NOT kept (the writer starts over); false: out of memory
     if (want <= cap_) return true;
-    if (!own_) { p_ = nullptr; cap_ = 0; own_ = true; }
     std::free(p_);
     p_ = static_cast<uint8_t*>(std::malloc(want)); cap_ = p_ ? want : 0; n_ = 0;
     return p_ != nullptr;
   }
  private:
-  uint8_t* p_ = nullptr; size_t n_ = 0, cap_ = 0; bool own_ = true;
+  uint8_t* p_ = nullptr; size_t n_ = 0, cap_ = 0;
 };
 struct JpegGpuScan {
   bool eligible = false;               // baseline, ONE interleaved scan over all components (with or without restart intervals)

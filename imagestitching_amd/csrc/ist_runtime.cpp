@@ -176,7 +176,6 @@ void ist_ctx_destroy(ist_ctx* ctx) {
   dev_free(ctx->scratch_dst);
   dev_free(ctx->scratch_dec);
   dev_free(ctx->scratch_huff);
-  if (ctx->scan_pin) (void)hipHostFree(ctx->scan_pin);
   dev_free(ctx->scratch_png);
   dev_free(ctx->scratch_file);
   dev_free(ctx->scratch_arena);
@@ -615,6 +614,7 @@ int ensure_image_lanes(ist_ctx* ctx, int n) {
     ctx->img_event.push_back(ev);
   }
   if (ctx->img_huff.size() < static_cast<size_t>(n)) { ctx->img_huff.resize(static_cast<size_t>(n), nullptr); ctx->img_huff_bytes.resize(static_cast<size_t>(n), 0); }
+  if (ctx->scan_bufs.size() < static_cast<size_t>(n)) ctx->scan_bufs.resize(static_cast<size_t>(n));
   return IST_OK;
 }
 
@@ -624,12 +624,14 @@ class FileDecoder {
  public:
   FileDecoder(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n, Phases* ph)
       : ctx_(ctx), files_(files), lens_(lens), n_(n), ph_(ph), dec_(static_cast<size_t>(n)), th_(static_cast<size_t>(n)),
-        on_gpu_(static_cast<size_t>(n), 0), taken_(static_cast<size_t>(n), 0), uploaded_(static_cast<size_t>(n), 0), started_(static_cast<size_t>(n), 0), jo_(static_cast<size_t>(n)),
-        pin_off_(static_cast<size_t>(n), 0), pin_cap_(static_cast<size_t>(n), 0) {}
+        on_gpu_(static_cast<size_t>(n), 0), taken_(static_cast<size_t>(n), 0), uploaded_(static_cast<size_t>(n), 0), started_(static_cast<size_t>(n), 0), jo_(static_cast<size_t>(n)) {}
   ~FileDecoder() {
     join_all();
-    // (the scans' uploads read the context's pinned block: they are done before the next call writes it)
     for (int i = 0; i < n_; ++i) if (started_[static_cast<size_t>(i)]) (void)hipStreamSynchronize(stream_of(i));
+    for (int i = 0; i < n_ && static_cast<size_t>(i) < ctx_->scan_bufs.size(); ++i) {      // keep the scans' memory for the next call (at most 8 MiB per image)
+      ScanBuf& mine = dec_[static_cast<size_t>(i)].G.stream;
+      if (mine.capacity() > ctx_->scan_bufs[static_cast<size_t>(i)].capacity() && mine.capacity() <= (8u << 20)) ctx_->scan_bufs[static_cast<size_t>(i)].swap(mine);
+    }
   }
 
   // 1. frame headers only (microseconds per file): sizes, sampling, EXIF orientation - what the planner and the arena need
@@ -662,24 +664,6 @@ class FileDecoder {
     arena_ = arena; img_ = img; pitch_ = pitch;
     const int rc = ensure_image_lanes(ctx_, n_);
     if (rc) return rc;
-    if (gpu_huffman_) {
-      // one pinned block for the de-stuffed scans of the call.  A scan is never longer than its file; restart intervals add
-      // padding (<= 272 bytes each, <= 2048 intervals on the GPU path); what does not fit goes to the heap (ScanBuf).
-      size_t total = 0;
-      for (int i = 0; i < n_; ++i) {
-        const size_t k = static_cast<size_t>(i);
-        if (!dec_[k].jpeg || lens_[i] > (int64_t{1} << 28)) continue;
-        pin_off_[k] = total;
-        pin_cap_[k] = (static_cast<size_t>(lens_[i]) + 2048u * 272u + 64u + 4095u) & ~static_cast<size_t>(4095);
-        total += pin_cap_[k];
-      }
-      if (total > ctx_->scan_pin_bytes) {
-        if (ctx_->scan_pin) { (void)hipHostFree(ctx_->scan_pin); ctx_->scan_pin = nullptr; ctx_->scan_pin_bytes = 0; }
-        if (hipHostMalloc(&ctx_->scan_pin, total + total / 4, hipHostMallocPortable) == hipSuccess) ctx_->scan_pin_bytes = total + total / 4;
-        else { (void)hipGetLastError(); ctx_->scan_pin = nullptr; }
-      }
-      if (!ctx_->scan_pin) std::fill(pin_cap_.begin(), pin_cap_.end(), size_t{0});
-    }
     for (int i = 0; i < n_; ++i) th_[static_cast<size_t>(i)] = std::thread([this, i]() { worker(i); });
     if (!ph_->on) return IST_OK;
     // phase timing: the steps one after the other
@@ -787,13 +771,12 @@ class FileDecoder {
       return;
     }
     JpegImage full;
-    // The scan is de-stuffed straight into the image's part of the context's page-locked block and goes to the device from
-    // there in ONE copy: a DMA that reads the bytes where they lie, instead of a pageable vector staged through the runtime's
-    // bounce buffer (host stage of nine 12 MP photos 0.60-0.79 -> 0.50 ms, measured).  (measured too: sending the scan in
-    // pieces while the rest is still being de-stuffed - 256 KB pieces cost more per copy than they hide, and with eight
-    // streams of them the stage sometimes took 8 ms; 1 MB pieces 0.58-0.68 ms.)  A scan that does not fit its part lies on the
-    // heap and is uploaded from there; any failure here only means the Huffman batch uploads the scan itself.
-    if (gpu_huffman_ && pin_cap_[k]) D.G.stream.lend(static_cast<uint8_t*>(ctx_->scan_pin) + pin_off_[k], pin_cap_[k]);
+    // The scan is de-stuffed (SSE2, 16 bytes a step) into a heap block the context keeps from call to call and goes to the
+    // device in ONE copy.  (measured, 120 calls each, twice: from a page-locked block of the context instead - a true DMA, no
+    // bounce buffer - the call's median was 0.08 ms lower, 2.35 vs 2.43 ms, but one call in ~100 took 8 ms: concurrent pinned
+    // copies from nine threads on eight streams now and then stall for ~6 ms; in 256 KB pieces they did so in half of the
+    // calls.  The pageable path never did.)
+    if (k < ctx_->scan_bufs.size()) D.G.stream.swap(ctx_->scan_bufs[k]);            // (a recycled block: capacity, no contents)
     const int rc = jpeg_parse_and_entropy_decode(f, len, &full, false, gpu_huffman_ ? &D.G : nullptr);
     if (rc) { failed(rc); return; }
     if (full.width != D.w || full.height != D.h || full.ncomp != D.J.ncomp) { g_last_error = "JPEG frame header changed between two reads"; failed(IST_E_DECODE); return; }
@@ -817,7 +800,6 @@ class FileDecoder {
   std::vector<std::thread> th_;
   std::vector<char> on_gpu_, taken_, uploaded_, started_;      // started_: the image's stream carries uploads of this call
   std::vector<JpegDevLayout> jo_;
-  std::vector<size_t> pin_off_, pin_cap_;                      // each JPEG's part of the context's pinned scan block (cap 0: none)
   uint8_t* arena_ = nullptr; uint8_t* const* img_ = nullptr; const size_t* pitch_ = nullptr;
   bool gpu_huffman_ = true, huff_done_ = false;
 };
