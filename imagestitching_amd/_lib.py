@@ -76,6 +76,7 @@ SYMBOLS = [
     ("ist_device_count", C.c_int, []),
     ("ist_debug_device_allocs", C.c_int64, []),
     ("ist_debug_gpu_entropy_files", C.c_int64, []),
+    ("ist_debug_direct_images", C.c_int64, []),
     ("ist_limits_default", None, [C.c_int, C.POINTER(Limits)]),
     ("ist_limits_unlimited", None, [C.POINTER(Limits)]),
     ("ist_plan_compute", C.c_int, [C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Limits), C.POINTER(Plan)]),

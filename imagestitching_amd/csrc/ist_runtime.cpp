@@ -40,6 +40,7 @@ int ctx_png_scratch(ist_ctx* ctx, size_t need, void** p) {
 
 static std::atomic<int64_t> g_dev_allocs{0};
 static std::atomic<int64_t> g_gpu_entropy_files{0};
+static std::atomic<int64_t> g_direct_images{0};
 int dev_malloc(void** p, size_t bytes) {
   g_dev_allocs.fetch_add(1, std::memory_order_relaxed);
   return static_cast<int>(hipMalloc(p, bytes));
@@ -126,6 +127,7 @@ extern "C" {
 
 int64_t ist_debug_device_allocs(void) { return g_dev_allocs.load(std::memory_order_relaxed); }
 int64_t ist_debug_gpu_entropy_files(void) { return g_gpu_entropy_files.load(std::memory_order_relaxed); }
+int64_t ist_debug_direct_images(void) { return g_direct_images.load(std::memory_order_relaxed); }
 
 int ist_device_count(void) {
   int n = 0;
@@ -1016,6 +1018,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
       for (size_t q = 0; q < bj.parts.size(); ++q) if (q != k && bj.parts[q].image == p.image) shared = true;
       if (shared) continue;
       direct[k] = 1;
+      g_direct_images.fetch_add(1, std::memory_order_relaxed);
       img[static_cast<size_t>(p.image)] = d + o_canvas + static_cast<size_t>(p.Y0) * canvas_pitch + static_cast<size_t>(p.X0) * 4;
       dpitch[static_cast<size_t>(p.image)] = canvas_pitch;
       dsrc[static_cast<size_t>(p.image)] = img[static_cast<size_t>(p.image)];

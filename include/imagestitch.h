@@ -134,6 +134,9 @@ IST_API int64_t ist_debug_device_allocs(void);
 /* JPEG files whose entropy-coded scan the GPU Huffman decoder has decoded AND validated in this process so far (files it
  * handed back to the host decoder do not count).  Tests use it to tell the GPU path from the silent host fall-back. */
 IST_API int64_t ist_debug_gpu_entropy_files(void);
+/* images the file pipeline has reconstructed STRAIGHT INTO the canvas so far (a draw that only moves an opaque image: no bitmap of
+ * its own, no stitch launch for it).  Tests use it to tell that path from the general one, which makes the same pixels. */
+IST_API int64_t ist_debug_direct_images(void);
 
 /* ---- planner: pure CPU, bit-exact to index.js:1211-1216, 1251-1386, 1432-1433, 1522-1554 -------------------- */
 IST_API void ist_limits_default(int platform, ist_limits* out);        /* index.js:126-156 fallback branch */

@@ -226,6 +226,43 @@ def test_gpu_entropy_decoder_damaged_restart_markers_go_to_the_host(tmp_path):
             assert np.array_equal(ist.decode_png(res["png"]), host), name
 
 
+@pytest.mark.parametrize("direction", ["vertical", "horizontal"])
+def test_images_placed_without_scaling_are_reconstructed_straight_into_the_canvas(tmp_path, direction):
+    """mode 'original' keeps every image at its own size: each draw only moves its image (odd offsets, gaps, narrower
+    images beside the canvas background), so the file pipeline reconstructs the JPEGs straight into their boxes of the canvas
+    (no bitmap, no band launch) - except the turned one, which keeps its bitmap.  Same pixels as the oracle's stitch of PIL's
+    bitmaps, and the phase-timed run (which renders every band through the stitch kernel) makes the same file."""
+    sizes = [(203, 317), (64, 251), (120, 317), (33, 90), (77, 318)]
+    paths, bitmaps, orients = [], [], []
+    for k, (h, w) in enumerate(sizes):
+        kw = {}
+        if k == 3:
+            ex = Image.Exif()
+            ex[0x0112] = 6
+            kw["exif"] = ex
+        data = _jpeg(_photo(300 + k, h, w), quality=88, subsampling=[2, 0, 1, 2, 2][k], **kw)
+        p = tmp_path / ("o%d.jpg" % k)
+        p.write_bytes(data)
+        paths.append(str(p))
+        bitmaps.append(_pil(data))
+        orients.append(6 if k == 3 else 1)
+    opts = {"filter": "nearest", "mode": "original", "gap": 7}
+    from imagestitching_amd import _lib as L
+    before = L.lib.ist_debug_direct_images()
+    res = ist.stitch_files(paths, direction, opts)
+    assert L.lib.ist_debug_direct_images() - before == 4          # every image but the turned one
+    ref, _, _ = U.oracle_stitch(bitmaps, direction, opts, orientations=orients)
+    got = ist.decode_png(res["png"])
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+    ist.set_phase_timing(True)
+    try:
+        timed = ist.stitch_files(paths, direction, opts)
+    finally:
+        ist.set_phase_timing(False)
+    assert np.array_equal(ist.decode_png(timed["png"]), got)
+
+
 def test_gpu_entropy_decoder_hands_damaged_scans_to_the_host_decoder(tmp_path):
     a = _photo(95, 120, 160)
     good = _jpeg(a, quality=85, subsampling=2)
