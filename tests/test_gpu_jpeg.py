@@ -209,6 +209,8 @@ def test_gpu_entropy_decoder_damaged_restart_markers_go_to_the_host(tmp_path):
     cases["out_of_sequence"] = bytes(swapped)
     cases["one_too_many"] = good[:-2] + b"\xff\xd7" + good[marks[0] + 2:marks[1]] + good[-2:]
     cases["short_interval"] = good[:marks[3] + 2] + good[marks[3] + 12:]
+    cases["empty_interval"] = good[:marks[2] + 2] + good[marks[3]:]                      # two markers back to back
+    cases["marker_at_the_end"] = good[:-2] + b"\xff\xd7" + good[-2:]                     # one more RSTn than intervals, no data behind it
     for name, data in cases.items():
         p = tmp_path / (name + ".jpg")
         p.write_bytes(data)
