@@ -249,7 +249,7 @@ static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool head
       for (int s = 0; s < ns; ++s) {
         if ((need_dc && !dc[td[s]].present) || (need_ac && !ac[ta[s]].present)) return fail(IST_E_DECODE, "JPEG scan uses an undefined Huffman table");
       }
-      // the GPU entropy decoder takes baseline files whose single scan interleaves all components, without restarts
+      // the GPU entropy decoder takes baseline files whose single scan interleaves all components (restart intervals or not)
       int mcu_blocks = 0;
       for (int s2 = 0; s2 < ns; ++s2) mcu_blocks += J->comp[ci[s2]].h * J->comp[ci[s2]].v;
       // ... and names at most two DC and two AC tables (the GPU decoder keeps that many in LDS)

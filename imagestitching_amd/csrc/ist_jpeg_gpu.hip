@@ -6,7 +6,8 @@
 // falls into step with the true code boundaries after a few symbols.  The published scheme for GPUs (Weissenberger &
 // Schmidt, "Massively Parallel Huffman Decoding on GPUs", ICPP 2018, and its JPEG follow-up) is restated here for this
 // path:
-//   * the de-stuffed scan is cut into subsequences of 2048 bits; one thread owns one subsequence;
+//   * the de-stuffed scan is cut into subsequences of 1024 bits; one thread owns one subsequence (a scan with restart
+//     intervals: every interval is cut on its own - it is an independent stream, T.81 E.1.4);
 //   * pass 0: every thread decodes its subsequence from its first bit, pretending a block starts there, and records
 //     the state in which it crosses its end (bit position, MCU slot, zig-zag index) and how many blocks it finished;
 //   * pass t >= 1: every thread decodes its subsequence again, starting from the exit state its LEFT neighbour

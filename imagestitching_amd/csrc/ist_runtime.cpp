@@ -572,7 +572,7 @@ int ist_image_decode_rgba8(ist_ctx* ctx, const uint8_t* file, int64_t len, uint8
 // runtime multiplexes streams onto four hardware queues, three chains per queue ran back to back).  Behind the batch the
 // images are reconstructed one by one as the consumer asks for them, so (ist_stitch_files_png) band k of the canvas is
 // rendered and exported while the images behind it are still being reconstructed.  Files the GPU entropy decoder does not
-// take (progressive, restart intervals, PNG / BMP / GIF / WebP) are decoded on their thread and uploaded when the consumer
+// take (progressive, non-interleaved scans, more than 2048 restart intervals, PNG / BMP / GIF / WebP) are decoded on their thread and uploaded when the consumer
 // asks for the image.  With phase timing on, the same steps run with a stream sync between them.
 extern "C++" {
 namespace {
@@ -698,7 +698,7 @@ class FileDecoder {
       else up.push_back(RowsCopy{img_[i], D.px.data(), nullptr, row, row, static_cast<size_t>(D.h)});
       return stager_of(ctx_).upload(up, consumer);
     }
-    // a JPEG whose coefficients are on the host (progressive, restart intervals, non-interleaved scans, or a file that
+    // a JPEG whose coefficients are on the host (progressive, non-interleaved scans, thousands of restart intervals, or a file that
     // failed the GPU decoder's validation and is decoded again by the host decoder)
     if (D.G.eligible) {
       D.G.eligible = false;
