@@ -66,16 +66,29 @@ struct DeflArgs {
 
 __device__ __forceinline__ int padpos(int p) { return p + ((p >> 6) << 2); }
 
+// Paeth residuals of one RGBA pixel (PNG spec 9.4): per channel the neighbour - left, up or upper left - closest to left +
+// up - upper left, ties in that order.  Two channels at a time as packed 16-bit lanes (v_pk_sub_i16 / v_pk_max_i16 /
+// v_pk_ashrrev_i16): pa = |up - ul|, pb = |left - ul|, pc = |(up - ul) + (left - ul)|; a comparison is the sign of a packed
+// difference spread over its lane, a selection is a bit-field insert.  52 operations per pixel instead of ~85 byte-wise ones; the
+// kernel is instruction-issue-bound (87 % of its issue slots busy, profiles/r03_counters_png.txt).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t paeth_pred2(uint32_t l, uint32_t u, uint32_t ul) {      // two channels, 16-bit lanes holding 0..255
+  const s16x2 zero = {0, 0};
+  const s16x2 d1 = as_s16x2(u) - as_s16x2(ul), d2 = as_s16x2(l) - as_s16x2(ul), d3 = d1 + d2;
+  const s16x2 pa = __builtin_elementwise_max(d1, zero - d1), pb = __builtin_elementwise_max(d2, zero - d2), pc = __builtin_elementwise_max(d3, zero - d3);
+  const uint32_t a_gt_b = as_u32((pb - pa) >> 15), a_gt_c = as_u32((pc - pa) >> 15), b_gt_c = as_u32((pc - pb) >> 15);      // all ones where greater
+  const uint32_t not_a = a_gt_b | a_gt_c;
+  const uint32_t u_or_ul = (ul & b_gt_c) | (u & ~b_gt_c);
+  return (u_or_ul & not_a) | (l & ~not_a);
+}
 __device__ __forceinline__ uint32_t paeth4(uint32_t cur, uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t out = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int x = (cur >> (8 * k)) & 255, l = (a >> (8 * k)) & 255, u = (b >> (8 * k)) & 255, ul = (c >> (8 * k)) & 255;
-    const int pa = abs(u - ul), pb = abs(l - ul), pc = abs(l + u - 2 * ul);
-    const int pred = (pa <= pb && pa <= pc) ? l : (pb <= pc ? u : ul);
-    out |= static_cast<uint32_t>((x - pred) & 255) << (8 * k);
-  }
-  return out;
+  const uint32_t m = 0x00FF00FFu;
+  const uint32_t pe = paeth_pred2(a & m, b & m, c & m), po = paeth_pred2((a >> 8) & m, (b >> 8) & m, (c >> 8) & m);
+  const uint32_t pred = pe | (po << 8);
+  // cur - pred in every byte: borrow-free subtraction of the low seven bits, the top bits by xor
+  return ((cur | 0x80808080u) - (pred & 0x7F7F7F7Fu)) ^ ((cur ^ ~pred) & 0x80808080u);
 }
 
 // deflate length symbol for a match of l bytes (3 <= l <= 66): symbol, extra-bit count, extra-bit value
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void i
       on[u] = q < npix;
       cur[u] = a[u] = b[u] = c[u] = 0u; pos[u] = 0; first[u] = false;
       if (on[u]) {
-        const int r = q / npr, xx = q - r * npr;
+        const int r = nrows == 1 ? 0 : q / npr, xx = q - r * npr;      // (one row per chunk - every image wider than 2047 px - needs no division)
         const int64_t y = y0 + r; const int x = x0 + xx;
         const uint8_t* row = P.canvas + static_cast<size_t>(y) * P.pitch;
         cur[u] = *reinterpret_cast<const uint32_t*>(row + 4 * static_cast<size_t>(x));
