@@ -184,25 +184,37 @@ __device__ __forceinline__ int walk_span(const uint32_t (&sp)[16], int n, const 
     if (4 * d >= n) break;                           // (wave-uniform only in full chunks; a scalar branch there)
     const uint32_t w = span_word(sp, d);
     const uint32_t lit4 = static_cast<uint32_t>(M.lit >> (4 * d)) & 15u;
-    const uint32_t ms4 = PASS == 2 ? static_cast<uint32_t>(M.mstart >> (4 * d)) & 15u : 0u;
+    if (PASS != 2) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t b = (w >> (8 * k)) & 255u;
-      if (lit4 & (1u << k)) {
-        if (PASS == 0) atomicAdd(&hist[b], 1u);
-        else if (PASS == 1) bits += static_cast<int>(clen[b]);
-        else { const uint32_t pv = code[b]; bw->put(pv & 0xFFFFu, static_cast<int>(pv >> 16)); }      // (code[] carries the length in its upper half)
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t b = (w >> (8 * k)) & 255u;
+        if (lit4 & (1u << k)) {
+          if (PASS == 0) atomicAdd(&hist[b], 1u);
+          else bits += static_cast<int>(clen[b]);
+        }
       }
-      if (PASS == 2 && (ms4 & (1u << k))) {          // the match behind a run's first byte (distance 1: one zero bit)
-        const int i = 4 * d + k;
-        const unsigned long long rest = ~(M.covered >> i);
-        const int mlen = rest ? __ffsll(static_cast<long long>(rest)) - 1 : 64 - i;
-        int msym, meb, mev;
-        len_code(mlen, &msym, &meb, &mev);
-        const uint32_t pm = code[msym];
-        bw->put(pm & 0xFFFFu, static_cast<int>(pm >> 16));
-        if (meb) bw->put(static_cast<uint32_t>(mev), meb);
-        bw->put(0u, 1);
+    } else {
+      // emission, two bytes per put: a byte that is no literal contributes zero bits (a select, not a branch), so the pair's
+      // codes go out as ONE word of at most 30 bits; the match that starts at one of the two positions - its bytes are no
+      // literals, so the order inside the pair does not matter - follows in a rarely taken branch
+      const uint32_t ms4 = static_cast<uint32_t>(M.mstart >> (4 * d)) & 15u;
+#pragma unroll
+      for (int k = 0; k < 4; k += 2) {
+        const uint32_t p0 = code[(w >> (8 * k)) & 255u], p1 = code[(w >> (8 * k + 8)) & 255u];      // (code[] carries the length in its upper half)
+        const uint32_t c0 = (lit4 & (1u << k)) ? p0 : 0u, c1 = (lit4 & (2u << k)) ? p1 : 0u;
+        const uint32_t l0 = c0 >> 16;
+        bw->put((c0 & 0xFFFFu) | ((c1 & 0xFFFFu) << l0), static_cast<int>(l0 + (c1 >> 16)));
+        if (ms4 & (3u << k)) {                       // the match behind a run's first byte (distance 1: one zero bit)
+          const int i = 4 * d + k + ((ms4 >> k) & 1u ? 0 : 1);
+          const unsigned long long rest = ~(M.covered >> i);
+          const int mlen = rest ? __ffsll(static_cast<long long>(rest)) - 1 : 64 - i;
+          int msym, meb, mev;
+          len_code(mlen, &msym, &meb, &mev);
+          const uint32_t pm = code[msym];
+          bw->put(pm & 0xFFFFu, static_cast<int>(pm >> 16));
+          if (meb) bw->put(static_cast<uint32_t>(mev), meb);
+          bw->put(0u, 1);
+        }
       }
     }
   }
