@@ -775,9 +775,8 @@ class FileDecoder {
     JpegImage full;
     // The scan is de-stuffed (SSE2, 16 bytes a step) into a heap block the context keeps from call to call and goes to the
     // device in ONE copy.  (measured, 120 calls each, twice: from a page-locked block of the context instead - a true DMA, no
-    // bounce buffer - the call's median was 0.08 ms lower, 2.35 vs 2.43 ms, but one call in ~100 took 8 ms: concurrent pinned
-    // copies from nine threads on eight streams now and then stall for ~6 ms; in 256 KB pieces they did so in half of the
-    // calls.  The pageable path never did.)
+    // bounce buffer - the call's median was the same, 2.35 vs 2.34-2.37 ms, so the simpler path stayed; in 256 KB pieces sent
+    // while the rest was still being de-stuffed, half of the calls took 8 ms.)
     if (k < ctx_->scan_bufs.size()) D.G.stream.swap(ctx_->scan_bufs[k]);            // (a recycled block: capacity, no contents)
     const int rc = jpeg_parse_and_entropy_decode(f, len, &full, false, gpu_huffman_ ? &D.G : nullptr);
     if (rc) { failed(rc); return; }
