@@ -308,7 +308,7 @@ static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool head
         const uint32_t total_mcus = static_cast<uint32_t>(J->mcus_x) * static_cast<uint32_t>(J->mcus_y);
         const uint32_t ri = static_cast<uint32_t>(restart_interval);
         const uint32_t n_iv = ri ? (total_mcus + ri - 1) / ri : 0;
-        // (every interval occupies whole workgroups of the GPU decoder - 32 KB of bitstream positions - so a file cut into
+        // (every interval occupies whole workgroups of the GPU decoder - 16 KB of bitstream positions - so a file cut into
         // thousands of tiny intervals is cheaper on the host)
         bool in_sequence = n_iv <= kMaxGpuIntervals;
         // the output never overtakes the input; every interval adds at most 271 bytes of padding; 32 bytes of slack for the

@@ -48,7 +48,14 @@ namespace {
 #define IST_SUB_BITS 1024
 #endif
 constexpr int kSubBits = IST_SUB_BITS;
-constexpr int kSyncThreads = 256;       // subsequences per workgroup of the synchronisation kernel
+#ifndef IST_SYNC_THREADS
+#define IST_SYNC_THREADS 128
+#endif
+// subsequences per workgroup of the synchronisation kernel (a multiple of kWriteThreads); a unit - an image, or ONE RESTART
+// INTERVAL of it - is padded to whole workgroups.  (measured: 128 instead of 256 costs scans without restart intervals nothing,
+// sync launches 0.95-0.96 vs 0.96-0.98 ms, and halves what short intervals waste: nine 12 MP photos with an interval per MCU row
+// 4.17 -> 2.72 ms, per 32 MCUs 13.7 -> 6.4 ms)
+constexpr int kSyncThreads = IST_SYNC_THREADS;
 constexpr int kWriteThreads = 128;      // ... of the writing kernel (it also holds one 8x8 block per thread in LDS)
 constexpr int kMarginWords = 64;        // staged behind a workgroup's own bits: a block can run 64 x 27 bits past its start
 constexpr int kMaxPasses = 64;
@@ -79,7 +86,7 @@ typedef __attribute__((address_space(1))) int16_t* GlobalI16;
 typedef __attribute__((address_space(1))) uint32_t* GlobalU32;
 
 // What a workgroup keeps in LDS: the scan's Huffman tables and the record of its image (a workgroup never spans two
-// images: the host pads every image's subsequences to a multiple of 256) and ITS PART OF THE BITSTREAM, byte-swapped
+// images: the host pads every image's subsequences to whole workgroups) and ITS PART OF THE BITSTREAM, byte-swapped
 // into big-endian words, plus a margin.  The decoding loop then touches global memory only to store finished blocks.
 // (Round 2's first version kept all of this in global memory.  What paced it was not the dependent look-ups but the
 // lock step: the 64 lanes of a wave refill their bit windows at different symbols, so nearly EVERY step of the wave
@@ -342,16 +349,18 @@ constexpr int kSyncBlock = kSyncThreads + 64;
 
 __global__ __launch_bounds__(kSyncBlock) void ist_jpeg_sync_kernel(const SyncArgs A) {
   __shared__ uint32_t ex_p[kSyncThreads + kGhosts], ex_cz[kSyncThreads + kGhosts];
-  __shared__ uint32_t tot[2][4];
+  constexpr int kHalves = kSyncThreads / 128;                    // groups of kWriteThreads subsequences per workgroup
+  static_assert(kSyncThreads % 128 == 0 && kHalves >= 1 && kHalves <= 2, "half totals");
+  __shared__ uint32_t tot[kHalves][4];
   __shared__ WgShared<kSyncThreads + kGhosts> sh;
   const int tid = threadIdx.x;
   const bool owned = tid < kSyncThreads;
-  const int g0 = blockIdx.x * kSyncThreads;                      // (the grid is exactly the padded subsequence count / 256)
+  const int g0 = blockIdx.x * kSyncThreads;                      // (the grid is exactly the padded subsequence count / kSyncThreads)
   const DevImg* gimg = &A.imgs[A.sub_img[g0 / kWriteThreads]];   // one image per workgroup
   const int i0 = g0 - gimg->first_sub;                           // the workgroup's first subsequence inside its image
   const int n_ghost = A.pass == 0 ? min(kGhosts, i0) : 0;
   const uint32_t first_bit = static_cast<uint32_t>(i0 - n_ghost) * static_cast<uint32_t>(kSubBits);
-  if (tid < 8) tot[tid >> 2][tid & 3] = 0u;
+  if (tid < 4 * kHalves) tot[tid >> 2][tid & 3] = 0u;
   load_record(&sh, gimg);
   // e = position in the exchange arrays: ghosts first, then the owned subsequences; everybody's left neighbour is e - 1
   const int ghost_k = tid - kSyncThreads;                        // 0 .. for the ghost wave's first lanes
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(kSyncBlock) void ist_jpeg_sync_kernel(const SyncArg
     atomicAdd(&tot[tid >> 7][2], static_cast<uint32_t>(T.dc[1])); atomicAdd(&tot[tid >> 7][3], static_cast<uint32_t>(T.dc[2]));
   }
   __syncthreads();
-  if (tid < 8) A.half_total[(2 * blockIdx.x + (tid >> 2)) * 4 + (tid & 3)] = tot[tid >> 2][tid & 3];
+  if (tid < 4 * kHalves) A.half_total[(kHalves * blockIdx.x + (tid >> 2)) * 4 + (tid & 3)] = tot[tid >> 2][tid & 3];
   if (!live || !owned) return;
   // the launch changed something the NEXT workgroup depends on (or ran out of inner passes): not the fixed point yet
   const bool last = tid == kSyncThreads - 1 || i + 1 == static_cast<uint32_t>(sh.img.n_sub);
@@ -513,14 +522,28 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   std::vector<size_t> o_stream(n_img), o_tab(n_img), first_unit(n_img + 1);
   std::vector<DevImg> H;
   int64_t n_sub_total = 0;
+  // (the group -> unit map is 16 bits wide: when a batch has more units than that, the files with the most restart intervals
+  // are left to the host decoder - their ok[] stays 0 - until the rest fits)
+  std::vector<char> skip(n_img, 0);
+  {
+    size_t total = 0;
+    for (size_t k = 0; k < n_img; ++k) total += items[k].S->iv.empty() ? 1 : items[k].S->iv.size();
+    while (total > 65535) {
+      size_t worst = n_img, most = 1;
+      for (size_t k = 0; k < n_img; ++k) if (!skip[k] && items[k].S->iv.size() > most) { most = items[k].S->iv.size(); worst = k; }
+      if (worst == n_img) break;                       // (only single-unit files left: more than 65535 files cannot happen, kMaxImages)
+      skip[worst] = 1; total -= most;
+    }
+  }
   for (size_t k = 0; k < n_img; ++k) {
     const JpegImage& J = *items[k].J; const JpegGpuScan& S = *items[k].S;
+    first_unit[k] = units.size();
+    if (skip[k]) { o_stream[k] = 0; continue; }
     if (S.bits >= (1ll << 32) - 65536) return fail(IST_E_UNSUPPORTED, "JPEG scan too large for the GPU entropy decoder");
     // the kernels index slot_comp / slot_idx (10 entries, T.81 B.2.3) with the MCU slot: never launch outside that
     if (S.slots < 1 || S.slots > 10) return fail(IST_E_DECODE, "JPEG scan with more than 10 blocks per MCU");
     if (S.iv.empty() && S.stream.size() != static_cast<size_t>(S.bits / 8) + 16) return fail(IST_E_INVALID, "JPEG scan buffer without its padding");
     o_stream[k] = items[k].d_stream ? 0 : take(S.stream.size());
-    first_unit[k] = units.size();
     const size_t n_units = S.iv.empty() ? 1 : S.iv.size();
     for (size_t u = 0; u < n_units; ++u) {
       DevImg I;
@@ -542,7 +565,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
       I.first_sub = static_cast<int32_t>(n_sub_total & 0x7fffffff);
       I.n_sub = static_cast<int32_t>((I.bits + kSubBits - 1) / kSubBits);
       if (I.n_sub < 1) I.n_sub = 1;
-      n_sub_total += (static_cast<int64_t>(I.n_sub) + 255) & ~255LL;        // a workgroup (256 subsequences) never spans two units
+      n_sub_total += (static_cast<int64_t>(I.n_sub) + (kSyncThreads - 1)) & ~static_cast<int64_t>(kSyncThreads - 1);        // a workgroup never spans two units
       I.slots = S.slots; I.mcus_x = J.mcus_x;
       std::memcpy(I.slot_comp, S.slot_comp, 10); std::memcpy(I.slot_idx, S.slot_idx, 10);
       std::memcpy(I.dc_tab, S.dc_tab, 3); std::memcpy(I.ac_tab, S.ac_tab, 3);
@@ -557,11 +580,10 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   }
   first_unit[n_img] = units.size();
   const size_t n_unit = units.size();
-  // (the group -> unit map is 16 bits wide: a batch with more restart intervals than that goes to the host decoder)
-  if (n_unit > 65535) return IST_OK;
+  if (n_unit > 65535 || n_unit == 0) return IST_OK;          // (every file skipped: the host decodes)
   if (n_sub_total >= (1ll << 31)) return fail(IST_E_UNSUPPORTED, "too much JPEG data for one GPU entropy-decode batch");
   const int ns = static_cast<int>(n_sub_total);
-  const int n_half = ns / kWriteThreads;            // groups of 128 subsequences (ns is a multiple of 256)
+  const int n_half = ns / kWriteThreads;            // groups of 128 subsequences (ns is a multiple of kSyncThreads)
   // the small inputs (Huffman tables, image records, the group -> image map) are ONE contiguous region, uploaded by ONE copy
   // from a pinned block: as nine pageable copies of 10 KB each they were blocking staged copies, ~0.2 ms of the call
   const size_t o_small = off;
@@ -601,6 +623,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   uint16_t* half_img = reinterpret_cast<uint16_t*>(hs + (o_sub - o_small));   // unit of every group of 128 subsequences
   for (size_t k = 0; k < n_img; ++k) {
     const JpegGpuScan& S = *items[k].S;
+    if (skip[k]) continue;
     if (!items[k].d_stream) JG_HIP(hipMemcpyAsync(d + o_stream[k], S.stream.data(), S.stream.size(), hipMemcpyHostToDevice, stream));
     std::memcpy(hs + (o_tab[k] - o_small), &S.tables, sizeof(S.tables));
   }
@@ -609,7 +632,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     H[u].stream = (items[k].d_stream ? items[k].d_stream : d + o_stream[k]) + units[u].byte_off;
     H[u].tables = reinterpret_cast<const JpegGpuTables*>(d + o_tab[k]);
     H[u].err = reinterpret_cast<uint32_t*>(d + o_err) + u;
-    for (int i = 0; i < ((H[u].n_sub + 255) & ~255); i += kWriteThreads) half_img[static_cast<size_t>((H[u].first_sub + i) / kWriteThreads)] = static_cast<uint16_t>(u);
+    for (int i = 0; i < ((H[u].n_sub + (kSyncThreads - 1)) & ~(kSyncThreads - 1)); i += kWriteThreads) half_img[static_cast<size_t>((H[u].first_sub + i) / kWriteThreads)] = static_cast<uint16_t>(u);
     // (the writing pass stores every block of the planes whole, DC included: no clearing pass, no DC pass)
   }
   JG_HIP(hipMemsetAsync(d + o_err, 0, 4 * n_unit, stream));
@@ -653,11 +676,11 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   JG_HIP(hipMemcpyAsync(h_err, d + o_err, 4 * n_unit, hipMemcpyDeviceToHost, stream));
   JG_HIP(hipStreamSynchronize(stream));
   for (size_t k = 0; k < n_img; ++k) {
-    bool good = true;
+    bool good = !skip[k];
     for (size_t w = first_unit[k]; w < first_unit[k + 1]; ++w) {              // every restart interval holds exactly its MCUs
       const DevImg& I = H[w];
       uint32_t blocks = 0;
-      for (int u = I.first_sub / kWriteThreads; u < (I.first_sub + ((I.n_sub + 255) & ~255)) / kWriteThreads; ++u) blocks += half[4 * static_cast<size_t>(u)];
+      for (int u = I.first_sub / kWriteThreads; u < (I.first_sub + ((I.n_sub + (kSyncThreads - 1)) & ~(kSyncThreads - 1))) / kWriteThreads; ++u) blocks += half[4 * static_cast<size_t>(u)];
       good = good && blocks == static_cast<uint32_t>(I.total_blocks) && err[w] == 0;
     }
     (*ok)[k] = good ? 1 : 0;

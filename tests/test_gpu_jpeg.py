@@ -197,6 +197,28 @@ def test_gpu_entropy_decoder_restart_intervals_full_size_and_too_many(tmp_path):
     assert _gpu_files() - before == 1
 
 
+def test_more_restart_intervals_than_a_batch_holds(tmp_path):
+    """The Huffman batch addresses its units with 16 bits.  33 files of 2016 intervals each + 2 plain ones are 66 530 units: the
+    batch leaves as many of the interval-heavy files to the host decoder as it takes to fit (one), and every file still decodes
+    to PIL's pixels."""
+    paths, want = [], []
+    base = _photo(400, 1008, 512)
+    dri = _jpeg(base, quality=70, subsampling=2, restart_marker_blocks=1)           # 32 x 63 MCUs, one interval each
+    plain = _jpeg(base, quality=70, subsampling=2)
+    for k in range(35):
+        data = plain if k in (0, 20) else dri
+        p = tmp_path / ("b%d.jpg" % k)
+        p.write_bytes(data)
+        paths.append(str(p))
+    before = _gpu_files()
+    res = ist.stitch_files(paths, "horizontal", {"filter": "nearest"})
+    assert _gpu_files() - before == 34
+    got = ist.decode_png(res["png"])
+    a, b = _pil(plain), _pil(dri)
+    for k in range(35):
+        assert np.array_equal(got[:, 512 * k:512 * (k + 1)], a if k in (0, 20) else b), k
+
+
 def test_gpu_entropy_decoder_damaged_restart_markers_go_to_the_host(tmp_path):
     """a marker missing, a marker out of sequence, one too many, and a truncated interval: never the GPU path's pixels
     unless they are the host decoder's too"""
