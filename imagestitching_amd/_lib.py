@@ -130,6 +130,8 @@ SYMBOLS = [
     ("ist_ctx_last_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     ("ist_stitch_files_png", C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_double,
                                        C.POINTER(Limits), C.c_int, C.POINTER(Plan), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int64)]),
+    ("ist_stitch_paths_png", C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_double,
+                                       C.POINTER(Limits), C.c_int, C.POINTER(Plan), C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int64)]),
     ("ist_png_bound", C.c_int64, [C.c_int64, C.c_int64]),
     ("ist_png_encode_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                                         C.POINTER(C.c_int64), C.c_void_p]),

@@ -5,6 +5,10 @@
 // index.js:1391-1428, 1532-1551); launch for the raster flush the export forces (utils/canvas.js:205-242).
 // There is deliberately no CPU fallback: without a HIP device every rendering entry point fails.
 #include <hip/hip_runtime_api.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <cstdlib>
@@ -1095,6 +1099,32 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   *out_png = host; *out_len = len;
   pg.keep = true;
   return IST_OK;
+}
+
+int ist_stitch_paths_png(ist_ctx* ctx, const char* const* paths, int n_images, int direction, int mode, double gap, const ist_limits* limits,
+                         int filter, ist_plan* out_plan, uint8_t** out_png, int64_t* out_len) {
+  if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (n_images <= 0) return IST_NOTHING_TO_DO;
+  if (!paths) return fail(IST_E_INVALID, "ist_stitch_paths_png: NULL input");
+  if (n_images > kMaxImages) return fail(IST_E_UNSUPPORTED, "more than 128 images in one launch");
+  struct Maps {
+    std::vector<const uint8_t*> p; std::vector<int64_t> n;
+    ~Maps() { for (size_t i = 0; i < p.size(); ++i) if (p[i]) (void)munmap(const_cast<uint8_t*>(p[i]), static_cast<size_t>(n[i])); }
+  } m;
+  m.p.assign(static_cast<size_t>(n_images), nullptr); m.n.assign(static_cast<size_t>(n_images), 0);
+  for (int i = 0; i < n_images; ++i) {
+    const int fd = paths[i] ? open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0 || st.st_size <= 0) {
+      if (fd >= 0) (void)close(fd);
+      return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常: " + (fd < 0 ? "cannot open the file" : "empty file"));
+    }
+    void* at = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+    (void)close(fd);
+    if (at == MAP_FAILED) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常: cannot map the file");
+    m.p[static_cast<size_t>(i)] = static_cast<const uint8_t*>(at); m.n[static_cast<size_t>(i)] = static_cast<int64_t>(st.st_size);
+  }
+  return ist_stitch_files_png(ctx, m.p.data(), m.n.data(), n_images, direction, mode, gap, limits, filter, out_plan, out_png, out_len);
 }
 
 // PNG of host pixels (H2D, encode, D2H)

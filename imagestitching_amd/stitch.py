@@ -363,35 +363,14 @@ def stitch_files(paths, direction, opts=None, out_path=None, device=0, copy=True
     n = len(paths)
     if n == 0:
         return None
-    # the files are MAPPED, not read: the library parses them where the page cache holds them (reading nine 12 MP JPEGs into
-    # Python bytes cost ~1 ms of the 8 ms call)
-    import mmap
-    maps, views = [], []
-    try:
-        for p in paths:
-            with open(p, "rb") as f:
-                size = os.fstat(f.fileno()).st_size
-                if size == 0:
-                    raise L.StitchError(-6, "图片%d解码异常: empty file" % len(maps))
-                m = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
-            maps.append(m)
-            views.append(np.frombuffer(m, np.uint8))
-        files = (C.c_char_p * n)()
-        for i, v in enumerate(views):
-            files[i] = C.cast(C.c_void_p(v.ctypes.data), C.c_char_p)
-        lens = (C.c_int64 * n)(*[v.size for v in views])
-        cplan = L.Plan()
-        lim = _limits(o)
-        out, ln = C.POINTER(C.c_uint8)(), C.c_int64(0)
-        rc = L.check(L.lib.ist_stitch_files_png(_ctx_png(device, o["pngLevel"]), files, lens, n, _DIRECTIONS[direction], _MODES[o["mode"]], float(o["gap"] or 0),
-                                                C.byref(lim), _filter_of(o), C.byref(cplan), C.byref(out), C.byref(ln)))
-    finally:
-        del views
-        for m in maps:
-            try:
-                m.close()
-            except BufferError:
-                pass
+    # the library maps the files itself (ist_stitch_paths_png): it parses them where the page cache holds them.  (Reading nine
+    # 12 MP JPEGs into Python bytes cost ~1 ms of the call; opening and mapping them from Python still 0.2 ms.)
+    cpaths = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    cplan = L.Plan()
+    lim = _limits(o)
+    out, ln = C.POINTER(C.c_uint8)(), C.c_int64(0)
+    rc = L.check(L.lib.ist_stitch_paths_png(_ctx_png(device, o["pngLevel"]), cpaths, n, _DIRECTIONS[direction], _MODES[o["mode"]], float(o["gap"] or 0),
+                                            C.byref(lim), _filter_of(o), C.byref(cplan), C.byref(out), C.byref(ln)))
     if rc == L.IST_NOTHING_TO_DO:
         return None
     w, h = int(cplan.canvas_w), int(cplan.canvas_h)

@@ -296,6 +296,12 @@ IST_API int ist_ctx_last_timing(ist_ctx* ctx, double* ms, int n);
 IST_API int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images,
                                  int direction, int mode, double gap, const ist_limits* limits, int filter,
                                  ist_plan* out_plan, uint8_t** out_png, int64_t* out_len);
+/* the same from file PATHS (what wx.chooseImage hands the page: tempFilePaths, index.js:1441-1450): the library maps the files
+ * read-only for the duration of the call (no copy: the parsers read the page cache).  A path that cannot be opened or is
+ * empty fails with IST_E_DECODE and '图片N解码异常: ...'. */
+IST_API int ist_stitch_paths_png(ist_ctx* ctx, const char* const* paths, int n_images,
+                                 int direction, int mode, double gap, const ist_limits* limits, int filter,
+                                 ist_plan* out_plan, uint8_t** out_png, int64_t* out_len);
 
 /* ---- export: lossless PNG (fileType 'png', quality 1; utils/canvas.js:205-242, index.js:1577-1579) --------------- */
 /* upper bound of the file size for a w x h RGBA canvas */

@@ -197,6 +197,20 @@ def test_gpu_entropy_decoder_restart_intervals_full_size_and_too_many(tmp_path):
     assert _gpu_files() - before == 1
 
 
+def test_stitch_files_names_the_file_it_cannot_open(tmp_path):
+    """ist_stitch_paths_png maps the files itself: a missing or empty one fails the call like a file that does not decode -
+    the reference's message with the image's index (index.js:1512-1514)."""
+    good = tmp_path / "good.jpg"
+    good.write_bytes(_jpeg(_photo(1, 40, 56), quality=80))
+    (tmp_path / "empty.jpg").write_bytes(b"")
+    for bad, what in ((tmp_path / "missing.jpg", "cannot open"), (tmp_path / "empty.jpg", "empty")):
+        with pytest.raises(ist.StitchError) as e:
+            ist.stitch_files([str(good), str(bad)], "vertical")
+        assert "图片1解码异常" in str(e.value) and what in str(e.value)
+    res = ist.stitch_files([str(good), str(good)], "vertical", {"filter": "nearest"})
+    assert res["height"] == 80 and res["width"] == 56
+
+
 def test_more_restart_intervals_than_a_batch_holds(tmp_path):
     """The Huffman batch addresses its units with 16 bits.  33 files of 2016 intervals each + 2 plain ones are 66 530 units: the
     batch leaves as many of the interval-heavy files to the host decoder as it takes to fit (one), and every file still decodes
