@@ -233,4 +233,43 @@ int Stager::run(const std::vector<RowsCopy>& items, bool up, hipStream_t other) 
   return IST_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ parked host threads
+WorkerPool::~WorkerPool() {
+  { std::lock_guard<std::mutex> lock(mu_); stop_ = true; }
+  work_cv_.notify_all();
+  for (std::thread& t : th_) if (t.joinable()) t.join();
+}
+
+void WorkerPool::loop() {
+  std::unique_lock<std::mutex> lock(mu_);
+  for (;;) {
+    work_cv_.wait(lock, [&]() { return stop_ || next_ < total_; });
+    if (stop_) return;
+    const int i = next_++;
+    lock.unlock();
+    fn_(i);
+    lock.lock();
+    if (++done_ == total_) done_cv_.notify_all();
+  }
+}
+
+void WorkerPool::run(int n, std::function<void(int)> fn) {
+  if (n <= 0) return;
+  {
+    std::lock_guard<std::mutex> lock(mu_);
+    fn_ = std::move(fn);
+    next_ = 0; done_ = 0; total_ = n;
+    const size_t want = static_cast<size_t>(n < kMaxThreads ? n : kMaxThreads);
+    while (th_.size() < want) th_.emplace_back([this]() { loop(); });
+  }
+  work_cv_.notify_all();
+}
+
+void WorkerPool::wait() {
+  std::unique_lock<std::mutex> lock(mu_);
+  done_cv_.wait(lock, [&]() { return done_ == total_; });
+  total_ = 0; next_ = 0; done_ = 0;
+}
+
 }  // namespace ist

@@ -194,6 +194,7 @@ void ist_ctx_destroy(ist_ctx* ctx) {
   if (ctx->png2) { (void)hipStreamSynchronize(ctx->png2); (void)hipStreamDestroy(ctx->png2); }
   if (ctx->render_done) (void)hipEventDestroy(ctx->render_done);
   for (const ist_ctx::TableBlock& b : ctx->table_pool) dev_free(b.p);
+  ctx->workers.reset();
   ctx->stager.reset();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -629,7 +630,7 @@ int ensure_image_lanes(ist_ctx* ctx, int n) {
 class FileDecoder {
  public:
   FileDecoder(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n, Phases* ph)
-      : ctx_(ctx), files_(files), lens_(lens), n_(n), ph_(ph), dec_(static_cast<size_t>(n)), th_(static_cast<size_t>(n)),
+      : ctx_(ctx), files_(files), lens_(lens), n_(n), ph_(ph), dec_(static_cast<size_t>(n)),
         on_gpu_(static_cast<size_t>(n), 0), taken_(static_cast<size_t>(n), 0), uploaded_(static_cast<size_t>(n), 0), started_(static_cast<size_t>(n), 0), jo_(static_cast<size_t>(n)) {}
   ~FileDecoder() {
     join_all();
@@ -670,7 +671,9 @@ class FileDecoder {
     arena_ = arena; img_ = img; pitch_ = pitch;
     const int rc = ensure_image_lanes(ctx_, n_);
     if (rc) return rc;
-    for (int i = 0; i < n_; ++i) th_[static_cast<size_t>(i)] = std::thread([this, i]() { worker(i); });
+    if (!ctx_->workers) ctx_->workers.reset(new WorkerPool());
+    ctx_->workers->run(n_, [this](int i) { worker(i); });
+    running_ = true;
     if (!ph_->on) return IST_OK;
     // phase timing: the steps one after the other
     join_all();
@@ -729,7 +732,7 @@ class FileDecoder {
 
  private:
   hipStream_t stream_of(int i) const { return ctx_->img_stream[static_cast<size_t>(i % kImgStreams) % ctx_->img_stream.size()]; }
-  void join_all() { for (std::thread& t : th_) if (t.joinable()) t.join(); }
+  void join_all() { if (running_) { ctx_->workers->wait(); running_ = false; } }
   int first_error() {
     for (int i = 0; i < n_; ++i) if (dec_[static_cast<size_t>(i)].rc != IST_OK) return fail(dec_[static_cast<size_t>(i)].rc, "图片" + std::to_string(i) + "解码异常: " + dec_[static_cast<size_t>(i)].err);
     return IST_OK;
@@ -802,7 +805,7 @@ class FileDecoder {
 
   ist_ctx* ctx_; const uint8_t* const* files_; const int64_t* lens_; int n_; Phases* ph_;
   std::vector<Dec> dec_;
-  std::vector<std::thread> th_;
+  bool running_ = false;                                       // the context's worker pool is on this call's files
   std::vector<char> on_gpu_, taken_, uploaded_, started_;      // started_: the image's stream carries uploads of this call
   std::vector<JpegDevLayout> jo_;
   uint8_t* arena_ = nullptr; uint8_t* const* img_ = nullptr; const size_t* pitch_ = nullptr;
@@ -928,9 +931,14 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
   Phases ph(ctx);
+  // (IST_TUNING=1 IST_TIMELINE=1: host-side marks of one call on stderr, microseconds from its start)
+  static const bool timeline = tuning_mode() && std::getenv("IST_TIMELINE") != nullptr;
+  const auto tl0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) { if (timeline) std::fprintf(stderr, "[ist timeline] %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl0).count(), what); };
   FileDecoder fd(ctx, files, lens, n, &ph);
   int rc = fd.headers();
   if (rc) return rc;
+  mark("headers parsed");
   // plan (orientation from the file, like getImageInfo -> index.js:734)
   std::vector<ist_image_desc> descs(static_cast<size_t>(n));
   for (int i = 0; i < n; ++i) {
@@ -971,8 +979,10 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
     dsrc[static_cast<size_t>(i)] = img[static_cast<size_t>(i)];
     dpitch[static_cast<size_t>(i)] = static_cast<size_t>(fd.dec(i).w) * 4;
   }
+  mark("plan + arena");
   rc = fd.start(d, img.data(), dpitch.data());          // the images decode from here on
   if (rc) return rc;
+  mark("workers started");
   // Two streams: RENDER (Huffman batch, then per image: reconstruction + its band of the canvas) and ctx->stream (the PNG
   // encoder, which waits for band k's event before it compresses the slabs that read it).  On one stream the reconstruction
   // of image k+1 sat between the slabs of band k and band k+1 and cost its full time; on its own stream it runs beside them.
@@ -989,6 +999,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   BandedJobs bj;
   rc = compile_banded(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, descs.data(), n, filter, &bj);
   if (rc) return rc;
+  mark("banded jobs compiled");
   ist_job* whole = nullptr;
   struct JobFree { ist_job** j; ~JobFree() { if (*j) ist_job_destroy(*j); } } jf{&whole};
   if (!bj.ok) {
@@ -1061,6 +1072,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
     // first request (the short first slab): only the bands it reads, so that the file's first bytes are on their way while the
     // rest is rendered; every later request: everything that is left
     const bool first_request = next_part == 0;
+    if (next_part < bj.parts.size()) mark(first_request ? "first rows requested" : "rest of the rows requested");
     while (next_part < bj.parts.size() && (!first_request || bj.parts[next_part].Y0 < y_end)) {
       const ist_part& p = bj.parts[next_part];
       int rc2 = fd.take(p.image, render);
@@ -1070,6 +1082,7 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
       if (hipEventRecord(ctx->img_event[next_part], render) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "hipEventRecord failed"); }
       ++next_part;
     }
+    if (first_request) mark("first band submitted (Huffman batch done)");
     // the last band that rows [0, y_end) touch (bands are sorted by Y0; the background launch precedes them all on the render
     // stream).  Rows that no band touches (a gap at the top) are ordered behind the background launch alone.
     size_t last = bj.parts.size();
@@ -1089,9 +1102,12 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   uint8_t* host = nullptr;
   int64_t hint_rows = 0;
   for (const ist_part& p : bj.parts) hint_rows = std::max<int64_t>(hint_rows, p.Y1 - p.Y0);
+  mark("encoder entered");
   rc = png_to_host(ctx, d + o_canvas, canvas_pitch, out_plan->canvas_w, out_plan->canvas_h, d + o_png, &host, &len, need_rows, hint_rows);
+  mark("encoder returned (file in host memory)");
   if (rc == IST_OK) rc = fd.finish(render);               // (images whose draw is clipped away entirely)
   (void)hipStreamSynchronize(render);                     // nothing of this call runs on when the arena is handed to the next
+  mark("render stream idle");
   if (rc) { if (host) pool_give(host); (void)hipStreamSynchronize(ctx->stream); return rc; }
   ph.lap(IST_PHASE_PNG, "PNG encode (GPU) + D2H, overlapped", ctx->stream);
   ph.lap(IST_PHASE_D2H, "(D2H: inside the PNG phase)", nullptr);
