@@ -301,8 +301,8 @@ static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool head
         // interval: the entropy coder starts afresh behind it (byte aligned, DC predictors zero), so the intervals are
         // independent streams for the GPU decoder - each is padded to a 256-byte boundary with at least 16 zero bytes.
         // A restart marker out of sequence, or one more than the frame has intervals for, leaves this scan to the host
-        // decoder below (which has the resynchronisation rules); too few intervals fail the GPU decoder's block count and
-        // end up there too.
+        // decoder below (which has the resynchronisation rules); so does a scan that ends with fewer intervals than the frame
+        // needs (checked behind the loop: the GPU decoder's block count is per interval and would not see it).
         const uint8_t* q = d + dl; const uint8_t* qe = f + n;
         gs->iv.clear();
         const uint32_t total_mcus = static_cast<uint32_t>(J->mcus_x) * static_cast<uint32_t>(J->mcus_y);
@@ -355,9 +355,15 @@ static int jpeg_parse_inner(const uint8_t* f, int64_t n, JpegImage* J, bool head
           }
           break;                                                                  // a marker (or a lone FF at the end)
         }
+        if (in_sequence && ri) {
+          close_interval();                                                       // the last interval (ends at the marker that ends the scan)
+          // A scan that ends after k < n_iv intervals (EOI or the end of the file right behind an RSTn) would pass the GPU
+          // decoder's PER-INTERVAL block count while the MCUs behind k*ri are never written: the planes there would still
+          // hold what an earlier call left in the arena.  Such a file is the host decoder's (which reports it).
+          if (gs->iv.size() != n_iv) in_sequence = false;
+        }
         if (in_sequence) {
           if (ri) {
-            close_interval();                                                     // the last interval (ends at the marker that ends the scan)
             gs->bits = static_cast<int64_t>(out - base) * 8;
           } else {
             gs->bits = static_cast<int64_t>(out - base) * 8;

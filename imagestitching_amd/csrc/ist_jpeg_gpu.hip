@@ -543,6 +543,14 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     // the kernels index slot_comp / slot_idx (10 entries, T.81 B.2.3) with the MCU slot: never launch outside that
     if (S.slots < 1 || S.slots > 10) return fail(IST_E_DECODE, "JPEG scan with more than 10 blocks per MCU");
     if (S.iv.empty() && S.stream.size() != static_cast<size_t>(S.bits / 8) + 16) return fail(IST_E_INVALID, "JPEG scan buffer without its padding");
+    // the intervals must tile the frame's MCUs exactly, in order: the per-unit block count below cannot see a missing
+    // interval, and the planes of a MCU nobody writes would keep what an earlier call left in the caller's arena
+    if (!S.iv.empty()) {
+      int64_t at = 0;
+      bool tiled = true;
+      for (const JpegGpuInterval& V : S.iv) { tiled = tiled && V.n_mcus > 0 && static_cast<int64_t>(V.mcu0) == at; at += V.n_mcus; }
+      if (!tiled || at != static_cast<int64_t>(J.mcus_x) * J.mcus_y) { skip[k] = 1; o_stream[k] = 0; continue; }   // ok[k] stays 0: the host decodes (and reports)
+    }
     o_stream[k] = items[k].d_stream ? 0 : take(S.stream.size());
     const size_t n_units = S.iv.empty() ? 1 : S.iv.size();
     for (size_t u = 0; u < n_units; ++u) {

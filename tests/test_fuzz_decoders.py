@@ -98,3 +98,29 @@ def test_progressive_jpeg_gives_the_coefficients_of_its_sequential_twin(tmp_path
     for b, p in zip(rows[0::2], rows[1::2]):
         assert b[-1] == p[-1], (b, p)                 # same coefficient hash
         assert b[2] == "scans=1" and int(p[2].split("=")[1]) > 1
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++ for the sanitizer build")
+def test_a_scan_with_too_few_restart_intervals_is_not_eligible_for_the_gpu_decoder(tmp_path):
+    """a DRI scan that ends (EOI) at an RSTn boundary after k < n intervals must not reach the GPU entropy
+    decoder - its block count is per interval, and the MCUs nobody writes would keep an earlier call's coefficients.  The
+    harness aborts when an eligible scan's intervals do not tile the frame's MCUs; it runs that check on files the host
+    decoder rejects too."""
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, 256, (160, 240, 3), dtype=np.uint8)
+    import io
+    b = io.BytesIO()
+    Image.fromarray(a).save(b, "JPEG", quality=90, subsampling=2, restart_marker_rows=1)
+    good = b.getvalue()
+    marks = [i for i in range(good.find(b"\xff\xda"), len(good) - 1) if good[i] == 0xFF and 0xD0 <= good[i + 1] <= 0xD7]
+    assert len(marks) == 9
+    files = []
+    for k, cut in enumerate((marks[0], marks[3], marks[3] + 2, marks[8], marks[8] + 2)):
+        p = tmp_path / ("cut%d.jpg" % k)
+        p.write_bytes(good[:cut] + b"\xff\xd9")
+        files.append(str(p))
+    (tmp_path / "whole.jpg").write_bytes(good)
+    env = dict(os.environ, IST_FUZZ_BIN=str(tmp_path / "fuzz"))
+    r = subprocess.run([os.path.join(ROOT, "tools", "run_fuzz.sh"), "0", str(tmp_path / "whole.jpg")] + files, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "0 crashes" in r.stdout

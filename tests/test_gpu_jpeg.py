@@ -264,6 +264,46 @@ def test_gpu_entropy_decoder_damaged_restart_markers_go_to_the_host(tmp_path):
             assert np.array_equal(ist.decode_png(res["png"]), host), name
 
 
+def test_a_scan_that_ends_after_too_few_restart_intervals_never_shows_an_earlier_calls_image(tmp_path):
+    """ADVICE r03 (high): a DRI scan cut at an RSTn boundary (k < n intervals, EOI appended) passes a PER-INTERVAL block count;
+    the coefficient planes live in the context's grow-only arena, so the rows of the missing intervals would be reconstructed
+    from what the previous call left there.  The parser now hands such a file to the host decoder: the result is the host
+    decoder's (an error, or its pixels), never the GPU path's, and it does not depend on what was decoded before."""
+    a, b = _photo(401, 160, 240), 255 - _photo(402, 160, 240)
+    first = tmp_path / "first.jpg"
+    first.write_bytes(_jpeg(b, quality=90, subsampling=2, restart_marker_rows=1))
+    good = _jpeg(a, quality=90, subsampling=2, restart_marker_rows=1)
+    marks = [i for i in range(good.find(b"\xff\xda"), len(good) - 1) if good[i] == 0xFF and 0xD0 <= good[i + 1] <= 0xD7]
+    assert len(marks) == 9                                                # ten MCU rows of 16
+    for cut in (marks[3], marks[3] + 2, marks[8]):                        # in front of an RSTn, right behind it, the last one
+        data = good[:cut] + b"\xff\xd9"
+        p = tmp_path / ("cut%d.jpg" % cut)
+        p.write_bytes(data)
+        try:
+            host = ist.decode_image(data)
+        except ist.StitchError:
+            host = None
+        outcomes = []
+        for prime in (True, False, True):
+            if prime:                                                     # same size, same arena offsets: the stale planes are the other photo's
+                before = _gpu_files()
+                ist.stitch_files([str(first)], "vertical", {"filter": "nearest"})
+                assert _gpu_files() - before == 1
+            before = _gpu_files()
+            try:
+                res = ist.stitch_files([str(p)], "vertical", {"filter": "nearest"})
+            except ist.StitchError as e:
+                assert host is None and "解码异常" in str(e)
+                outcomes.append(None)
+            else:
+                assert host is not None
+                got = ist.decode_png(res["png"])
+                assert np.array_equal(got, host)
+                outcomes.append(got)
+            assert _gpu_files() == before                                 # the GPU entropy decoder did not take the file
+        assert all((o is None) == (outcomes[0] is None) for o in outcomes)
+
+
 @pytest.mark.parametrize("direction", ["vertical", "horizontal"])
 def test_images_placed_without_scaling_are_reconstructed_straight_into_the_canvas(tmp_path, direction):
     """mode 'original' keeps every image at its own size: each draw only moves its image (odd offsets, gaps, narrower

@@ -25,9 +25,17 @@ static void one(const std::vector<uint8_t>& f, long* ok, long* bad) {
     ist::JpegImage J;
     rc = ist::jpeg_parse_and_entropy_decode(p, n, &J, true);
     if (rc == IST_OK && int64_t(J.width) * J.height <= (1 << 24)) rc = ist::jpeg_parse_and_entropy_decode(p, n, &J, false);
-    if (rc == IST_OK) {                                        // the container walk that feeds the GPU entropy decoder (de-stuffing, tables)
+    // the container walk that feeds the GPU entropy decoder (de-stuffing, tables) - also for files the host decoder REJECTS:
+    // the GPU path sees a file first, and a scan it wrongly calls eligible is decoded without the host's checks
+    ist::JpegImage Jh;
+    if (ist::jpeg_parse_and_entropy_decode(p, n, &Jh, true) == IST_OK && int64_t(Jh.width) * Jh.height <= (1 << 24)) {
       ist::JpegImage J2; ist::JpegGpuScan G;
       (void)ist::jpeg_parse_and_entropy_decode(p, n, &J2, false, &G);
+      if (G.eligible && !G.iv.empty()) {                       // the intervals tile the frame's MCUs exactly, in order
+        int64_t at = 0;
+        for (const ist::JpegGpuInterval& V : G.iv) { if (V.n_mcus == 0 || int64_t(V.mcu0) != at) abort(); at += V.n_mcus; }
+        if (at != int64_t(J2.mcus_x) * J2.mcus_y) abort();
+      }
       if (G.eligible && (G.slots < 1 || G.slots > 10 || G.bits < 0 || G.stream.size() > G.stream.capacity())) abort();
       if (G.eligible && G.iv.empty() && G.stream.size() != size_t(G.bits / 8) + 16) abort();
       for (const ist::JpegGpuInterval& V : G.iv)                 // restart intervals: aligned, inside the scan, 16 zero bytes behind each
