@@ -18,7 +18,7 @@ VERTICAL, HORIZONTAL = 0, 1
 MODE_MIN, MODE_MAX, MODE_ORIGINAL = 0, 1, 2
 PLATFORM_OTHER, PLATFORM_IOS, PLATFORM_ANDROID = 0, 1, 2
 FILTER_NEAREST, FILTER_BILINEAR, FILTER_AREA = 0, 1, 2
-SPLIT_IMAGE, SPLIT_BAND = 0, 1
+SPLIT_IMAGE, SPLIT_BAND, SPLIT_ROWS, SPLIT_AUTO = 0, 1, 2, 3
 
 IST_OK, IST_NOTHING_TO_DO = 0, 1
 ERROR_NAMES = {-1: "IST_E_INVALID", -2: "IST_E_SIZE_UNAVAILABLE", -3: "IST_E_OUTPUT_SIZE", -4: "IST_E_NO_CONTEXT",
@@ -77,6 +77,7 @@ SYMBOLS = [
     ("ist_debug_device_allocs", C.c_int64, []),
     ("ist_debug_gpu_entropy_files", C.c_int64, []),
     ("ist_debug_direct_images", C.c_int64, []),
+    ("ist_debug_host_sink_stitches", C.c_int64, []),
     ("ist_limits_default", None, [C.c_int, C.POINTER(Limits)]),
     ("ist_limits_unlimited", None, [C.POINTER(Limits)]),
     ("ist_plan_compute", C.c_int, [C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Limits), C.POINTER(Plan)]),
@@ -85,6 +86,8 @@ SYMBOLS = [
     ("ist_op_box", C.c_int, [C.POINTER(Op), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int32)]),
     ("ist_shard_parts", C.c_int, [C.POINTER(Op), C.c_int, C.c_int64, C.c_int64, C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(Part), C.c_int, C.POINTER(C.c_int)]),
+    ("ist_shard_row_cuts", C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_int32)]),
+    ("ist_shard_resolve", C.c_int, [C.POINTER(Op), C.c_int, C.c_int64, C.c_int64, C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int]),
     ("ist_ctx_create", C.c_void_p, [C.c_int]),
     ("ist_ctx_destroy", None, [C.c_void_p]),
     ("ist_ctx_sync", C.c_int, [C.c_void_p]),

@@ -33,6 +33,7 @@ struct ist_ctx {
   std::vector<void*> img_huff; std::vector<size_t> img_huff_bytes;
   std::unique_ptr<ist::WorkerPool> workers;   // parked host threads for the per-file work of a call (made on first use)
   std::vector<ist::ScanBuf> scan_bufs;        // de-stuffed scans of the last call: their memory is reused (a fresh 1.8 MB block per image and call is 450 page faults on its parse thread)
+  std::vector<ist::ScanBuf> file_bufs;        // ist_stitch_paths_png: the files' bytes, read (not mapped) into blocks kept from call to call
   void* scratch_ent = nullptr; size_t scratch_ent_bytes = 0;   // sparse coefficient entries of host-decoded JPEGs (progressive, restart intervals)
   hipStream_t render = nullptr;          // file pipeline: Huffman batch + per-image reconstruction + band launches, beside the PNG encoder on `stream`
   hipEvent_t render_done = nullptr;

@@ -17,12 +17,18 @@
 //     point: each sender has its own link to the root, so there is no ring and no tree to build.
 // RCCL is dlopen'ed on first use (librccl.so.1): hosts that stay on one GPU never load it.
 //
+// UNITS.  What a slot renders into one buffer and delivers in one piece is a UNIT: under IST_SPLIT_IMAGE / IST_SPLIT_BAND a unit
+// is one part (a box of one draw); under IST_SPLIT_ROWS it is the slot's whole band of canvas rows - full width whatever the
+// layout (horizontal strips, index.js:1540-1553; centred rects) - rendered from the whole op list clipped to those rows, so
+// every unit is received in place: no staging band, no placement launch, and the host sink below is always available.
+//
 // HOST SINK (ist_group_stitch_rgba8 on a strip of full-width bands): the export of the reference is host-destined
 // (index.js:1577-1581, utils/canvas.js:205-242), so nothing has to meet on one GPU: every device uploads only the rows its
 // parts sample over its own PCIe link, renders them into compact bands and DMAs each finished band STRAIGHT into its byte
 // range of the pooled pinned result (a full-width band is contiguous there) - no xGMI gather and no 439 MB readback over
-// the root's single link.  The root's launch supplies everything that is not a band (background rows, gaps).  Strips whose
-// bands are not full-width (horizontal, centred) keep the gather + root readback.
+// the root's single link.  The root's launch supplies everything that is not a band (background rows, gaps).  Per-draw cuts
+// of strips whose boxes are not full-width (horizontal, centred) keep the gather + root readback; IST_SPLIT_ROWS - what
+// IST_SPLIT_AUTO picks for them - does not.
 //
 // Nothing is allocated per call after the first: band / staging buffers are grow-only arenas of the group (jobs hold
 // offsets; streams are in order, so jobs may share them), and the one-call host path keeps its compiled group jobs in a
@@ -31,6 +37,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -60,11 +67,14 @@ struct Rccl {
   const char* (*GetErrorString)(int) = nullptr;
   std::string error;
 };
+std::atomic<int64_t> g_host_sink_stitches{0};
 constexpr int kNcclUint8 = 1;        // ncclDataType_t::ncclUint8 (rccl.h)
 
 Rccl* rccl() {
   static Rccl* R = [] {
     Rccl* r = new Rccl;
+    // (IST_TUNING=1 IST_RCCL_UNAVAILABLE=1, tests only: behave as on a host where librccl cannot be loaded)
+    if (tuning_mode() && std::getenv("IST_RCCL_UNAVAILABLE")) { r->error = "librccl.so.1 could not be loaded: disabled by IST_RCCL_UNAVAILABLE"; return r; }
     // the copy already in the process first (a PyTorch host carries its own librccl.so bound to ITS HIP runtime)
     const char* names[] = {"librccl.so", "librccl.so.1"};
     for (const char* n : names) if (!r->lib) r->lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
@@ -117,13 +127,22 @@ struct ist_group_job {
   struct PartRt {
     ist_part part;
     int rank = 0;                         // device index of the owner
-    bool local = false;                   // device sink: rendered on the root's device straight into the canvas
-    ist_job* band_job = nullptr;          // slot != 0
-    size_t band_off = 0;                  // compact band in the owner's arena (slot != 0)
-    ist_job* place_job = nullptr;         // root: staged band -> canvas
-    size_t staging_off = 0;               // root arena (remote parts that are not full-width)
   };
   std::vector<PartRt> parts;
+  // what a non-root slot renders into ONE buffer and delivers in one piece: a part (IMAGE / BAND) or the slot's band (ROWS)
+  struct Unit {
+    int slot = 0, rank = 0;
+    int32_t X0 = 0, Y0 = 0, X1 = 0, Y1 = 0;   // canvas box
+    bool in_place = false;                // full canvas width: a contiguous byte range of the canvas
+    bool local = false;                   // device sink: rendered on the root's device straight into the canvas
+    std::vector<size_t> part_idx;         // the parts whose source pointers the unit's job reads
+    ist_job* band_job = nullptr;
+    size_t band_off = 0;                  // compact band in the owner's arena
+    ist_job* place_job = nullptr;         // root: staged band -> canvas
+    size_t staging_off = 0;               // root arena (units that are not full-width)
+  };
+  std::vector<Unit> units;
+  int split = IST_SPLIT_IMAGE;            // the effective cut (AUTO resolved)
   ist_job* root_job = nullptr;
   std::vector<size_t> band_need;          // per device: bytes of band arena this job addresses
   size_t staging_need = 0;
@@ -135,15 +154,15 @@ namespace {
 
 void group_job_free(ist_group_job* j) {
   if (!j) return;
-  for (auto& p : j->parts) {
-    if (p.band_job) ist_job_destroy(p.band_job);
-    if (p.place_job) ist_job_destroy(p.place_job);
+  for (auto& u : j->units) {
+    if (u.band_job) ist_job_destroy(u.band_job);
+    if (u.place_job) ist_job_destroy(u.place_job);
   }
   if (j->root_job) ist_job_destroy(j->root_job);
   delete j;
 }
 
-inline size_t part_bytes(const ist_part& p) { return static_cast<size_t>(p.X1 - p.X0) * 4 * static_cast<size_t>(p.Y1 - p.Y0); }
+inline size_t unit_bytes(const ist_group_job::Unit& u) { return static_cast<size_t>(u.X1 - u.X0) * 4 * static_cast<size_t>(u.Y1 - u.Y0); }
 inline size_t round256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 
 int group_sync_locked(ist_group* g) {
@@ -226,6 +245,8 @@ void ist_group_destroy(ist_group* g) {
   delete g;
 }
 
+int64_t ist_debug_host_sink_stitches(void) { return g_host_sink_stitches.load(std::memory_order_relaxed); }
+
 int ist_group_slots(const ist_group* g) { return g ? static_cast<int>(g->slot_dev.size()) : 0; }
 int ist_group_device(const ist_group* g, int slot) {
   if (!g || slot < 0 || slot >= static_cast<int>(g->slot_dev.size())) return -1;
@@ -237,17 +258,51 @@ ist_group_job* ist_group_job_create(ist_group* g, int64_t canvas_w, int64_t canv
   if (!g) { fail(IST_E_NO_CONTEXT, "无法获取绘图上下文"); return nullptr; }
   if (!ops || n_ops < 1 || !images || n_images < 1) { fail(IST_E_INVALID, "ist_group_job_create: empty op list"); return nullptr; }
   const int n_slots = static_cast<int>(g->slot_dev.size());
-  std::vector<ist_part> cut(static_cast<size_t>(n_ops) + static_cast<size_t>(n_slots) + 8);
+  split = ist_shard_resolve(ops, n_ops, canvas_w, canvas_h, images, n_images, filter, split);
+  if (split < 0) return nullptr;
+  const bool by_rows = split == IST_SPLIT_ROWS;
+  std::vector<ist_part> cut(by_rows ? static_cast<size_t>(n_ops) * static_cast<size_t>(n_slots) + 8 : static_cast<size_t>(n_ops) + static_cast<size_t>(n_slots) + 8);
   int n_parts = 0;
   if (ist_shard_parts(ops, n_ops, canvas_w, canvas_h, images, n_images, filter, n_slots, split, cut.data(), static_cast<int>(cut.size()), &n_parts) != IST_OK)
     return nullptr;
   std::unique_ptr<ist_group_job, void (*)(ist_group_job*)> job(new ist_group_job, group_job_free);
-  job->g = g; job->cw = canvas_w; job->ch = canvas_h; job->n_images = n_images;
+  job->g = g; job->cw = canvas_w; job->ch = canvas_h; job->n_images = n_images; job->split = split;
   job->band_need.assign(g->devs.size(), 0);
   static const uint8_t transparent[4] = {0, 0, 0, 0};
   const uint8_t* clear = clear_rgba ? clear_rgba : transparent;
+  for (int k = 0; k < n_parts; ++k) {
+    ist_group_job::PartRt rt;
+    rt.part = cut[k];
+    rt.rank = g->slot_rank[static_cast<size_t>(cut[k].slot)];
+    job->parts.push_back(rt);
+  }
+  // units of the non-root slots
+  auto new_unit = [&](int slot, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1) -> ist_group_job::Unit& {
+    ist_group_job::Unit u;
+    u.slot = slot; u.rank = g->slot_rank[static_cast<size_t>(slot)];
+    u.X0 = X0; u.Y0 = Y0; u.X1 = X1; u.Y1 = Y1;
+    u.in_place = X0 == 0 && static_cast<int64_t>(X1) == canvas_w;
+    u.local = u.rank == 0 && !g->self_send;
+    job->units.push_back(u);
+    return job->units.back();
+  };
+  if (by_rows) {
+    std::vector<int32_t> cuts(static_cast<size_t>(n_slots) + 1);
+    if (ist_shard_row_cuts(canvas_h, n_slots, cuts.data()) != IST_OK) return nullptr;
+    for (int sl = 1; sl < n_slots; ++sl) {
+      if (cuts[static_cast<size_t>(sl) + 1] <= cuts[static_cast<size_t>(sl)]) continue;
+      ist_group_job::Unit& u = new_unit(sl, 0, cuts[static_cast<size_t>(sl)], static_cast<int32_t>(canvas_w), cuts[static_cast<size_t>(sl) + 1]);
+      for (size_t k = 0; k < job->parts.size(); ++k) if (job->parts[k].part.slot == sl) u.part_idx.push_back(k);
+    }
+  } else {
+    for (size_t k = 0; k < job->parts.size(); ++k) {
+      const ist_part& p = job->parts[k].part;
+      if (p.slot == 0) continue;
+      new_unit(p.slot, p.X0, p.Y0, p.X1, p.Y1).part_idx.push_back(k);
+    }
+  }
   // the root's own launch: every op that is not a sharded draw (fills), the draws slot 0 owns a part of, and - listed
-  // last, so that nothing lies on top of them - a HOLE over every part someone else writes
+  // last, so that nothing lies on top of them - a HOLE over every unit someone else writes
   std::vector<ist_op> root_ops;
   std::vector<char> root_draw(static_cast<size_t>(n_ops), 0);
   for (int k = 0; k < n_parts; ++k) if (cut[k].slot == 0) root_draw[static_cast<size_t>(cut[k].op)] = 1;
@@ -255,31 +310,23 @@ ist_group_job* ist_group_job_create(ist_group* g, int64_t canvas_w, int64_t canv
     if (ops[k].kind != IST_OP_DRAW || root_draw[static_cast<size_t>(k)]) root_ops.push_back(ops[k]);
   // (a draw that shards into nothing draws nothing: dropping it changes no pixel)
   job->host_sink_ok = true;
-  for (int k = 0; k < n_parts; ++k) {
-    const ist_part& p = cut[k];
-    ist_group_job::PartRt rt;
-    rt.part = p;
-    rt.rank = g->slot_rank[static_cast<size_t>(p.slot)];
-    rt.local = rt.rank == 0 && !g->self_send;
-    if (p.slot != 0) {
-      if (!p.in_place) job->host_sink_ok = false;
-      rt.band_off = job->band_need[static_cast<size_t>(rt.rank)];
-      job->band_need[static_cast<size_t>(rt.rank)] += round256(part_bytes(p));
-      ist_op hole;
-      std::memset(&hole, 0, sizeof hole);
-      hole.kind = IST_OP_HOLE; hole.image = -1;
-      hole.m[0] = 1.0; hole.m[3] = 1.0;
-      hole.d[0] = p.X0; hole.d[1] = p.Y0; hole.d[2] = p.X1 - p.X0; hole.d[3] = p.Y1 - p.Y0;
-      root_ops.push_back(hole);
-    }
-    job->parts.push_back(rt);
+  for (auto& u : job->units) {
+    if (!u.in_place) job->host_sink_ok = false;
+    u.band_off = job->band_need[static_cast<size_t>(u.rank)];
+    job->band_need[static_cast<size_t>(u.rank)] += round256(unit_bytes(u));
+    ist_op hole;
+    std::memset(&hole, 0, sizeof hole);
+    hole.kind = IST_OP_HOLE; hole.image = -1;
+    hole.m[0] = 1.0; hole.m[3] = 1.0;
+    hole.d[0] = u.X0; hole.d[1] = u.Y0; hole.d[2] = u.X1 - u.X0; hole.d[3] = u.Y1 - u.Y0;
+    root_ops.push_back(hole);
   }
   job->root_job = ist_job_create(g->ctx[0], canvas_w, canvas_h, clear, root_ops.data(), static_cast<int>(root_ops.size()), images, n_images, filter, nullptr);
   if (!job->root_job) return nullptr;
-  // host sink: the canvas rows that no band delivers come from the root's launch (the complement of the bands' rows)
+  // host sink: the canvas rows that no unit delivers come from the root's launch (the complement of the units' rows)
   if (job->host_sink_ok) {
     std::vector<std::pair<int64_t, int64_t>> holes;
-    for (const auto& rt : job->parts) if (rt.part.slot != 0) holes.emplace_back(rt.part.Y0, rt.part.Y1);
+    for (const auto& u : job->units) holes.emplace_back(u.Y0, u.Y1);
     std::sort(holes.begin(), holes.end());
     int64_t y = 0;
     for (const auto& h : holes) {
@@ -288,33 +335,39 @@ ist_group_job* ist_group_job_create(ist_group* g, int64_t canvas_w, int64_t canv
     }
     if (y < canvas_h) job->root_rows.emplace_back(y, canvas_h);
   }
-  // the first fill of the list paints the background of every band (index.js:1423-1424)
+  // the first fill of the list paints the background of every per-draw band (index.js:1423-1424)
   int fill_at = -1;
   for (int k = 0; k < n_ops && fill_at < 0; ++k) if (ops[k].kind == IST_OP_FILL) fill_at = k;
-  for (auto& rt : job->parts) {
-    const ist_part& p = rt.part;
-    if (p.slot == 0) continue;
-    ist_op two[2]; int n2 = 0;
-    if (fill_at >= 0 && fill_at < p.op) two[n2++] = ops[fill_at];
-    two[n2++] = ops[p.op];
-    const ist_region clip{p.X0, p.Y0, p.X1 - p.X0, p.Y1 - p.Y0};
-    rt.band_job = ist_job_create(g->ctx[static_cast<size_t>(rt.rank)], canvas_w, canvas_h, clear, two, n2, images, n_images, filter, &clip);
-    if (!rt.band_job) return nullptr;
-    if (rt.local || p.in_place) continue;
+  std::vector<ist_op> band_ops;
+  for (auto& u : job->units) {
+    band_ops.clear();
+    if (by_rows) {                       // the whole op list, minus the draws that do not reach these rows, in canvas order
+      std::vector<char> mine(static_cast<size_t>(n_ops), 0);
+      for (size_t k : u.part_idx) mine[static_cast<size_t>(job->parts[k].part.op)] = 1;
+      for (int k = 0; k < n_ops; ++k) if (ops[k].kind != IST_OP_DRAW || mine[static_cast<size_t>(k)]) band_ops.push_back(ops[k]);
+    } else {
+      const ist_part& p = job->parts[u.part_idx[0]].part;
+      if (fill_at >= 0 && fill_at < p.op) band_ops.push_back(ops[fill_at]);
+      band_ops.push_back(ops[p.op]);
+    }
+    const ist_region clip{u.X0, u.Y0, u.X1 - u.X0, u.Y1 - u.Y0};
+    u.band_job = ist_job_create(g->ctx[static_cast<size_t>(u.rank)], canvas_w, canvas_h, clear, band_ops.data(), static_cast<int>(band_ops.size()), images, n_images, filter, &clip);
+    if (!u.band_job) return nullptr;
+    if (u.local || u.in_place) continue;
     // staged: received into a compact band on the root, then placed by a 1:1 draw clipped to the box
-    rt.staging_off = job->staging_need;
-    job->staging_need += round256(part_bytes(p));
+    u.staging_off = job->staging_need;
+    job->staging_need += round256(unit_bytes(u));
     ist_op put;
     std::memset(&put, 0, sizeof put);
     put.kind = IST_OP_DRAW; put.image = 0;
     put.m[0] = 1.0; put.m[3] = 1.0;
-    put.s[2] = p.X1 - p.X0; put.s[3] = p.Y1 - p.Y0;
-    put.d[0] = p.X0; put.d[1] = p.Y0; put.d[2] = p.X1 - p.X0; put.d[3] = p.Y1 - p.Y0;
+    put.s[2] = u.X1 - u.X0; put.s[3] = u.Y1 - u.Y0;
+    put.d[0] = u.X0; put.d[1] = u.Y0; put.d[2] = u.X1 - u.X0; put.d[3] = u.Y1 - u.Y0;
     ist_image_desc band_desc;
     std::memset(&band_desc, 0, sizeof band_desc);
-    band_desc.width = p.X1 - p.X0; band_desc.height = p.Y1 - p.Y0; band_desc.orientation = 1; band_desc.opaque = 1;
-    rt.place_job = ist_job_create(g->ctx[0], canvas_w, canvas_h, clear, &put, 1, &band_desc, 1, IST_FILTER_NEAREST, &clip);
-    if (!rt.place_job) return nullptr;
+    band_desc.width = u.X1 - u.X0; band_desc.height = u.Y1 - u.Y0; band_desc.orientation = 1; band_desc.opaque = 1;
+    u.place_job = ist_job_create(g->ctx[0], canvas_w, canvas_h, clear, &put, 1, &band_desc, 1, IST_FILTER_NEAREST, &clip);
+    if (!u.place_job) return nullptr;
   }
   return job.release();
 }
@@ -334,20 +387,22 @@ int ist_group_job_parts(const ist_group_job* job, ist_part* parts, int max_parts
 
 namespace {
 
-// one band of a non-root slot into `to` (a compact band, or - biased by the caller - the canvas itself), on its owner's stream
-int launch_band(ist_group_job* job, size_t k, const void* const* src, const size_t* src_pitch, void* to, size_t to_pitch, bool compact) {
-  auto& rt = job->parts[k];
-  const ist_part& p = rt.part;
-  if (!src[k]) return fail(IST_E_DECODE, "图片" + std::to_string(p.image) + "解码异常");
+// one unit of a non-root slot into `to` (a compact band, or - biased by the caller - the canvas itself), on its owner's stream
+int launch_band(ist_group_job* job, size_t ui, const void* const* src, const size_t* src_pitch, void* to, size_t to_pitch, bool compact) {
+  auto& u = job->units[ui];
   const size_t ni = static_cast<size_t>(job->n_images);
   std::vector<const void*> one(ni, nullptr);
   std::vector<size_t> one_pitch(ni, 0);
-  one[static_cast<size_t>(p.image)] = src[k];
-  one_pitch[static_cast<size_t>(p.image)] = src_pitch ? src_pitch[k] : 0;
+  for (size_t k : u.part_idx) {
+    const ist_part& p = job->parts[k].part;
+    if (!src[k]) return fail(IST_E_DECODE, "图片" + std::to_string(p.image) + "解码异常");
+    one[static_cast<size_t>(p.image)] = src[k];
+    one_pitch[static_cast<size_t>(p.image)] = src_pitch ? src_pitch[k] : 0;
+  }
   void* dst = to;
-  if (compact) dst = reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(to) - (static_cast<uintptr_t>(p.Y0) * to_pitch + static_cast<uintptr_t>(p.X0) * 4));
-  return ist_job_launch(rt.band_job, one.data(), src_pitch ? one_pitch.data() : nullptr, job->n_images, dst, to_pitch,
-                        job->g->ctx[static_cast<size_t>(rt.rank)]->stream);
+  if (compact) dst = reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(to) - (static_cast<uintptr_t>(u.Y0) * to_pitch + static_cast<uintptr_t>(u.X0) * 4));
+  return ist_job_launch(u.band_job, one.data(), src_pitch ? one_pitch.data() : nullptr, job->n_images, dst, to_pitch,
+                        job->g->ctx[static_cast<size_t>(u.rank)]->stream);
 }
 
 int launch_root(ist_group_job* job, const void* const* src, const size_t* src_pitch, void* dst, size_t dst_pitch) {
@@ -380,17 +435,16 @@ int group_launch_locked(ist_group_job* job, const void* const* src, const size_t
   ist_group* g = job->g;
   int rc = ensure_arenas(g, job);
   if (rc) return rc;
-  for (const auto& rt : job->parts)
-    if (rt.part.slot != 0 && !rt.local) { rc = ensure_rccl(g); if (rc) return rc; break; }      // before anything is queued
+  for (const auto& u : job->units)
+    if (!u.local) { rc = ensure_rccl(g); if (rc) return rc; break; }      // before anything is queued
   bool any_remote = false;
-  // 1. every band on its owner's stream
-  for (size_t k = 0; k < job->parts.size(); ++k) {
-    auto& rt = job->parts[k];
-    if (rt.part.slot == 0) continue;
-    if (rt.local) rc = launch_band(job, k, src, src_pitch, dst, dst_pitch, false);
+  // 1. every unit on its owner's stream
+  for (size_t k = 0; k < job->units.size(); ++k) {
+    auto& u = job->units[k];
+    if (u.local) rc = launch_band(job, k, src, src_pitch, dst, dst_pitch, false);
     else {
-      rc = launch_band(job, k, src, src_pitch, static_cast<uint8_t*>(g->band_arena[static_cast<size_t>(rt.rank)]) + rt.band_off,
-                       static_cast<size_t>(rt.part.X1 - rt.part.X0) * 4, true);
+      rc = launch_band(job, k, src, src_pitch, static_cast<uint8_t*>(g->band_arena[static_cast<size_t>(u.rank)]) + u.band_off,
+                       static_cast<size_t>(u.X1 - u.X0) * 4, true);
       any_remote = true;
     }
     if (rc) return rc;
@@ -403,24 +457,24 @@ int group_launch_locked(ist_group_job* job, const void* const* src, const size_t
   Rccl* R = rccl();
   int nrc = R->GroupStart();
   if (nrc) return nccl_fail("ncclGroupStart", nrc);
-  for (auto& rt : job->parts) {
-    if (rt.part.slot == 0 || rt.local) continue;
-    const size_t bytes = part_bytes(rt.part);
-    void* into = rt.part.in_place ? static_cast<void*>(static_cast<uint8_t*>(dst) + static_cast<size_t>(rt.part.Y0) * dst_pitch)
-                                  : static_cast<void*>(static_cast<uint8_t*>(g->staging) + rt.staging_off);
-    const void* band = static_cast<const uint8_t*>(g->band_arena[static_cast<size_t>(rt.rank)]) + rt.band_off;
-    nrc = R->Send(band, bytes, kNcclUint8, 0, g->comm[static_cast<size_t>(rt.rank)], g->ctx[static_cast<size_t>(rt.rank)]->stream);
-    if (!nrc) nrc = R->Recv(into, bytes, kNcclUint8, rt.rank, g->comm[0], g->recv_stream);
+  for (auto& u : job->units) {
+    if (u.local) continue;
+    const size_t bytes = unit_bytes(u);
+    void* into = u.in_place ? static_cast<void*>(static_cast<uint8_t*>(dst) + static_cast<size_t>(u.Y0) * dst_pitch)
+                            : static_cast<void*>(static_cast<uint8_t*>(g->staging) + u.staging_off);
+    const void* band = static_cast<const uint8_t*>(g->band_arena[static_cast<size_t>(u.rank)]) + u.band_off;
+    nrc = R->Send(band, bytes, kNcclUint8, 0, g->comm[static_cast<size_t>(u.rank)], g->ctx[static_cast<size_t>(u.rank)]->stream);
+    if (!nrc) nrc = R->Recv(into, bytes, kNcclUint8, u.rank, g->comm[0], g->recv_stream);
     if (nrc) { (void)R->GroupEnd(); return nccl_fail("ncclSend/ncclRecv", nrc); }
   }
   nrc = R->GroupEnd();
   if (nrc) return nccl_fail("ncclGroupEnd", nrc);
   // 4. staged bands: placed behind their receive (same stream)
-  for (auto& rt : job->parts) {
-    if (!rt.place_job) continue;
-    const void* band = static_cast<const uint8_t*>(g->staging) + rt.staging_off;
-    const size_t bp = static_cast<size_t>(rt.part.X1 - rt.part.X0) * 4;
-    rc = ist_job_launch(rt.place_job, &band, &bp, 1, dst, dst_pitch, g->recv_stream);
+  for (auto& u : job->units) {
+    if (!u.place_job) continue;
+    const void* band = static_cast<const uint8_t*>(g->staging) + u.staging_off;
+    const size_t bp = static_cast<size_t>(u.X1 - u.X0) * 4;
+    rc = ist_job_launch(u.place_job, &band, &bp, 1, dst, dst_pitch, g->recv_stream);
     if (rc) return rc;
   }
   return IST_OK;
@@ -568,12 +622,12 @@ int ist_group_stitch_rgba8(ist_group* g, const ist_image_desc* images, const uin
       }
       if (rc2 == IST_OK) { if (!c->stager) c->stager.reset(new Stager(c->device)); rc2 = c->stager->upload(up, c->stream); }
       if (rc2 == IST_OK && host_sink) {
-        for (size_t k = 0; k < job->parts.size() && rc2 == IST_OK; ++k) {
-          const auto& rt = job->parts[k];
-          if (rt.part.slot == 0 || static_cast<size_t>(rt.rank) != r) continue;
-          uint8_t* band = static_cast<uint8_t*>(g->band_arena[r]) + rt.band_off;
+        for (size_t k = 0; k < job->units.size() && rc2 == IST_OK; ++k) {
+          const auto& u = job->units[k];
+          if (static_cast<size_t>(u.rank) != r) continue;
+          uint8_t* band = static_cast<uint8_t*>(g->band_arena[r]) + u.band_off;
           rc2 = launch_band(job, k, psrc.data(), ppitch.data(), band, canvas_pitch, true);
-          if (rc2 == IST_OK && hipMemcpyAsync(host + static_cast<size_t>(rt.part.Y0) * canvas_pitch, band, part_bytes(rt.part), hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+          if (rc2 == IST_OK && hipMemcpyAsync(host + static_cast<size_t>(u.Y0) * canvas_pitch, band, unit_bytes(u), hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
             (void)hipGetLastError();
             rc2 = fail(IST_E_HIP, "band readback failed");
           }
@@ -605,6 +659,7 @@ int ist_group_stitch_rgba8(ist_group* g, const ist_image_desc* images, const uin
   }
   rc = group_sync_locked(g);
   if (rc) return rc;
+  if (host_sink) g_host_sink_stitches.fetch_add(1, std::memory_order_relaxed);
   hg.keep = true;
   *out_pixels = host;
   pg.keep = true;

@@ -6,7 +6,7 @@
 // There is deliberately no CPU fallback: without a HIP device every rendering entry point fails.
 #include <hip/hip_runtime_api.h>
 #include <fcntl.h>
-#include <sys/mman.h>
+#include <cerrno>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -785,9 +785,26 @@ class FileDecoder {
     // bounce buffer - the call's median was the same, 2.35 vs 2.34-2.37 ms, so the simpler path stayed; in 256 KB pieces sent
     // while the rest was still being de-stuffed, half of the calls took 8 ms.)
     if (k < ctx_->scan_bufs.size()) D.G.stream.swap(ctx_->scan_bufs[k]);            // (a recycled block: capacity, no contents)
+    // (IST_TUNING=1 IST_JPEG_SECOND_READ_444=1, tests only: the second read sees the luma sampling factors as 1x1 - what a
+    // caller's buffer rewritten between the two parses would look like)
+    static const bool flip = tuning_mode() && std::getenv("IST_JPEG_SECOND_READ_444") != nullptr;
+    std::vector<uint8_t> flipped;
+    if (flip) {
+      flipped.assign(f, f + len);
+      for (int64_t q = 2; q + 12 < len; ++q) if (flipped[static_cast<size_t>(q)] == 0xFF && flipped[static_cast<size_t>(q) + 1] == 0xC0) { flipped[static_cast<size_t>(q) + 11] = 0x11; break; }
+      f = flipped.data();
+    }
     const int rc = jpeg_parse_and_entropy_decode(f, len, &full, false, gpu_huffman_ ? &D.G : nullptr);
     if (rc) { failed(rc); return; }
-    if (full.width != D.w || full.height != D.h || full.ncomp != D.J.ncomp) { g_last_error = "JPEG frame header changed between two reads"; failed(IST_E_DECODE); return; }
+    // The arena (coefficient + sample planes, layout()) was sized from the header-only parse: every input of that layout must
+    // be the same on this second read, or the Huffman write kernel, the IDCT and the scatter would run past their planes
+    // (4:2:0 turning 4:4:4 doubles blocks_x * blocks_y).  The bytes may be a caller's buffer another thread is still writing.
+    bool same = full.width == D.w && full.height == D.h && full.ncomp == D.J.ncomp && full.hmax == D.J.hmax && full.vmax == D.J.vmax &&
+                full.mcus_x == D.J.mcus_x && full.mcus_y == D.J.mcus_y;
+    for (int c = 0; same && c < full.ncomp; ++c)
+      same = full.comp[c].h == D.J.comp[c].h && full.comp[c].v == D.J.comp[c].v && full.comp[c].blocks_x == D.J.comp[c].blocks_x &&
+             full.comp[c].blocks_y == D.J.comp[c].blocks_y;
+    if (!same) { g_last_error = "JPEG frame header changed between two reads"; failed(IST_E_DECODE); return; }
     D.J = std::move(full);
     if (!D.G.eligible) return;
     const size_t bytes = D.G.stream.size();
@@ -829,6 +846,9 @@ int compile_banded(ist_ctx* ctx, int64_t cw, int64_t ch, const uint8_t clear[4],
   int n_parts = 0;
   if (ist_shard_parts(ops, n_ops, cw, ch, images, n_images, filter, std::max(1, n_images), IST_SPLIT_IMAGE, cut.data(), static_cast<int>(cut.size()), &n_parts) != IST_OK || n_parts < 2)
     return IST_OK;                       // overlapping draws (or a single image): not banded, not an error
+  // the per-band events are the context's per-IMAGE events (ensure_image_lanes): a cut with more parts than images - an image
+  // drawn twice, a draw split in two - is rendered whole instead
+  if (n_parts > n_images) return IST_OK;
   cut.resize(static_cast<size_t>(n_parts));
   std::stable_sort(cut.begin(), cut.end(), [](const ist_part& a, const ist_part& b) { return a.Y0 < b.Y0; });
   std::vector<ist_op> bg_ops;
@@ -856,6 +876,9 @@ int compile_banded(ist_ctx* ctx, int64_t cw, int64_t ch, const uint8_t clear[4],
   out->ok = true;
   return IST_OK;
 }
+
+int stitch_files_png_locked(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images, int direction, int mode,
+                            double gap, const ist_limits* limits, int filter, ist_plan* out_plan, uint8_t** out_png, int64_t* out_len);
 
 }  // namespace
 }  // extern "C++"
@@ -927,8 +950,16 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   if (n_images <= 0) return IST_NOTHING_TO_DO;
   if (!files || !lens) return fail(IST_E_INVALID, "ist_stitch_files_png: NULL input");
   if (n_images > kMaxImages) return fail(IST_E_UNSUPPORTED, "more than 128 images in one launch");
-  const int n = n_images;
   std::lock_guard<std::mutex> lock(ctx->mu);
+  return stitch_files_png_locked(ctx, files, lens, n_images, direction, mode, gap, limits, filter, out_plan, out_png, out_len);
+}
+
+extern "C++" {
+namespace {
+// (the caller holds ctx->mu and has checked the arguments)
+int stitch_files_png_locked(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images, int direction, int mode,
+                            double gap, const ist_limits* limits, int filter, ist_plan* out_plan, uint8_t** out_png, int64_t* out_len) {
+  const int n = n_images;
   DeviceGuard g(ctx->device);
   Phases ph(ctx);
   // (IST_TUNING=1 IST_TIMELINE=1: host-side marks of one call on stderr, microseconds from its start)
@@ -1116,31 +1147,70 @@ int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_
   pg.keep = true;
   return IST_OK;
 }
+}  // namespace
+}  // extern "C++"
 
 int ist_stitch_paths_png(ist_ctx* ctx, const char* const* paths, int n_images, int direction, int mode, double gap, const ist_limits* limits,
                          int filter, ist_plan* out_plan, uint8_t** out_png, int64_t* out_len) {
   if (!ctx) return fail(IST_E_NO_CONTEXT, "无法获取绘图上下文");
+  if (!out_plan || !out_png || !out_len) return fail(IST_E_INVALID, "ist_stitch_paths_png: NULL output");
+  *out_png = nullptr; *out_len = 0;
+  std::memset(out_plan, 0, sizeof(*out_plan));
   if (n_images <= 0) return IST_NOTHING_TO_DO;
   if (!paths) return fail(IST_E_INVALID, "ist_stitch_paths_png: NULL input");
   if (n_images > kMaxImages) return fail(IST_E_UNSUPPORTED, "more than 128 images in one launch");
-  struct Maps {
-    std::vector<const uint8_t*> p; std::vector<int64_t> n;
-    ~Maps() { for (size_t i = 0; i < p.size(); ++i) if (p[i]) (void)munmap(const_cast<uint8_t*>(p[i]), static_cast<size_t>(n[i])); }
-  } m;
-  m.p.assign(static_cast<size_t>(n_images), nullptr); m.n.assign(static_cast<size_t>(n_images), 0);
-  for (int i = 0; i < n_images; ++i) {
-    const int fd = paths[i] ? open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
-    struct stat st;
-    if (fd < 0 || fstat(fd, &st) != 0 || st.st_size <= 0) {
-      if (fd >= 0) (void)close(fd);
-      return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常: " + (fd < 0 ? "cannot open the file" : "empty file"));
+  // The files are READ into blocks the context keeps from call to call (grow-only up to kKeepFileBytes each), one parked
+  // worker per file - not mapped: the decoders parse a file twice (headers for the arena layout, then the scan) and walk it
+  // with plain loads, so a file that another process rewrites or truncates while it is mapped would change under them
+  // (a different layout on the second read) or raise SIGBUS in a worker thread and take the host process down.
+  // A short read - the file shrank between fstat and read - is an error of that image.
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  const size_t n = static_cast<size_t>(n_images);
+  constexpr size_t kKeepFileBytes = size_t{64} << 20;
+  if (ctx->file_bufs.size() < n) ctx->file_bufs.resize(n);
+  std::vector<int> fds(n, -1);
+  std::vector<int64_t> lens(n, 0);
+  std::vector<const uint8_t*> ptr(n, nullptr);
+  std::vector<int> bad(n, 0);                             // 1: out of memory, 2: short read / read error
+  struct Close {
+    std::vector<int>& f; ist_ctx* c; size_t n;
+    ~Close() {
+      for (int d : f) if (d >= 0) (void)close(d);
+      for (size_t i = 0; i < n && i < c->file_bufs.size(); ++i) if (c->file_bufs[i].capacity() > kKeepFileBytes) { ScanBuf none; c->file_bufs[i].swap(none); }
     }
-    void* at = mmap(nullptr, static_cast<size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
-    (void)close(fd);
-    if (at == MAP_FAILED) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常: cannot map the file");
-    m.p[static_cast<size_t>(i)] = static_cast<const uint8_t*>(at); m.n[static_cast<size_t>(i)] = static_cast<int64_t>(st.st_size);
+  } closer{fds, ctx, n};
+  for (size_t i = 0; i < n; ++i) {
+    fds[i] = paths[i] ? open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
+    struct stat st;
+    if (fds[i] < 0 || fstat(fds[i], &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0)
+      return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常: " + (fds[i] < 0 ? "cannot open the file" : "empty file, or not a regular file"));
+    lens[i] = static_cast<int64_t>(st.st_size);
   }
-  return ist_stitch_files_png(ctx, m.p.data(), m.n.data(), n_images, direction, mode, gap, limits, filter, out_plan, out_png, out_len);
+  auto read_one = [&](int k) {
+    const size_t i = static_cast<size_t>(k), want = static_cast<size_t>(lens[i]);
+    ScanBuf& b = ctx->file_bufs[i];
+    if (!b.reserve(want + want / 8 + 64)) { bad[i] = 1; return; }
+    size_t got = 0;
+    while (got < want) {
+      const ssize_t r = pread(fds[i], b.data() + got, want - got, static_cast<off_t>(got));
+      if (r < 0 && errno == EINTR) continue;
+      if (r <= 0) { bad[i] = 2; return; }
+      got += static_cast<size_t>(r);
+    }
+    b.set_size(want);
+    ptr[i] = b.data();
+  };
+  if (n_images == 1) read_one(0);
+  else {
+    if (!ctx->workers) ctx->workers.reset(new WorkerPool());
+    ctx->workers->run(n_images, read_one);
+    ctx->workers->wait();
+  }
+  for (size_t i = 0; i < n; ++i) {
+    if (bad[i] == 1) return fail(IST_E_NOMEM, "out of memory for the bytes of image " + std::to_string(i));
+    if (bad[i]) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常: the file changed while it was read");
+  }
+  return stitch_files_png_locked(ctx, ptr.data(), lens.data(), n_images, direction, mode, gap, limits, filter, out_plan, out_png, out_len);
 }
 
 // PNG of host pixels (H2D, encode, D2H)

@@ -7,6 +7,14 @@
 //   IST_SPLIT_BAND   the draws' canvas rows are dealt out in canvas order so that every slot renders the same number of
 //                    output pixels (9 images over 8 GPUs leave a 2-image straggler otherwise);
 //                    a slot then needs only the source rows its canvas rows sample
+//   IST_SPLIT_ROWS   slot s owns canvas rows [cuts[s], cuts[s+1]) ACROSS ALL DRAWS (ist_shard_row_cuts: equal rows, cuts on
+//                    multiples of 8) and renders the whole op list clipped to them; it holds rows [sy0, sy1) of every image
+//                    its rows sample.  A horizontal strip (index.js:1540-1553: every rect spans the canvas height) or a
+//                    centred 'original' rect is a COLUMN band under the two cuts above - never a contiguous byte range of
+//                    the canvas; under this one every slot's band is full-width whatever the layout: received in place,
+//                    no staging, no placement launch, and a host sink is always possible.  Draws may overlap and edges may
+//                    be anti-aliased: every canvas pixel has one owner, who paints the whole stack there.
+//   IST_SPLIT_AUTO   IMAGE when that cut yields full-width parts only (vertical min / max strips), else ROWS
 // Used by the single-process device group (ist_mgpu.cpp) and, through the C-ABI, by the one-process-per-GPU layout
 // (imagestitching_amd/dist.py), so both cut a job the same way.
 #include <algorithm>
@@ -51,11 +59,25 @@ void tap_range(double k, double o, int lo, int hi, int clo, int chi, int filter,
 
 using namespace ist;
 
+extern "C" int ist_shard_row_cuts(int64_t canvas_h, int n_slots, int32_t* cuts) {
+  if (!cuts || n_slots < 1 || n_slots > 4096 || canvas_h < 1 || canvas_h > 2147483647LL) return fail(IST_E_INVALID, "ist_shard_row_cuts: bad argument");
+  // equal rows per slot, every cut on a multiple of 8 rows (the tile height of the copy path: no tile straddles two owners);
+  // a canvas shorter than 8 * n_slots rows leaves some slots without rows (never the root)
+  cuts[0] = 0;
+  for (int s = 1; s < n_slots; ++s) {
+    int64_t c = (static_cast<__int128>(canvas_h) * s + n_slots - 1) / n_slots;
+    c = (c + 7) & ~7LL;                         // (rounded UP: the root's band is never the empty one)
+    cuts[s] = static_cast<int32_t>(std::min<int64_t>(std::max<int64_t>(c, cuts[s - 1]), canvas_h));
+  }
+  cuts[n_slots] = static_cast<int32_t>(canvas_h);
+  return IST_OK;
+}
+
 extern "C" int ist_shard_parts(const ist_op* ops, int n_ops, int64_t canvas_w, int64_t canvas_h, const ist_image_desc* images,
                                int n_images, int filter, int n_slots, int split, ist_part* parts, int max_parts, int* n_parts) {
   if (!ops || n_ops < 0 || !images || !parts || !n_parts) return fail(IST_E_INVALID, "ist_shard_parts: NULL argument");
   if (n_slots < 1 || n_slots > 4096) return fail(IST_E_INVALID, "ist_shard_parts: bad slot count");
-  if (split != IST_SPLIT_IMAGE && split != IST_SPLIT_BAND) return fail(IST_E_INVALID, "ist_shard_parts: unknown split");
+  if (split != IST_SPLIT_IMAGE && split != IST_SPLIT_BAND && split != IST_SPLIT_ROWS && split != IST_SPLIT_AUTO) return fail(IST_E_INVALID, "ist_shard_parts: unknown split");
   if (canvas_w < 1 || canvas_h < 1 || canvas_w > (1 << 29) || canvas_h > 2147483647LL) return fail(IST_E_OUTPUT_SIZE, "输出尺寸计算失败: canvas size out of range");
   const bool aa = (filter & IST_FILTER_EDGE_AA) != 0;
   const int f = filter & 0xFF;
@@ -77,21 +99,28 @@ extern "C" int ist_shard_parts(const ist_op* ops, int n_ops, int64_t canvas_w, i
     if (rc > 0) continue;                      // draws nothing (clipped away entirely): no part
     draws.push_back(d);
   }
-  // parts must not share canvas pixels: each is rendered by one GPU over the background alone
-  for (size_t a = 0; a < draws.size(); ++a)
+  // parts of the per-draw cuts must not share canvas pixels: each is rendered by one GPU over the background alone
+  bool overlap = false;
+  for (size_t a = 0; a < draws.size() && !overlap; ++a)
     for (size_t b = a + 1; b < draws.size(); ++b) {
       const DevOp& p = draws[a].r; const DevOp& q = draws[b].r;
-      if (p.X0 < q.X1 && q.X0 < p.X1 && p.Y0 < q.Y1 && q.Y0 < p.Y1)
-        return fail(IST_E_UNSUPPORTED, aa ? "edge anti-aliasing blends neighbouring images in one pixel row: stitch on one GPU"
-                                          : "overlapping draws cannot be sharded across GPUs (stitch on one GPU)");
+      if (p.X0 < q.X1 && q.X0 < p.X1 && p.Y0 < q.Y1 && q.Y0 < p.Y1) { overlap = true; break; }
     }
+  if (split == IST_SPLIT_AUTO) {
+    bool full_width = !overlap;
+    for (const Draw& d : draws) full_width = full_width && d.r.X0 == 0 && static_cast<int64_t>(d.r.X1) == canvas_w;
+    split = full_width ? IST_SPLIT_IMAGE : IST_SPLIT_ROWS;
+  }
+  if (overlap && split != IST_SPLIT_ROWS)
+    return fail(IST_E_UNSUPPORTED, aa ? "edge anti-aliasing blends neighbouring images in one pixel row: split by rows (IST_SPLIT_ROWS) or stitch on one GPU"
+                                      : "overlapping draws cannot be sharded draw by draw: split by rows (IST_SPLIT_ROWS) or stitch on one GPU");
   auto emit = [&](const Draw& d, int slot, int Y0, int Y1) -> int {
     if (*n_parts >= max_parts) return fail(IST_E_INVALID, "ist_shard_parts: part table too small");
     ist_part& p = parts[(*n_parts)++];
     std::memset(&p, 0, sizeof p);
     p.image = d.r.image; p.op = d.op; p.slot = slot;
     p.X0 = d.r.X0; p.X1 = d.r.X1; p.Y0 = Y0; p.Y1 = Y1;
-    p.in_place = (p.X0 == 0 && static_cast<int64_t>(p.X1) == canvas_w) ? 1 : 0;
+    p.in_place = (split == IST_SPLIT_ROWS || (p.X0 == 0 && static_cast<int64_t>(p.X1) == canvas_w)) ? 1 : 0;     // (ROWS: the slot's BAND is the unit, always full-width)
     // the source rows / columns this canvas box samples.  Source x is driven by canvas X (or canvas Y after a quarter turn)
     const bool sw = (d.r.flags & OPF_SWAP) != 0;
     int a, b;
@@ -103,6 +132,24 @@ extern "C" int ist_shard_parts(const ist_op* ops, int n_ops, int64_t canvas_w, i
   };
   if (split == IST_SPLIT_IMAGE) {
     for (const Draw& d : draws) { const int rc = emit(d, d.r.image % n_slots, d.r.Y0, d.r.Y1); if (rc) return rc; }
+    return IST_OK;
+  }
+  if (split == IST_SPLIT_ROWS) {
+    // slot by slot, draws in op order: part = (the slot's rows) x (one draw's box).  The unit that is rendered and delivered is
+    // the slot's whole band [0, canvas_w) x [cuts[s], cuts[s+1]) - the parts say which rows of which image the slot must hold.
+    std::vector<int32_t> cuts(static_cast<size_t>(n_slots) + 1);
+    const int rc0 = ist_shard_row_cuts(canvas_h, n_slots, cuts.data());
+    if (rc0) return rc0;
+    for (int s = 0; s < n_slots; ++s) {
+      const int y0 = cuts[static_cast<size_t>(s)], y1 = cuts[static_cast<size_t>(s) + 1];
+      if (y1 <= y0) continue;
+      for (const Draw& d : draws) {
+        const int a = std::max(d.r.Y0, y0), b = std::min(d.r.Y1, y1);
+        if (b <= a) continue;
+        const int rc = emit(d, s, a, b);
+        if (rc) return rc;
+      }
+    }
     return IST_OK;
   }
   // IST_SPLIT_BAND: equal output pixels per slot, dealt in canvas (= op) order.  Cuts fall on multiples of 8 rows inside
@@ -135,4 +182,19 @@ extern "C" int ist_shard_parts(const ist_op* ops, int n_ops, int64_t canvas_w, i
     }
   }
   return IST_OK;
+}
+
+extern "C" int ist_shard_resolve(const ist_op* ops, int n_ops, int64_t canvas_w, int64_t canvas_h, const ist_image_desc* images, int n_images,
+                                 int filter, int split) {
+  if (split == IST_SPLIT_IMAGE || split == IST_SPLIT_BAND || split == IST_SPLIT_ROWS) return split;
+  if (split != IST_SPLIT_AUTO) return fail(IST_E_INVALID, "ist_shard_resolve: unknown split");
+  if (!ops || n_ops < 0 || !images) return fail(IST_E_INVALID, "ist_shard_resolve: NULL argument");
+  // what ist_shard_parts does with IST_SPLIT_AUTO: by image when that yields full-width parts only, else by rows
+  std::vector<ist_part> parts(static_cast<size_t>(std::max(n_ops, 1)));
+  int n = 0;
+  const int rc = ist_shard_parts(ops, n_ops, canvas_w, canvas_h, images, n_images, filter, 1, IST_SPLIT_IMAGE, parts.data(), static_cast<int>(parts.size()), &n);
+  if (rc == IST_E_UNSUPPORTED) return IST_SPLIT_ROWS;          // overlapping draws
+  if (rc != IST_OK) return rc;
+  for (int k = 0; k < n; ++k) if (!parts[static_cast<size_t>(k)].in_place) return IST_SPLIT_ROWS;
+  return IST_SPLIT_IMAGE;
 }

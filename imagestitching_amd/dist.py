@@ -8,6 +8,12 @@ ist_shard_parts (the single-process device group, ist_mgpu_*, cuts the same way)
                  with two)
   split="band"   canvas rows dealt out so that every rank renders the same number of output pixels; a rank then needs
                  only the source rows its rows sample (still disjoint input subsets, up to one shared row at a cut)
+  split="rows"   rank s owns a band of canvas rows ACROSS ALL DRAWS and renders the whole op list clipped to it; it holds
+                 the rows of every image its band samples.  The unit that travels is the band - full canvas width for any
+                 layout, so horizontal strips (index.js:1540-1553) and centred rects are received in place like vertical
+                 ones, need no staging / placement launch, and can use the host sink; overlapping draws and anti-aliased
+                 seams are allowed
+  split="auto"   "image" when its parts are full-width (vertical min / max strips), else "rows" (the default)
 Each rank renders its parts into compact bands; the root assembles the strip:
   * parts that span the full canvas width are contiguous byte ranges of the canvas -> received IN PLACE while the root's
     own launch runs (that launch leaves those rows untouched: op kind HOLE);
@@ -28,7 +34,8 @@ from . import _lib as L
 S = importlib.import_module(".stitch", __package__)   # the package attribute `stitch` is the function, not the module
 
 OP_FILL, OP_DRAW, OP_HOLE = 0, 1, 2
-_SPLITS = {"image": L.SPLIT_IMAGE, "band": L.SPLIT_BAND}
+_SPLITS = {"image": L.SPLIT_IMAGE, "band": L.SPLIT_BAND, "rows": L.SPLIT_ROWS, "auto": L.SPLIT_AUTO}
+_SPLIT_NAMES = {v: k for k, v in _SPLITS.items()}
 
 
 def owner_of(image_index, world):
@@ -56,10 +63,39 @@ class Part:
         return (self.Y1 - self.Y0) * (self.X1 - self.X0) * 4
 
 
+class Band:
+    """split="rows": the band of canvas rows [Y0, Y1) slot `slot` owns, across all draws - what that slot renders into one
+    buffer and delivers in one piece.  Quacks like a Part (index, slot, box, in_place) for run_step / run_step_host_sink."""
+    __slots__ = ("index", "image", "op", "slot", "X0", "Y0", "X1", "Y1", "sy0", "sy1", "in_place", "pieces")
+
+    def __init__(self, index, slot, width, y0, y1, pieces):
+        self.index, self.slot = index, slot
+        self.image, self.op = -1, -1
+        self.X0, self.Y0, self.X1, self.Y1 = 0, y0, width, y1
+        self.sy0 = self.sy1 = 0
+        self.in_place = True
+        self.pieces = pieces                  # the (slot's rows) x (one draw's box) parts: which rows of which image the slot samples
+
+    shape = Part.shape
+    nbytes = Part.nbytes
+
+
+def resolve_split(plan, filter_code, split):
+    """the cut "auto" stands for on this plan (ist_shard_resolve)"""
+    ops, n_ops = plan.ops()
+    return _SPLIT_NAMES[L.check(L.lib.ist_shard_resolve(ops, n_ops, plan.canvas_w, plan.canvas_h, plan._descs, plan.n_images, filter_code, _SPLITS[split]))]
+
+
+def row_cuts(canvas_h, n_slots):
+    arr = (C.c_int32 * (n_slots + 1))()
+    L.check(L.lib.ist_shard_row_cuts(canvas_h, n_slots, arr))
+    return list(arr)
+
+
 def shard_parts(plan, filter_code, n_slots, split):
     """ist_shard_parts through the C-ABI (pure CPU)."""
     ops, n_ops = plan.ops()
-    cap = n_ops + n_slots + 8
+    cap = n_ops * n_slots + 8 if split in ("rows", "auto") else n_ops + n_slots + 8
     arr = (L.Part * cap)()
     cnt = C.c_int(0)
     L.check(L.lib.ist_shard_parts(ops, n_ops, plan.canvas_w, plan.canvas_h, plan._descs, plan.n_images, filter_code,
@@ -70,7 +106,7 @@ def shard_parts(plan, filter_code, n_slots, split):
 class ShardedStitch:
     """One stitch job sharded over `world` ranks.  Construct on every rank with identical arguments."""
 
-    def __init__(self, images, direction, opts=None, rank=0, world=1, root=0, split="image"):
+    def __init__(self, images, direction, opts=None, rank=0, world=1, root=0, split="auto"):
         self.rank, self.world, self.root, self.split = rank, world, root, split
         self.opts = S._merge(opts)
         self.plan = S.plan(images, direction, self.opts)
@@ -79,7 +115,13 @@ class ShardedStitch:
         self.n = len(images)
         self.filter = S._filter_of(self.opts)
         # edge anti-aliasing makes neighbouring draws share a pixel row: ist_shard_parts refuses (IST_E_UNSUPPORTED)
+        self.split = split = resolve_split(self.plan, self.filter, split)
         self.parts = shard_parts(self.plan, self.filter, world, split)
+        self.pieces = self.parts              # the per-draw parts: what rows_needed reads
+        if split == "rows":                   # the units that are rendered and delivered are the slots' bands
+            cuts = row_cuts(self.plan.canvas_h, world)
+            self.parts = [Band(k, s, self.plan.canvas_w, cuts[s], cuts[s + 1], [p for p in self.pieces if p.slot == s])
+                          for k, s in enumerate(s for s in range(world) if cuts[s + 1] > cuts[s])]
         self.slot = (rank - root) % world
         self.mine = [p for p in self.parts if p.slot == self.slot]
         self.remote = [p for p in self.parts if p.slot != 0]
@@ -91,7 +133,7 @@ class ShardedStitch:
         """{image: (first_row, end_row)} of the source rows the slot's parts sample: what that rank must hold."""
         slot = self.slot if slot is None else slot
         need = {}
-        for p in self.parts:
+        for p in self.pieces:
             if p.slot != slot:
                 continue
             a, b = need.get(p.image, (p.sy0, p.sy1))
@@ -116,17 +158,23 @@ class ShardedStitch:
 
     # ---- op lists ------------------------------------------------------------------------------------------------
     def band_ops(self, part):
-        """ops + clip for rendering a part on its owner: white fill + that draw, clipped to the part's box."""
-        ops, _ = self.plan.ops()
+        """ops + clip for rendering a part on its owner: white fill + that draw, clipped to the part's box; a band of the
+        rows split: the whole op list minus the draws that do not reach its rows, clipped to the band."""
+        ops, n_ops = self.plan.ops()
+        clip = (part.X0, part.Y0, part.X1 - part.X0, part.Y1 - part.Y0)
+        if isinstance(part, Band):
+            mine = {q.op for q in part.pieces}
+            sel = [ops[k] for k in range(n_ops) if ops[k].kind != OP_DRAW or k in mine]
+            return (L.Op * len(sel))(*sel), len(sel), clip
         sel = (L.Op * 2)(ops[0], ops[part.op])
-        return sel, 2, (part.X0, part.Y0, part.X1 - part.X0, part.Y1 - part.Y0)
+        return sel, 2, clip
 
     def root_ops(self):
         """ops of the root's own fused launch: the fill, every draw the root owns a part of, and a HOLE over every part
         another rank delivers (listed last: the launch then writes nothing there, whatever lies under it)."""
         ops, n_ops = self.plan.ops()
-        own = sorted({p.op for p in self.parts if p.slot == 0})
-        out = [ops[0]] + [ops[k] for k in own]
+        own = {p.op for p in self.pieces if p.slot == 0}
+        out = [ops[k] for k in range(n_ops) if ops[k].kind != OP_DRAW or k in own]
         for p in self.remote:
             r = L.Op()
             r.kind, r.image = OP_HOLE, -1

@@ -47,10 +47,12 @@ DEFAULT_OPTS = {
     "edgeAA": None,         # anti-alias fractional rectangle edges by area coverage (IST_FILTER_EDGE_AA); None: on iff `platform` is given (edge_aa_of)
     "pngLevel": None,       # PNG export form of the *_png / stitch_files calls: 0 stored, 1 compressed on the GPU; None = DEFAULT_PNG_LEVEL
     "devices": None,        # list of GPU indices (devices[0] = root): shard the stitch over them from this one process (ist_stitch_rgba8_multi)
-    "split": "image",       # with devices: "image" (image i -> devices[i mod n], BASELINE configs[3]) or "band" (equal output rows per device)
+    "split": "auto",        # with devices: "image" (image i -> devices[i mod n], BASELINE configs[3]), "band" (equal output rows per device, cut draw
+                            # by draw), "rows" (device s owns a band of canvas rows across ALL draws: full-width bands for horizontal strips and
+                            # centred rects too, index.js:1540-1553), "auto" = "image" when its parts are full-width (vertical min / max), else "rows"
 }
 
-_SPLITS = {"image": L.SPLIT_IMAGE, "band": L.SPLIT_BAND}
+_SPLITS = {"image": L.SPLIT_IMAGE, "band": L.SPLIT_BAND, "rows": L.SPLIT_ROWS, "auto": L.SPLIT_AUTO}
 
 DEFAULT_PNG_LEVEL = 1
 
@@ -363,8 +365,8 @@ def stitch_files(paths, direction, opts=None, out_path=None, device=0, copy=True
     n = len(paths)
     if n == 0:
         return None
-    # the library maps the files itself (ist_stitch_paths_png): it parses them where the page cache holds them.  (Reading nine
-    # 12 MP JPEGs into Python bytes cost ~1 ms of the call; opening and mapping them from Python still 0.2 ms.)
+    # the library reads the files itself (ist_stitch_paths_png: one parked worker per file, into blocks its context keeps).
+    # (Reading nine 12 MP JPEGs into Python bytes cost ~1 ms of the call; opening and mapping them from Python still 0.2 ms.)
     cpaths = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
     cplan = L.Plan()
     lim = _limits(o)

@@ -137,6 +137,9 @@ IST_API int64_t ist_debug_gpu_entropy_files(void);
 /* images the file pipeline has reconstructed STRAIGHT INTO the canvas so far (a draw that only moves an opaque image: no bitmap of
  * its own, no stitch launch for it).  Tests use it to tell that path from the general one, which makes the same pixels. */
 IST_API int64_t ist_debug_direct_images(void);
+/* diagnostics: ist_group_stitch_rgba8 / ist_stitch_rgba8_multi calls of this process whose result was delivered by the HOST
+ * SINK (every device DMAs its bands into the pinned result; no gather, no root readback) */
+IST_API int64_t ist_debug_host_sink_stitches(void);
 
 /* ---- planner: pure CPU, bit-exact to index.js:1211-1216, 1251-1386, 1432-1433, 1522-1554 -------------------- */
 IST_API void ist_limits_default(int platform, ist_limits* out);        /* index.js:126-156 fallback branch */
@@ -160,8 +163,18 @@ IST_API int ist_op_box(const ist_op* op, int64_t canvas_w, int64_t canvas_h, int
  * order so that every slot renders the same number of output pixels (9 images on 8 GPUs: 1.125 images each); cuts fall
  * on multiples of 8 rows inside a draw's box.  A slot needs only source rows [sy0, sy1) of the part's image (readable
  * for 16 bytes past the last row when a partial buffer is passed, biased by -sy0 rows, to ist_job_launch).
- * Draws that overlap (edge anti-aliasing makes neighbours share a pixel row) cannot be sharded: IST_E_UNSUPPORTED. */
-enum { IST_SPLIT_IMAGE = 0, IST_SPLIT_BAND = 1 };
+ * Draws that overlap (edge anti-aliasing makes neighbours share a pixel row) cannot be sharded draw by draw: IST_E_UNSUPPORTED.
+ * IST_SPLIT_ROWS: slot s owns canvas rows [cuts[s], cuts[s+1]) (ist_shard_row_cuts) ACROSS ALL DRAWS and renders the whole op
+ * list clipped to them.  The unit that is rendered and delivered is the slot's BAND - full canvas width whatever the layout,
+ * so it is a contiguous byte range of the canvas for horizontal strips (index.js:1540-1553: every rect spans the canvas
+ * height, i.e. is a column band under the two cuts above) and centred 'original' rects too: received in place, no staging,
+ * no placement launch, host sink always available; overlapping draws and anti-aliased seams are allowed (one owner per
+ * pixel paints the whole stack).  Its parts are (slot's rows) x (one draw's box), slot by slot in op order, and say which
+ * rows of which image the slot must hold (a horizontal strip on 8 slots: 1/8 of the rows of EVERY image per slot - still
+ * disjoint input subsets); in_place is 1 for all of them (it describes the band).
+ * IST_SPLIT_AUTO: IMAGE when that cut yields full-width parts only (vertical min / max strips: BASELINE configs[3]),
+ * otherwise ROWS; ist_shard_resolve says which. */
+enum { IST_SPLIT_IMAGE = 0, IST_SPLIT_BAND = 1, IST_SPLIT_ROWS = 2, IST_SPLIT_AUTO = 3 };
 typedef struct ist_part {
   int32_t image, op;          /* source image; index of the draw in the op list */
   int32_t slot;               /* owner, 0 .. n_slots-1; slot 0 is the root */
@@ -169,8 +182,15 @@ typedef struct ist_part {
   int32_t sx0, sy0, sx1, sy1; /* source columns / rows the part samples, half open */
   int32_t in_place;           /* the box spans the canvas width: a contiguous byte range of the canvas */
 } ist_part;
+/* max_parts: n_ops + n_slots + 8 suffices for IMAGE / BAND, n_ops * n_slots for ROWS / AUTO */
 IST_API int ist_shard_parts(const ist_op* ops, int n_ops, int64_t canvas_w, int64_t canvas_h, const ist_image_desc* images,
                             int n_images, int filter, int n_slots, int split, ist_part* parts, int max_parts, int* n_parts);
+/* IST_SPLIT_ROWS: cuts[0 .. n_slots] - equal rows per slot, every cut on a multiple of 8 rows, cuts[n_slots] = canvas_h; a
+ * canvas shorter than 8 * n_slots rows leaves some slots empty (cuts[s] == cuts[s+1]; never slot 0) */
+IST_API int ist_shard_row_cuts(int64_t canvas_h, int n_slots, int32_t* cuts);
+/* the split IST_SPLIT_AUTO stands for on this op list (other values are returned unchanged); negative on error */
+IST_API int ist_shard_resolve(const ist_op* ops, int n_ops, int64_t canvas_w, int64_t canvas_h, const ist_image_desc* images,
+                              int n_images, int filter, int split);
 
 /* ---- device path: inputs and output already resident in HBM ------------------------------------------------- */
 IST_API ist_ctx* ist_ctx_create(int device);
@@ -290,15 +310,21 @@ IST_API int ist_ctx_set_timing(ist_ctx* ctx, int on);
 IST_API int ist_ctx_last_timing(ist_ctx* ctx, double* ms, int n);
 
 /* ---- files in, file out: the whole onStitch (decode -> plan -> resample+blit -> PNG export; index.js:1441-1581) ---- */
-/* files[i] = PNG or JPEG file bytes.  Huffman / inflate on host threads (one per image), everything else on the GPU;
- * decoded bitmaps, canvas and PNG stay in HBM - only file bytes go in and PNG bytes come out.  A file that does not
- * decode fails with IST_E_DECODE / IST_E_UNSUPPORTED and the message '图片N解码异常: ...' (index.js:1512-1514). */
+/* files[i] = the bytes of one image file of any type ist_image_info recognises.  Baseline JPEG: container parse + de-stuffing
+ * on a host thread per image, Huffman decoding, reconstruction, stitch and PNG compression on the GPU; progressive JPEG /
+ * PNG / BMP / GIF / WebP: entropy stage on that host thread, the rest on the GPU.  Decoded bitmaps, canvas and PNG stay in
+ * HBM - only file bytes go in and PNG bytes come out.  A file that does not decode fails with IST_E_DECODE /
+ * IST_E_UNSUPPORTED and the message '图片N解码异常: ...' (index.js:1512-1514).
+ * files[i] must not change during the call: a file is parsed twice (frame header for the device layout, then the scan); a
+ * JPEG whose frame layout differs between the two reads fails with IST_E_DECODE instead of overrunning the layout. */
 IST_API int ist_stitch_files_png(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n_images,
                                  int direction, int mode, double gap, const ist_limits* limits, int filter,
                                  ist_plan* out_plan, uint8_t** out_png, int64_t* out_len);
-/* the same from file PATHS (what wx.chooseImage hands the page: tempFilePaths, index.js:1441-1450): the library maps the files
- * read-only for the duration of the call (no copy: the parsers read the page cache).  A path that cannot be opened or is
- * empty fails with IST_E_DECODE and '图片N解码异常: ...'. */
+/* the same from file PATHS (what wx.chooseImage hands the page: tempFilePaths, index.js:1441-1450): the library READS the
+ * files (one parked worker per file) into blocks the context keeps from call to call - it does not map them, so a file that
+ * another process rewrites or truncates meanwhile can neither change under the parsers nor raise SIGBUS in the host
+ * process.  A path that cannot be opened, is not a regular file, is empty, or shrinks while it is read fails with
+ * IST_E_DECODE and '图片N解码异常: ...'. */
 IST_API int ist_stitch_paths_png(ist_ctx* ctx, const char* const* paths, int n_images,
                                  int direction, int mode, double gap, const ist_limits* limits, int filter,
                                  ist_plan* out_plan, uint8_t** out_png, int64_t* out_len);

@@ -8,7 +8,7 @@
  *   plan(images, direction, mode, gap, limits)                         -> plan object        (pure CPU)
  *   stitch(images, direction, mode, gap, limits, filter, asPng?, devices?, split?) -> Promise<{width,height,data}>  (napi_async_work)
  *       devices: number[] (devices[0] = root) shards the stitch over several GPUs from this process (ist_stitch_rgba8_multi:
- *       RCCL gather over xGMI); split 0 = by image (round robin), 1 = by band (equal output rows)
+ *       RCCL gather over xGMI); split 0 = by image (round robin), 1 = by band (equal output rows, draw by draw), 2 = by rows (across all draws), 3 = auto
  *   stitchSync(...same...)                                             -> {width,height,data}
  *   render(canvasW, canvasH, clearRGBA, ops, images, filter, region, asPng?) -> Buffer (region pixels, or the PNG file)
  *   encodePng(data, width, height) -> Buffer;  stitch(..., filter, true) resolves {width,height,png}

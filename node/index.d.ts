@@ -19,7 +19,7 @@ export interface StitchOptions {
   onProgress?: (percent: number) => void;   // stitchProgress checkpoints (index.js:1193-1611)
   pngLevel?: 0 | 1;                         // PNG export form: 0 stored, 1 compressed on the GPU (process-wide once set)
   devices?: number[];                       // GPUs to shard the stitch over from this process; devices[0] is the root (RCCL gather over xGMI)
-  split?: 'image' | 'band';                 // with devices: image i -> devices[i mod n] (default) | equal output rows per GPU
+  split?: 'image' | 'band' | 'rows' | 'auto';   // with devices: image i -> devices[i mod n] | equal output rows per GPU, draw by draw | GPU s owns canvas rows across all draws (horizontal strips: full-width bands) | default 'auto': 'image' when its parts are full-width, else 'rows'
 }
 export interface PlanRect { image: number; orientation: number; dx: number; dy: number; dw: number; dh: number; }
 export interface StitchPlan {

@@ -18,7 +18,9 @@
  *              reference plan has fractional edges as a rule - false otherwise: pixel-centre rule),
  *              devices: number[] - shard the stitch over these GPUs from this one process (devices[0] = root; parts render
  *              on their GPUs, one grouped RCCL send/recv batch over xGMI gathers the bands into the root's canvas),
- *              split: 'image' (image i -> devices[i mod n], the BASELINE layout) | 'band' (equal output rows per GPU)}
+ *              split: 'image' (image i -> devices[i mod n], the BASELINE layout) | 'band' (equal output rows per GPU, cut draw by draw)
+ *                     | 'rows' (GPU s owns a band of canvas rows across ALL draws: full-width bands for horizontal strips too,
+ *                     index.js:1540-1553) | 'auto' (default: 'image' when its parts are full-width, else 'rows')}
  * Errors reject with Error('拼图失败：' + reason) like the reference's catch (index.js:1618-1624); err.code is the
  * C-ABI code.  No pixel arithmetic happens in JavaScript; there is no CPU fallback.
  */
@@ -30,7 +32,7 @@ const MODE = { min: 0, max: 1, original: 2 };
 const FILTER = { nearest: 0, bilinear: 1, area: 2 };
 const PLATFORM = { other: 0, devtools: 0, windows: 0, mac: 0, ios: 1, android: 2 };
 const KNOWN = ['mode', 'gap', 'filter', 'platform', 'maxSide', 'maxPixels', 'superSample', 'onProgress', 'edgeAA', 'pngLevel', 'devices', 'split'];
-const SPLIT = { image: 0, band: 1 };
+const SPLIT = { image: 0, band: 1, rows: 2, auto: 3 };
 const FILTER_EDGE_AA = 0x100;    // IST_FILTER_EDGE_AA: anti-alias fractional rectangle edges by area coverage
 
 function limitsOf(opts) {
@@ -79,7 +81,7 @@ function groupArgs(opts) {
   const o = opts || {};
   if (o.devices === undefined || o.devices === null) return [];
   if (!Array.isArray(o.devices) || !o.devices.length || !o.devices.every((d) => Number.isInteger(d) && d >= 0)) throw new TypeError('devices must be a non-empty array of GPU indices');
-  const split = o.split || 'image';
+  const split = o.split || 'auto';
   if (!(split in SPLIT)) throw new TypeError('unknown split ' + split);
   return [false, o.devices, SPLIT[split]];
 }

@@ -51,7 +51,8 @@ class OracleBackend:
 
     def render_band(self, part, srcs):
         ops, n, clip = self.sh.band_ops(part)
-        full = self.O.render_ops(self.sh.plan.canvas_w, self.sh.plan.canvas_h, self._ops(ops, n), self.descs, self._full(srcs), self.sh.opts["filter"])
+        full = self.O.render_ops(self.sh.plan.canvas_w, self.sh.plan.canvas_h, self._ops(ops, n), self.descs, self._full(srcs), self.sh.opts["filter"],
+                                 edge_aa=U.edge_aa_of(self.sh.opts))
         x, y, w, h = clip
         self.bands[part.index] = torch.from_numpy(np.ascontiguousarray(full[y:y + h, x:x + w]))
         return self.bands[part.index]
@@ -59,7 +60,8 @@ class OracleBackend:
     def render_root(self, srcs, canvas):
         ops, n = self.sh.root_ops()
         lst = self._ops(ops, n)
-        img = self.O.render_ops(self.sh.plan.canvas_w, self.sh.plan.canvas_h, [o for o in lst if o["kind"] != "hole"], self.descs, self._full(srcs), self.sh.opts["filter"])
+        img = self.O.render_ops(self.sh.plan.canvas_w, self.sh.plan.canvas_h, [o for o in lst if o["kind"] != "hole"], self.descs, self._full(srcs), self.sh.opts["filter"],
+                                edge_aa=U.edge_aa_of(self.sh.opts))
         keep = np.ones(img.shape[:2], bool)
         for o in lst:
             if o["kind"] == "hole":
@@ -135,6 +137,7 @@ def test_round_robin_ownership_and_hole_ops():
     from imagestitching_amd import dist as D
     imgs = [{"width": 4032, "height": 3024}] * 9
     sh = D.ShardedStitch(imgs, "vertical", None, 0, 8, 0)
+    assert sh.split == "image"                                 # auto on a vertical min strip = BASELINE configs[3]
     assert [p.image for p in sh.mine] == [0, 8]               # GPU0 holds images 0 and 8
     assert [D.owner_of(i, 8) for i in range(9)] == [0, 1, 2, 3, 4, 5, 6, 7, 0]
     assert [p.slot for p in sh.parts] == [0, 1, 2, 3, 4, 5, 6, 7, 0]
@@ -191,27 +194,31 @@ def test_band_split_of_scaled_draws_names_the_rows_it_samples():
         assert 0 <= p.sy0 < p.sy1 <= imgs[p.image]["height"]
 
 
-def test_overlapping_draws_are_refused():
+def test_overlapping_draws_are_refused_draw_by_draw():
     from imagestitching_amd import dist as D
     import imagestitching_amd as ist
     # the reference's orientation-7 placement draws image k one rect-height ABOVE its rect (utils/canvas.js:187-192):
     # with heights 30, 20, 50 image 2 lands on [0,50) and covers image 1 at [10,30)
     imgs = [{"width": 40, "height": h, "orientation": 7} for h in (30, 20, 50)]
-    with pytest.raises(ist.StitchError):
-        D.ShardedStitch(imgs, "vertical", None, 0, 2, 0)
-    ok = D.ShardedStitch([{"width": 40, "height": 30, "orientation": 7}] * 2, "vertical", None, 0, 2, 0)
+    for split in ("image", "band"):
+        with pytest.raises(ist.StitchError) as e:
+            D.ShardedStitch(imgs, "vertical", None, 0, 2, 0, split=split)
+        assert e.value.code == -7 and "IST_SPLIT_ROWS" in e.value.reason
+    assert D.ShardedStitch(imgs, "vertical", None, 0, 2, 0).split == "rows"       # auto: one owner per pixel paints the whole stack
+    ok = D.ShardedStitch([{"width": 40, "height": 30, "orientation": 7}] * 2, "vertical", None, 0, 2, 0, split="image")
     assert [p.image for p in ok.parts] == [1]                 # image 0 is drawn entirely off-canvas
 
 
-def test_edge_antialiasing_is_refused_because_neighbours_share_a_pixel_row():
-    """with IST_FILTER_EDGE_AA two draws blend into the seam row, so no single GPU owns it"""
+def test_edge_antialiasing_is_refused_draw_by_draw_because_neighbours_share_a_pixel_row():
+    """with IST_FILTER_EDGE_AA two draws blend into the seam row, so no single DRAW's owner owns it"""
     from imagestitching_amd import dist as D
     import imagestitching_amd as ist
     imgs = [{"width": 64, "height": 48}] * 3
     with pytest.raises(ist.StitchError) as e:
-        D.ShardedStitch(imgs, "vertical", {"platform": "ios", "edgeAA": True}, 0, 2, 0)      # superSample 2.2: fractional seams
+        D.ShardedStitch(imgs, "vertical", {"platform": "ios", "edgeAA": True}, 0, 2, 0, split="image")      # superSample 2.2: fractional seams
     assert e.value.code == -7
-    D.ShardedStitch(imgs, "vertical", {"edgeAA": True}, 0, 2, 0)       # integer seams: nothing overlaps, AA or not
+    assert D.ShardedStitch(imgs, "vertical", {"platform": "ios", "edgeAA": True}, 0, 2, 0).split == "rows"   # by rows the seam row has ONE owner
+    assert D.ShardedStitch(imgs, "vertical", {"edgeAA": True}, 0, 2, 0).split == "image"       # integer seams: nothing overlaps, AA or not
 
 
 @pytest.mark.parametrize("world,split", [(3, "image"), (4, "band"), (8, "image"), (8, "band")])
@@ -237,14 +244,14 @@ def test_horizontal_band_split_three_ranks(tmp_path):
     assert np.array_equal(np.load(out), ref)
 
 
-def _sink_worker(rank, world, port, split, opts, out_dir):
+def _sink_worker(rank, world, port, split, opts, out_dir, direction="vertical"):
     """host sink: no exchange; every rank leaves its finished bands in 'host' buffers, the root the rows no band covers"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from imagestitching_amd import dist as D
         pixels = [U.rand_image(200 + i, h, w) for i, (w, h) in enumerate(SIZES)]
-        sh = D.ShardedStitch(U.hip_images(pixels), "vertical", opts, rank, world, 0, split=split)
+        sh = D.ShardedStitch(U.hip_images(pixels), direction, opts, rank, world, 0, split=split)
         assert sh.root_rows() is not None
         be = OracleBackend(sh, pixels)
         srcs = _holdings(sh, pixels, sh.slot)
@@ -281,5 +288,113 @@ def test_host_sink_needs_no_exchange(world, split, tmp_path):
     assert (covered == 1).all()
     ref, _, _ = U.oracle_stitch(pixels, "vertical", opts)
     assert np.array_equal(got, ref)
-    # a horizontal strip has no full-width bands: the gather stays
+    # cut draw by draw a horizontal strip has no full-width bands (the gather stays); cut by rows - the default - it has
     assert D.ShardedStitch(U.hip_images(pixels), "horizontal", opts, 0, world, 0, split=split).root_rows() is None
+    assert D.ShardedStitch(U.hip_images(pixels), "horizontal", opts, 0, world, 0).root_rows() is not None
+
+
+# ---------------------------------------------------------------------------------------------------- split = "rows"
+ROWS_CASES = [
+    ("horizontal", {"filter": "bilinear", "mode": "min", "gap": 3}),
+    ("horizontal", {"filter": "bilinear", "mode": "max", "gap": 0}),
+    ("horizontal", {"filter": "nearest", "mode": "original", "gap": 5}),
+    ("vertical", {"filter": "bilinear", "mode": "original", "gap": 4}),        # centred rects
+]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("direction,opts", ROWS_CASES)
+def test_rows_split_horizontal_and_centred_strips_are_received_in_place(world, direction, opts, tmp_path):
+    """VERDICT r03 item 2 (index.js:1540-1553: every rect of a horizontal strip spans the canvas height): cut by ROWS, slot s
+    owns canvas rows [cuts[s], cuts[s+1]) across all draws, so every band is full-width - received in place, nothing staged,
+    nothing placed - and every rank holds only the rows of every image its band samples (the oracle backend poisons the rest).
+    Bit-identical to the single-process stitch; "auto" picks this cut for these layouts."""
+    from imagestitching_amd import dist as D
+    pixels = [U.rand_image(200 + i, h, w) for i, (w, h) in enumerate(SIZES)]
+    sh = D.ShardedStitch(U.hip_images(pixels), direction, opts, 0, world, 0)
+    assert sh.split == "rows"
+    assert all(p.in_place and p.X0 == 0 and p.X1 == sh.plan.canvas_w for p in sh.parts)
+    cuts = D.row_cuts(sh.plan.canvas_h, world)
+    assert cuts[0] == 0 and cuts[-1] == sh.plan.canvas_h and all(c % 8 == 0 for c in cuts[1:-1]) and cuts == sorted(cuts)
+    assert [(p.Y0, p.Y1) for p in sh.parts] == [(a, b) for a, b in zip(cuts, cuts[1:]) if b > a]
+    assert sh.root_rows() == [(0, cuts[1])]                          # host sink: the root delivers its own band, nothing else
+    out = str(tmp_path / "canvas.npy")
+    mp.spawn(_worker, args=(world, _free_port(), direction, opts, "auto", out), nprocs=world, join=True)
+    ref, _, _ = U.oracle_stitch(pixels, direction, opts)
+    assert np.array_equal(np.load(out), ref)
+
+
+def test_rows_split_of_baseline_configs2_deals_an_eighth_of_every_image_to_every_gpu():
+    """BASELINE configs[2] (9 x 4032x3024 horizontal -> 36288x3024) on 8 GPUs: every slot renders 378 canvas rows of all nine
+    images and holds those 378 (+ the bilinear tap rows at its cuts) rows of each - disjoint input subsets; every band is a
+    contiguous 54.9 MB range of the canvas."""
+    from imagestitching_amd import dist as D
+    imgs = [{"width": 4032, "height": 3024}] * 9
+    sh = D.ShardedStitch(imgs, "horizontal", None, 0, 8, 0)
+    assert sh.split == "rows" and len(sh.parts) == 8 and len(sh.pieces) == 72
+    assert [p.Y1 - p.Y0 for p in sh.parts] == [384, 376, 376, 376, 384, 376, 376, 376]
+    assert all(p.nbytes == (p.Y1 - p.Y0) * 36288 * 4 for p in sh.parts)
+    for slot in range(8):
+        need = sh.rows_needed(slot)
+        assert sorted(need) == list(range(9))
+        b = sh.parts[slot]
+        for a0, a1 in need.values():
+            assert a0 == b.Y0 and b.Y1 <= a1 <= min(b.Y1 + 1, 3024)   # 1:1 draws: the band's rows (+ the second bilinear tap's row, weight 0)
+    assert D.ShardedStitch(imgs, "vertical", None, 0, 8, 0, split="rows").root_rows() == [(0, 3408)]
+
+
+def test_rows_split_allows_overlapping_draws_and_antialiased_seams(tmp_path):
+    """what the per-draw cuts refuse: the reference's orientation-7 placement (utils/canvas.js:187-192: image k lands one
+    rect-height above its rect, so draws overlap) and the iOS plan's fractional seams with edge anti-aliasing
+    (index.js:1363, 1426-1428).  By rows every canvas pixel has one owner who paints the whole stack there."""
+    from imagestitching_amd import dist as D
+    sizes = [(40, 30), (40, 20), (40, 50)]
+    pixels = [U.rand_image(300 + i, h, w) for i, (w, h) in enumerate(sizes)]
+    for case, (imgs, opts, orient) in enumerate([
+            (U.hip_images(pixels, orientations=[7, 7, 7]), {"filter": "nearest"}, [7, 7, 7]),
+            (U.hip_images(pixels), {"platform": "ios", "edgeAA": True, "filter": "bilinear"}, None)]):
+        out = str(tmp_path / ("c%d.npy" % case))
+        mp.spawn(_rows_worker, args=(3, _free_port(), sizes, orient, opts, out), nprocs=3, join=True)
+        ref, _, _ = U.oracle_stitch(pixels, "vertical", opts, orientations=orient)
+        assert np.array_equal(np.load(out), ref), case
+
+
+def _rows_worker(rank, world, port, sizes, orient, opts, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from imagestitching_amd import dist as D
+        pixels = [U.rand_image(300 + i, h, w) for i, (w, h) in enumerate(sizes)]
+        sh = D.ShardedStitch(U.hip_images(pixels, orientations=orient), "vertical", opts, rank, world, 0)
+        assert sh.split == "rows"
+        be = OracleBackend(sh, pixels)
+        be.descs = [{"width": a.shape[1], "height": a.shape[0], "orientation": (orient[i] if orient else 1)} for i, a in enumerate(pixels)]
+        srcs = _holdings(sh, pixels, sh.slot)
+        canvas = be.new_canvas() if rank == 0 else None
+        D.run_step(sh, be, srcs, canvas, dist)
+        dist.barrier()
+        if rank == 0:
+            np.save(out_path, canvas.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_host_sink_of_a_horizontal_strip_by_rows(world, tmp_path):
+    """configs[2]'s geometry with a host-destined result: every rank delivers its band of the HORIZONTAL strip into its byte
+    range of the host canvas - no gather, no 439 MB readback over the root's one link"""
+    from imagestitching_amd import dist as D
+    pixels = [U.rand_image(200 + i, h, w) for i, (w, h) in enumerate(SIZES)]
+    opts = {"filter": "bilinear", "mode": "min", "gap": 2}
+    mp.spawn(_sink_worker, args=(world, _free_port(), "rows", opts, str(tmp_path), "horizontal"), nprocs=world, join=True)
+    sh = D.ShardedStitch(U.hip_images(pixels), "horizontal", opts, 0, world, 0, split="rows")
+    got = np.load(str(tmp_path / "root.npy"))
+    covered = np.zeros(got.shape[0], np.int32)
+    for a, b in sh.root_rows():
+        covered[a:b] += 1
+    for p in sh.remote:
+        got[p.Y0:p.Y1] = np.load(str(tmp_path / ("band%d.npy" % p.index)))
+        covered[p.Y0:p.Y1] += 1
+    assert (covered == 1).all()
+    ref, _, _ = U.oracle_stitch(pixels, "horizontal", opts)
+    assert np.array_equal(got, ref)

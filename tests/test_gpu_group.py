@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 SIZES = [(403, 302), (302, 403), (400, 300), (192, 108), (640, 480)]
 
 
-@pytest.mark.parametrize("devices,split", [([0], "image"), ([0, 0], "image"), ([0, 0], "band"), ([0, 0, 0, 0, 0], "band"), ([0] * 8, "image")])
+@pytest.mark.parametrize("devices,split", [([0], "image"), ([0, 0], "image"), ([0, 0], "band"), ([0, 0, 0, 0, 0], "band"), ([0] * 8, "image"),
+                                           ([0, 0, 0], "rows"), ([0] * 8, "rows"), ([0] * 8, "auto")])
 @pytest.mark.parametrize("direction,opts", [
     ("vertical", {"filter": "bilinear", "mode": "max", "gap": 3}),
     ("horizontal", {"filter": "nearest", "mode": "min", "gap": 0}),
@@ -65,8 +66,9 @@ def test_full_size_nine_photos_on_eight_slots_of_one_gpu():
     g = ist.StitchGroup([0] * 8)
     imgs = [{"width": 4032, "height": 3024, "opaque": True}] * 9
     for direction, dim in (("vertical", 0), ("horizontal", 1)):
-        for split in ("image", "band"):
+        for split in ("image", "band", "rows"):
             job = g.compile(imgs, direction, {"filter": "bilinear", "split": split})
+            assert len(job.parts) == (72 if (split, direction) == ("rows", "horizontal") else 16 if split == "rows" else len(job.parts))
             out = torch.full((job.plan.canvas_h, job.plan.canvas_w, 4), 0x5A, dtype=torch.uint8, device="cuda")
             job.launch([srcs[p["image"]] for p in job.parts], out)
             g.sync()
@@ -84,13 +86,21 @@ def test_bad_device_lists_are_refused():
         ist.stitch(px, "vertical", {"devices": [0, 4096]})
 
 
-def test_edge_antialiased_plans_are_refused_by_a_group_and_fine_on_one_device():
+def test_edge_antialiased_and_overlapping_plans_shard_by_rows_only():
+    """fractional seams with edge anti-aliasing (the iOS plan) and the reference's orientation-7 placement (overlapping draws,
+    utils/canvas.js:187-192) are refused draw by draw (no single draw's owner owns the seam row) and are bit-identical to the
+    one-device result by rows - what "auto", the default, picks for them"""
     px = [U.rand_image(840 + i, 48, 64) for i in range(3)]
-    opts = {"platform": "ios", "edgeAA": True}                  # superSample 2.2: fractional seams
-    ist.stitch(px, "vertical", opts)
-    with pytest.raises(ist.StitchError) as e:
-        ist.stitch(px, "vertical", dict(opts, devices=[0, 0]))
-    assert e.value.code == -7
+    for opts, orient in (({"platform": "ios", "edgeAA": True}, None), ({"filter": "nearest"}, [7, 7, 7]), ({"filter": "bilinear", "gap": 3}, [7, 5, 7])):
+        imgs = U.hip_images(px, orientations=orient)
+        one = ist.stitch(imgs, "vertical", opts)
+        for split in ("image", "band"):
+            with pytest.raises(ist.StitchError) as e:
+                ist.stitch(imgs, "vertical", dict(opts, devices=[0, 0], split=split))
+            assert e.value.code == -7
+        for devices in ([0, 0], [0] * 5):
+            many = ist.stitch(imgs, "vertical", dict(opts, devices=devices))
+            assert np.array_equal(many["data"], one["data"]), (opts, devices)
 
 
 def test_rccl_binding_through_self_send():
@@ -106,7 +116,7 @@ import imagestitching_amd as ist
 from tests import util as U
 px = [U.rand_image(850 + i, h, w) for i, (w, h) in enumerate(%r)]
 for direction in ("vertical", "horizontal"):
-    for split in ("image", "band"):
+    for split in ("image", "band", "rows"):
         opts = {"filter": "bilinear", "mode": "max", "gap": 2}
         one = ist.stitch(px, direction, opts)
         many = ist.stitch(px, direction, dict(opts, devices=[0, 0, 0], split=split))
@@ -123,15 +133,58 @@ def test_host_sink_every_band_is_read_back_by_its_own_device():
     full-width bands compactly and DMAs each one straight into its byte range of the pinned result; the root's launch delivers
     only the rows no band covers (gaps, the last gap after the strip).  BASELINE configs[3] geometry on eight slots of one
     GPU must be bit-identical to the one-device result, both splits; a horizontal strip falls back to gather + readback."""
+    from imagestitching_amd import _lib as L
     px = [U.rand_image(870 + i, 302, 403) for i in range(9)]
     for opts in ({"filter": "bilinear"}, {"filter": "bilinear", "gap": 7}, {"filter": "nearest", "mode": "max", "gap": 2}):
         one = ist.stitch(px, "vertical", opts)
         for split in ("image", "band"):
             many = ist.stitch(px, "vertical", dict(opts, devices=[0] * 8, split=split))
             assert np.array_equal(many["data"], one["data"]), (opts, split)
-    one = ist.stitch(px, "horizontal", {"filter": "bilinear"})
-    many = ist.stitch(px, "horizontal", {"filter": "bilinear", "devices": [0] * 8})
-    assert np.array_equal(many["data"], one["data"])
+    # a horizontal strip (configs[2]'s geometry; index.js:1540-1553): cut draw by draw it has no full-width band and falls back to
+    # gather + readback; cut by rows - the default - every slot's band is a byte range of the result (host sink)
+    for opts in ({"filter": "bilinear"}, {"filter": "bilinear", "gap": 5, "mode": "max"}, {"filter": "nearest", "mode": "original", "gap": 3}):
+        one = ist.stitch(px[:5] + [U.rand_image(899, 200, 333)], "horizontal", opts)
+        for split in ("image", "rows", "auto"):
+            before = L.lib.ist_debug_host_sink_stitches()
+            many = ist.stitch(px[:5] + [U.rand_image(899, 200, 333)], "horizontal", dict(opts, devices=[0] * 8, split=split))
+            assert np.array_equal(many["data"], one["data"]), (opts, split)
+            assert L.lib.ist_debug_host_sink_stitches() - before == (0 if split == "image" else 1)      # host_sink_ok for configs[2]'s geometry
+
+
+def test_without_rccl_the_host_sink_still_works_and_the_gather_fails_cleanly():
+    """ist_group_create no longer touches RCCL; a host where librccl cannot be loaded sees the error at the
+    first launch that has to gather between DISTINCT devices - never on the host-sink path, which exchanges nothing.  On one
+    GPU the only gather is the tuning-mode self-send; IST_RCCL_UNAVAILABLE=1 makes the loader fail as on such a host: the
+    stitch fails with IST_E_NO_DEVICE naming RCCL, and the group stays usable."""
+    code = """
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import imagestitching_amd as ist
+from tests import util as U
+px = [U.rand_image(860 + i, h, w) for i, (w, h) in enumerate(%r)]
+try:
+    ist.stitch(px, "vertical", {"devices": [0, 0, 0]})
+    print("no failure")
+except ist.StitchError as e:
+    assert e.code == -5 and "RCCL" in e.reason, (e.code, e.reason)
+    print("failed cleanly")
+g = ist.StitchGroup([0, 0])
+try:
+    job = g.compile(U.hip_images(px), "horizontal", {})
+    print("compiled", len(job.parts))
+finally:
+    g.close()
+print("usable")
+""" % (U.ROOT, SIZES)
+    env = dict(os.environ, IST_TUNING="1", IST_GROUP_SELF_SEND="1", IST_RCCL_UNAVAILABLE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "failed cleanly" in r.stdout and "usable" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    # the same process without the self-send knob: host sink on a device list, no RCCL anywhere
+    code2 = code.replace('print("no failure")', 'print("host sink ok")')
+    env2 = dict(os.environ, IST_TUNING="1", IST_RCCL_UNAVAILABLE="1")
+    r = subprocess.run([sys.executable, "-c", code2], env=env2, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "host sink ok" in r.stdout and "usable" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_no_device_allocation_after_the_first_call():

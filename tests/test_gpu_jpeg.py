@@ -198,7 +198,7 @@ def test_gpu_entropy_decoder_restart_intervals_full_size_and_too_many(tmp_path):
 
 
 def test_stitch_files_names_the_file_it_cannot_open(tmp_path):
-    """ist_stitch_paths_png maps the files itself: a missing or empty one fails the call like a file that does not decode -
+    """ist_stitch_paths_png reads the files itself: a missing or empty one fails the call like a file that does not decode -
     the reference's message with the image's index (index.js:1512-1514)."""
     good = tmp_path / "good.jpg"
     good.write_bytes(_jpeg(_photo(1, 40, 56), quality=80))
@@ -209,6 +209,61 @@ def test_stitch_files_names_the_file_it_cannot_open(tmp_path):
         assert "图片1解码异常" in str(e.value) and what in str(e.value)
     res = ist.stitch_files([str(good), str(good)], "vertical", {"filter": "nearest"})
     assert res["height"] == 80 and res["width"] == 56
+
+
+def test_paths_are_read_not_mapped_and_a_rewritten_file_is_the_new_file(tmp_path):
+    """ist_stitch_paths_png reads every file into a block its context keeps from call to call.  A path
+    rewritten between calls (larger, smaller, other sampling, another type) gives the new file's pixels - nothing of the
+    block's earlier contents; a directory is refused like a file that cannot be read."""
+    p, q = tmp_path / "a.jpg", tmp_path / "b.jpg"
+    q.write_bytes(_jpeg(_photo(31, 64, 96), quality=85, subsampling=2))
+    versions = [_jpeg(_photo(32, 200, 96), quality=95, subsampling=0), _jpeg(_photo(33, 24, 96), quality=40, subsampling=2),
+                _jpeg(_photo(34, 120, 96), quality=80, subsampling=1, restart_marker_rows=1)]
+    b = io.BytesIO()
+    Image.fromarray(_photo(35, 50, 96)).save(b, "PNG")
+    versions.append(b.getvalue())
+    for data in versions:
+        p.write_bytes(data)
+        res = ist.stitch_files([str(p), str(q)], "vertical", {"filter": "nearest"})
+        want = np.concatenate([_pil(data), _pil(q.read_bytes())], 0)
+        assert np.array_equal(ist.decode_png(res["png"]), want)
+    with pytest.raises(ist.StitchError) as e:
+        ist.stitch_files([str(q), str(tmp_path)], "vertical")
+    assert "图片1解码异常" in str(e.value)
+
+
+def test_a_frame_layout_that_differs_on_the_second_read_is_refused():
+    """the device arena is sized from the header-only parse; the worker's second parse must see the same
+    sampling factors and block counts, or the Huffman write kernel / IDCT would run past the planes (4:2:0 -> 4:4:4 doubles
+    the chroma blocks).  IST_TUNING=1 IST_JPEG_SECOND_READ_444=1 shows the second read other luma sampling factors."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import sys, io
+sys.path.insert(0, %r)
+import numpy as np
+from PIL import Image
+import imagestitching_amd as ist
+a = (np.add.outer(np.arange(160), np.arange(240))[..., None] * np.array([1, 2, 3]) %% 256).astype(np.uint8)
+b = io.BytesIO(); Image.fromarray(a).save(b, "JPEG", quality=85, subsampling=2)
+open(sys.argv[1], "wb").write(b.getvalue())
+try:
+    ist.stitch_files([sys.argv[1]], "vertical")
+    print("accepted")
+except ist.StitchError as e:
+    print("refused:", e)
+b = io.BytesIO(); Image.fromarray(a).save(b, "JPEG", quality=85, subsampling=0)      # already 4:4:4: the flip changes nothing
+open(sys.argv[1], "wb").write(b.getvalue())
+res = ist.stitch_files([sys.argv[1]], "vertical")
+assert np.array_equal(ist.decode_png(res["png"]), np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGBA")))
+print("444 ok")
+""" % (U.ROOT,)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, IST_TUNING="1", IST_JPEG_SECOND_READ_444="1")
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(d, "x.jpg")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "refused:" in r.stdout and "changed between two reads" in r.stdout and "444 ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_more_restart_intervals_than_a_batch_holds(tmp_path):
