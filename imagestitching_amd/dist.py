@@ -276,6 +276,22 @@ class HipBackend:
         self.place_jobs[part.index].launch_ptrs([band.data_ptr()], [band.stride(0)], canvas.data_ptr(), canvas.stride(0), self._stream())
 
 
+class HostRows:
+    """The root's share of a host-destined canvas for run_step_host_sink: one pinned buffer per row range of sh.root_rows()
+    instead of a whole host canvas (the 64 x 48 MP canvas of BASELINE configs[4] is 12.3 GB; the root delivers 1/8 of it).
+    Indexed like the full canvas: rows[a:b] for exactly the ranges of sh.root_rows()."""
+
+    def __init__(self, torch, sh, pin=True):
+        w = sh.plan.canvas_w
+        self.rows = {}
+        for a, b in sh.root_rows():
+            t = torch.empty((b - a, w, 4), dtype=torch.uint8)
+            self.rows[(a, b)] = t.pin_memory() if pin else t
+
+    def __getitem__(self, sl):
+        return self.rows[(sl.start, sl.stop)]
+
+
 def run_step_host_sink(sh, backend, srcs, canvas, host_bands, host_canvas):
     """One sharded stitch whose result is HOST-destined: no exchange at all.  Every rank renders its parts and copies each
     finished band into `host_bands[part.index]` (pinned; in a deployment: the part's byte range of one shared pinned canvas);

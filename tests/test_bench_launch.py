@@ -12,6 +12,15 @@ from tests import util as U
 BENCH = os.path.join(U.ROOT, "bench.py")
 
 
+def _bench_free_port():
+    """a port nobody holds right now (a hard-coded port fails when another run or a TIME_WAIT socket has it)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ist_bench_for_port", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.free_port()
+
+
 def _clean_env():
     return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "IST_BENCH_CHILD")}
 
@@ -31,18 +40,42 @@ def test_plain_invocation_starts_the_ranks_itself():
     seen = line["extra"]["ranks_seen"]
     assert sorted(s["rank"] for s in seen) == [0, 1]
     assert len({s["pid"] for s in seen}) == 2                 # two processes, not one rank counted twice
-    assert line["extra"]["strip_assembled"] is True           # both splits: every part landed where the plan puts it
+    assert line["extra"]["strip_assembled"] is True           # every cut: every part landed where the plan puts it
     assert "started 2 rank processes" in line["extra"]["launcher"]
+    _check_scaling_keys(line)
+
+
+def _check_scaling_keys(line):
+    """the N > 1 line carries, per region, the N-rank time AND the one-GPU form of the same region timed by
+    rank 0 alone in the same process; BASELINE configs[4] (64 images) has its own legs; configs[2]'s horizontal strip is cut by
+    rows (full-width bands: nothing staged, host sink available)"""
+    ex = line["extra"]
+    assert {"resident/image", "resident/band", "resident/rows_horizontal"} <= set(ex["regions"])
+    h = ex["regions"]["resident/rows_horizontal"]
+    assert h["split"] == "rows" and h["bands_staged"] == 0 and h["host_sink_available"] is True
+    assert ex["regions"]["resident/image"]["split"] == "image"
+    for name in ("resident/image", "resident/band", "resident/rows_horizontal"):
+        sc = ex["scaling"][name]
+        assert set(sc) == {"ms_1gpu", "ms_Ngpu", "speedup"} and sc["ms_1gpu"] > 0 and sc["ms_Ngpu"] > 0
+        assert abs(sc["speedup"] - sc["ms_1gpu"] / sc["ms_Ngpu"]) < 0.01 * max(1.0, sc["speedup"])
+    assert ex["scaling"]["resident/image"]["ms_Ngpu"] == ex["regions"]["resident/image"]["ms_per_step"]
+    assert ex["scaling"]["resident/image"]["ms_1gpu"] == ex["one_gpu_same_lease"]["vertical"]["resident"]["ms_per_step"]
+    rank0 = [s["pid"] for s in ex["ranks_seen"] if s["rank"] == 0]
+    assert ex["one_gpu_same_lease"]["timed_by_pids"] == rank0          # the comparators come from rank 0's own process
+    c5 = ex["config5"]
+    assert "resident/image" in c5["regions"] and "resident" in c5["one_gpu"] and set(c5["scaling"]["resident/image"]) == {"ms_1gpu", "ms_Ngpu", "speedup"}
+    assert "host_in_host_out/band" in line["config"]["timed_region"] and "CANNOT scale" in line["config"]["timed_region"]
 
 
 def test_under_torchrun_the_existing_ranks_are_used():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-                        "--master-port", "29683", BENCH, "--gpus", "3", "--dry-launch", "--steps", "2", "--warmup", "1"], env=_clean_env(),
+                        "--master-port", str(_bench_free_port()), BENCH, "--gpus", "3", "--dry-launch", "--steps", "2", "--warmup", "1"], env=_clean_env(),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     line = _line(r.stdout)
     assert line["n_gpus"] == 3 and len({s["pid"] for s in line["extra"]["ranks_seen"]}) == 3
     assert "launcher" not in line["extra"]
+    _check_scaling_keys(line)
 
 
 def test_a_rank_count_that_does_not_match_gpus_is_refused():

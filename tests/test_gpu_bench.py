@@ -38,3 +38,66 @@ def test_single_process_group_leg_on_one_device():
     assert leg["devices"] == [0] and leg["checked"] is True
     for key in ("resident/image", "resident/band", "host_in_host_out/image", "host_in_host_out/band"):
         assert leg["regions"][key]["MPs"] > 0
+    assert leg["checked_horizontal"] is True
+    h = leg["regions"]["host_in_host_out/rows_horizontal"]
+    assert h["MPs"] > 0 and "error" not in h
+    c5 = leg["config5"]                                   # BASELINE configs[4] through the group, on the devices that exist
+    assert "error" not in c5
+    if "skipped" not in c5:
+        assert c5["resident/image"]["checked"] is True and c5["host_in_host_out/image"]["checked"] is True
+
+
+def _errors(node, path=""):
+    """every {"error": ...} object below `node` (bench.py swallows an informational leg's exception into one)"""
+    found = []
+    if isinstance(node, dict):
+        if "error" in node:
+            found.append((path, node["error"]))
+        for k, v in node.items():
+            found += _errors(v, path + "/" + str(k))
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            found += _errors(v, path + "/" + str(i))
+    return found
+
+
+def test_no_informational_leg_of_the_full_line_failed():
+    """the informational legs catch their exceptions so that the headline survives; here the FULL line (no
+    --kernels-only) runs once and none of them may have failed; the file pipeline reports its four stages with their bounds; the
+    BASELINE configs[4] leg ran at its own size and made the strip."""
+    line = _run(["--no-cpu", "--steps", "20", "--warmup", "2"], timeout=1500)
+    assert _errors(line) == []
+    ex = line["extra"]
+    for key in ("uniform_vertical", "uniform_horizontal", "mixed_vertical", "mixed_horizontal", "regions", "end_to_end_host_path", "file_pipeline", "config5_single_gpu"):
+        assert key in ex, key
+    assert set(ex["file_pipeline"]["stage_rooflines"]) == {"entropy_gpu", "reconstruct", "stitch", "png"}
+    for st in ex["file_pipeline"]["stage_rooflines"].values():
+        assert st["bound_ms"] > 0 and st["achieved_ms"] > 0 and 0 < st["frac"] <= 1.5
+    c5 = ex["config5_single_gpu"]
+    assert "skipped" not in c5 and c5["canvas"] == [8000, 384000] and c5["strip_is_the_images_in_order"] is True
+    assert c5["algorithmic_bytes"] == 2 * 64 * 8000 * 6000 * 4 and 0.3 < c5["frac"] <= 1.0
+    assert set(ex["regions"]) >= {"resident", "from_pinned_host", "host_in_host_out", "from_jpeg"}
+    assert line["d2d_copy_yardstick"]["GBs"] > 0
+
+
+def test_the_sharded_line_on_a_world_of_one():
+    """the N > 1 code path (run_sharded: regions, same-lease one-GPU comparators, configs[4] legs, horizontal strip by rows) with
+    WORLD_SIZE = 1 on the GPU that exists - everything but the cross-device transfer"""
+    env = dict(os.environ, IST_BENCH_FORCE_SHARDED="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29671")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "20", "--warmup", "2", "--no-cpu", "--kernels-only"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert _errors(line) == []
+    ex = line["extra"]
+    want = {"resident/image", "from_pinned_host/image", "host_in_host_out/image", "from_jpeg/image", "resident/band", "from_pinned_host/band", "host_in_host_out/band",
+            "resident/rows_horizontal", "host_in_host_out/rows_horizontal"}
+    assert want <= set(ex["regions"]) and want <= set(ex["scaling"])
+    for sc in ex["scaling"].values():
+        assert sc["ms_1gpu"] > 0 and sc["ms_Ngpu"] > 0 and 0.5 < sc["speedup"] < 2.0        # one rank against itself
+    assert ex["gather"]["rows_horizontal"]["split"] == "rows" and ex["gather"]["rows_horizontal"]["host_sink_available"] is True
+    c5 = ex["config5"]
+    assert "skipped" not in c5 and {"resident/image", "host_in_host_out/image"} <= set(c5["regions"]) <= set(c5["scaling"]) | set(c5["regions"])
+    assert set(c5["scaling"]) == {"resident/image", "host_in_host_out/image"}
+    assert "CANNOT scale" in line["config"]["timed_region"]

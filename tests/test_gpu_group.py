@@ -90,9 +90,10 @@ def test_edge_antialiased_and_overlapping_plans_shard_by_rows_only():
     """fractional seams with edge anti-aliasing (the iOS plan) and the reference's orientation-7 placement (overlapping draws,
     utils/canvas.js:187-192) are refused draw by draw (no single draw's owner owns the seam row) and are bit-identical to the
     one-device result by rows - what "auto", the default, picks for them"""
-    px = [U.rand_image(840 + i, 48, 64) for i in range(3)]
+    same = [U.rand_image(840 + i, 48, 64) for i in range(3)]
+    uneven = [U.rand_image(843 + i, h, 40) for i, h in enumerate((30, 20, 50))]      # orientation 7: image 2 lands on [0, 50) and covers image 1 at [10, 30)
     for opts, orient in (({"platform": "ios", "edgeAA": True}, None), ({"filter": "nearest"}, [7, 7, 7]), ({"filter": "bilinear", "gap": 3}, [7, 5, 7])):
-        imgs = U.hip_images(px, orientations=orient)
+        imgs = U.hip_images(uneven if orient else same, orientations=orient)
         one = ist.stitch(imgs, "vertical", opts)
         for split in ("image", "band"):
             with pytest.raises(ist.StitchError) as e:
