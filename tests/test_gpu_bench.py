@@ -95,7 +95,10 @@ def test_the_sharded_line_on_a_world_of_one():
             "resident/rows_horizontal", "host_in_host_out/rows_horizontal"}
     assert want <= set(ex["regions"]) and want <= set(ex["scaling"])
     for sc in ex["scaling"].values():
-        assert sc["ms_1gpu"] > 0 and sc["ms_Ngpu"] > 0 and 0.5 < sc["speedup"] < 2.0        # one rank against itself
+        # (one rank against itself; with 20 steps the contract's barrier + all-reduce bracket is a visible part of the sub-millisecond regions)
+        assert sc["ms_1gpu"] > 0 and sc["ms_Ngpu"] > 0 and abs(sc["speedup"] - sc["ms_1gpu"] / sc["ms_Ngpu"]) <= 0.01 * max(1.0, sc["speedup"])
+    for name in ("host_in_host_out/image", "host_in_host_out/band", "host_in_host_out/rows_horizontal", "from_pinned_host/image"):
+        assert 0.6 < ex["scaling"][name]["speedup"] < 1.6, (name, ex["scaling"][name])              # PCIe-bound regions: the same bytes over the same link
     assert ex["gather"]["rows_horizontal"]["split"] == "rows" and ex["gather"]["rows_horizontal"]["host_sink_available"] is True
     c5 = ex["config5"]
     assert "skipped" not in c5 and {"resident/image", "host_in_host_out/image"} <= set(c5["regions"]) <= set(c5["scaling"]) | set(c5["regions"])
