@@ -1,5 +1,6 @@
 // ist_jpeg_kernels.hip — the data-parallel half of JPEG decode on gfx950: dequantise + 8x8 inverse DCT per block, then
-// chroma upsampling + YCbCr->RGB per pixel, from coefficient planes produced by the host entropy decoder (ist_jpeg.cpp).
+// chroma upsampling + YCbCr->RGB per pixel, from coefficient planes produced by the entropy decoders (GPU: ist_jpeg_gpu.hip,
+// host: ist_jpeg.cpp).  Reference anchor: the Image.src decode of loadImageFrom (utils/canvas.js:27-121; pages/index/index.js:1441-1463).
 //
 // The arithmetic is the public "slow-but-accurate" integer IDCT (Loeffler-Ligtenberg-Moschytz, 13-bit constants,
 // 2-bit pass-1 scaling), triangle-filter ("fancy") chroma upsampling and the 16-bit fixed-point YCbCr->RGB tables that
@@ -47,50 +48,72 @@ __device__ __forceinline__ void idct8(const int in[8], int out[8], int shift, bo
   out[3] = descale(tmp13 + tmp0, shift); out[4] = descale(tmp13 - tmp0, shift);
 }
 
+// ---- the 8x8 inverse DCT of 32 blocks by one 256-thread workgroup: 8 lanes per block -------------------------------------------
+// (round 4; the first version gave every thread a whole block: 64 two-byte loads per thread at a lane stride of 128 bytes - a wave
+// touched 64 cache lines per load instruction - and 64 live ints per thread.)  Thread t = 8 * b + i.  Lane (b, i):
+//   1. reads ROW i of its block with one 16-byte load (a wave reads eight whole blocks = 1 KiB contiguous), dequantises it and
+//      writes it to the block's LDS image;
+//   2. reads COLUMN i of the image, runs pass 1 (columns, as the reference IDCT does first) and writes the column back;
+//   3. reads ROW i, runs pass 2, level-shifts and clamps: eight samples of row i of the block.
+// LDS image of a block: 72 dwords, element (y, x) at 9 * y + x.  With that pitch the row accesses and the column accesses of the 32
+// lanes that share an LDS cycle (4 blocks x 8 lanes, ds_read_b32 / ds_write_b32: bank = dword address mod 32) all fall on 32 different
+// banks.  The 8 lanes of a block sit in one wave, whose LDS operations execute in order: no barrier between the three steps.
+constexpr int kIdctBlocks = 32, kIdctPitch = 72;
+
+// q9: the quantisation table as int at [9 * y + x] (LDS).  Returns the eight samples of row i as two packed dwords.
+__device__ __forceinline__ uint2 idct_rows_of_32_blocks(const int16_t* blk, const int* q9, int* ws, int t) {
+  const int b = t >> 3, i = t & 7;
+  int* W = ws + b * kIdctPitch;
+  {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (blk) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(blk) + i);      // (read once)
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const int c = static_cast<int>(static_cast<int16_t>((w[x >> 1] >> (16 * (x & 1))) & 0xFFFFu));
+      W[9 * i + x] = __mul24(c, q9[9 * i + x]);      // (int16 x uint16: exact in 24-bit operands; the full-rate multiply)
+    }
+  }
+  int in[8], o[8];
+#pragma unroll
+  for (int y = 0; y < 8; ++y) in[y] = W[9 * y + i];
+  idct8(in, o, CONST_BITS - PASS1_BITS, true);
+#pragma unroll
+  for (int y = 0; y < 8; ++y) W[9 * y + i] = o[y];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) in[x] = W[9 * i + x];
+  idct8(in, o, CONST_BITS + PASS1_BITS + 3, false);
+  uint2 r; r.x = 0u; r.y = 0u;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    r.x |= static_cast<uint32_t>(min(max(o[x] + 128, 0), 255)) << (8 * x);
+    r.y |= static_cast<uint32_t>(min(max(o[x + 4] + 128, 0), 255)) << (8 * x);
+  }
+  return r;
+}
+
 // (the quantisation table travels BY VALUE in the kernel arguments: 128 bytes, read with scalar loads - as a 128-byte upload per
 // component it was three 5 us blit copies in front of every image's reconstruction)
-// ALL components of an image in ONE launch (a workgroup belongs to one component: wg0[c] = its first workgroup): as a launch
-// per component the reconstruction of nine photos was 27 launches on the file pipeline's critical submission path.
+// Components -> sample planes, all of them in ONE launch (a workgroup belongs to one component: wg0[c] = its first workgroup).
+// The fused kernel below takes the luma blocks itself, so for a colour image this launch carries the two chroma planes only.
 struct IdctComp { const int16_t* coef; uint8_t* plane; int blocks_x, n_blocks; uint16_t q[64]; };
 struct IdctArgs { IdctComp comp[3]; int wg0[3]; };
 
-// one thread per 8x8 block: 128 B of coefficients in, 64 samples out (plane row pitch = blocks_x * 8)
-__global__ __launch_bounds__(128) void ist_jpeg_idct_kernel(const IdctArgs P) {
-  const int wg = static_cast<int>(blockIdx.x);
+__global__ __launch_bounds__(256) void ist_jpeg_idct_kernel(const IdctArgs P) {
+  __shared__ int ws[kIdctBlocks * kIdctPitch];
+  __shared__ int q9[72];
+  const int wg = static_cast<int>(blockIdx.x), t = static_cast<int>(threadIdx.x);
   const int ci = wg >= P.wg0[2] ? 2 : (wg >= P.wg0[1] ? 1 : 0);             // (workgroup-uniform)
   const IdctComp& A = P.comp[ci];
-  const int b = (wg - P.wg0[ci]) * static_cast<int>(blockDim.x) + static_cast<int>(threadIdx.x);
-  if (b >= A.n_blocks) return;
+  if (t < 64) q9[9 * (t >> 3) + (t & 7)] = A.q[t];
+  __syncthreads();
+  const int b = (wg - P.wg0[ci]) * kIdctBlocks + (t >> 3);
+  const bool live = b < A.n_blocks;
+  const uint2 v = idct_rows_of_32_blocks(live ? A.coef + static_cast<size_t>(b) * 64 : nullptr, q9, ws, t);
+  if (!live) return;
   const int by = b / A.blocks_x, bx = b - by * A.blocks_x;
-  const int16_t* c = A.coef + static_cast<size_t>(b) * 64;
-  int ws[64];
-  // pass 1: columns
-#pragma unroll
-  for (int x = 0; x < 8; ++x) {
-    int in[8], o[8];
-#pragma unroll
-    for (int y = 0; y < 8; ++y) in[y] = static_cast<int>(c[y * 8 + x]) * static_cast<int>(A.q[y * 8 + x]);
-    idct8(in, o, CONST_BITS - PASS1_BITS, true);
-#pragma unroll
-    for (int y = 0; y < 8; ++y) ws[y * 8 + x] = o[y];
-  }
-  // pass 2: rows, level shift + clamp
-  uint8_t* dst = A.plane + (static_cast<size_t>(by) * 8) * (static_cast<size_t>(A.blocks_x) * 8) + static_cast<size_t>(bx) * 8;
-#pragma unroll
-  for (int y = 0; y < 8; ++y) {
-    int in[8], o[8];
-#pragma unroll
-    for (int x = 0; x < 8; ++x) in[x] = ws[y * 8 + x];
-    idct8(in, o, CONST_BITS + PASS1_BITS + 3, false);
-    uint32_t lo = 0, hi = 0;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      lo |= static_cast<uint32_t>(min(max(o[x] + 128, 0), 255)) << (8 * x);
-      hi |= static_cast<uint32_t>(min(max(o[x + 4] + 128, 0), 255)) << (8 * x);
-    }
-    uint2 v; v.x = lo; v.y = hi;
-    *reinterpret_cast<uint2*>(dst + static_cast<size_t>(y) * A.blocks_x * 8) = v;
-  }
+  *reinterpret_cast<uint2*>(A.plane + (static_cast<size_t>(by) * 8 + (t & 7)) * (static_cast<size_t>(A.blocks_x) * 8) + static_cast<size_t>(bx) * 8) = v;
 }
 
 // sparse -> dense: one thread per block writes its non-zero coefficients into the (zeroed) plane
@@ -103,45 +126,18 @@ __global__ __launch_bounds__(256) void ist_jpeg_scatter_kernel(const uint32_t* e
 }
 
 struct ColorArgs {
-  const uint8_t* Y; const uint8_t* Cb; const uint8_t* Cr;
-  int pitch_y, pitch_c;            // plane row pitches
+  const int16_t* coef_y; int blocks_x, blocks_y;   // luma coefficient blocks (blocks_x per block row)
+  const uint8_t* Cb; const uint8_t* Cr;
+  int pitch_c;                     // chroma plane row pitch
   int width, height;               // image size
   int cw, chh;                     // true chroma plane size (ceil(width*1/hmax), ceil(height*1/vmax))
   int hs, vs;                      // luma-to-chroma ratios (1 or 2)
   int ncomp;
   uint8_t* out; size_t out_pitch;
+  uint16_t q[64];                  // luma quantisation table
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// triangle-filter upsampling of one chroma sample at full-resolution position (x, y)
-__device__ __forceinline__ int chroma_at(const uint8_t* P, int pitch, int cw, int chh, int hs, int vs, int x, int y) {
-  if (hs == 1 && vs == 1) return P[static_cast<size_t>(y) * pitch + x];
-  if (hs == 2 && vs == 1) {                       // h2v1: 3/4 nearer + 1/4 further column
-    const int i = x >> 1;
-    const uint8_t* r = P + static_cast<size_t>(y) * pitch;
-    if (x & 1) return i == cw - 1 ? r[i] : (3 * r[i] + r[i + 1] + 2) >> 2;
-    return i == 0 ? r[i] : (3 * r[i] + r[i - 1] + 1) >> 2;
-  }
-  if (hs == 1 && vs == 2) {                       // h1v2: 3/4 nearer + 1/4 further row
-    const int j = y >> 1;
-    const int jn = (y & 1) ? min(j + 1, chh - 1) : max(j - 1, 0);
-    const int a = P[static_cast<size_t>(j) * pitch + x], b = P[static_cast<size_t>(jn) * pitch + x];
-    return (3 * a + b + ((y & 1) ? 2 : 1)) >> 2;
-  }
-  // h2v2: vertical 3:1 first (unscaled), then horizontal 3:1, one final shift by 4
-  const int j = y >> 1, i = x >> 1;
-  const int jn = (y & 1) ? min(j + 1, chh - 1) : max(j - 1, 0);
-  const uint8_t* r0 = P + static_cast<size_t>(j) * pitch;
-  const uint8_t* r1 = P + static_cast<size_t>(jn) * pitch;
-  const int cur = 3 * r0[i] + r1[i];
-  if (x & 1) {
-    if (i == cw - 1) return (cur * 4 + 7) >> 4;
-    return (cur * 3 + (3 * r0[i + 1] + r1[i + 1]) + 7) >> 4;
-  }
-  if (i == 0) return (cur * 4 + 8) >> 4;
-  return (cur * 3 + (3 * r0[i - 1] + r1[i - 1]) + 8) >> 4;
-}
 
 __device__ __forceinline__ uint32_t ycc_to_rgba(int Yv, int cb, int cr) {
   // 16-bit fixed point: FIX(1.40200)=91881, FIX(1.77200)=116130, FIX(0.71414)=46802, FIX(0.34414)=22554
@@ -152,62 +148,170 @@ __device__ __forceinline__ uint32_t ycc_to_rgba(int Yv, int cb, int cr) {
          (static_cast<uint32_t>(clampi(b, 0, 255)) << 16) | 0xFF000000u;
 }
 
-// 4:2:0 (the photo case), one thread per 4 output pixels x0 .. x0+3 of one row: the four pixels lie over chroma columns
-// i0 and i0+1 and blend with i0-1 and i0+2, so the thread reads 4 columns x 2 rows per chroma plane ONCE (the generic
-// path below reads 4 bytes per plane per PIXEL) and blends them vertically once.  Clamping a neighbour's column index to
-// the plane reproduces the edge rules of chroma_at exactly: (4 c + 8) >> 4 = (3 c + c + 8) >> 4.
-__device__ __forceinline__ void color4_h2v2(const ColorArgs& A, int x0, int y, uint32_t px[4]) {
-  const int j = y >> 1, i0 = x0 >> 1;
-  const int jn = (y & 1) ? min(j + 1, A.chh - 1) : max(j - 1, 0);
-  const int col[4] = {max(i0 - 1, 0), i0, min(i0 + 1, A.cw - 1), min(i0 + 2, A.cw - 1)};
-  int cb[4], cr[4];
-  {
-    const uint8_t* b0 = A.Cb + static_cast<size_t>(j) * A.pitch_c; const uint8_t* b1 = A.Cb + static_cast<size_t>(jn) * A.pitch_c;
-    const uint8_t* r0 = A.Cr + static_cast<size_t>(j) * A.pitch_c; const uint8_t* r1 = A.Cr + static_cast<size_t>(jn) * A.pitch_c;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { cb[k] = 3 * b0[col[k]] + b1[col[k]]; cr[k] = 3 * r0[col[k]] + r1[col[k]]; }
+// ---- luma IDCT + chroma upsampling + colour conversion, fused per tile of one MCU row (round 4) --------------------------------
+// A workgroup owns 32 luma blocks = one MCU row x 128 pixels (two block rows: v = 2) or x 256 pixels (one block row): it runs their
+// inverse DCT (above) into an LDS tile - the luma plane never exists in HBM -, stages the chroma samples the tile's pixels blend
+// (the tile's own + one row above and below + one column left and right, clamped to the plane: the edge rules of the triangle
+// filter are clamps) from the chroma planes into LDS, and converts.  Traffic per 4:2:0 pixel: 2 B of luma coefficients + 0.5 B of
+// chroma samples (+ halo, from L2) in, 4 B of RGBA out; the chroma planes cost their own 1 B + 0.5 B in the launch before: 8 B in
+// all against 10 B of the unfused pair (coefficients 3, planes out and in 1.5 + 1.5, RGBA 4), and every global access is a whole
+// 16-byte lane.  The arithmetic is unchanged (bit-exact against libjpeg-turbo's defaults, tests/test_gpu_jpeg.py).
+constexpr int kTileYPitchNarrow = 144, kTileYPitchWide = 272;      // bytes per luma tile row (128 / 256 px): 16 mod 128 keeps the row writes of step 3 off each other's banks
+constexpr int kChromaRows = 10, kChromaPitch = 272;                 // rows j0-1 .. j0+8; columns i0-4 .. i0+267 (dword aligned origin)
+
+template <int HS, int VS>
+__device__ __forceinline__ int chroma_lds(const uint8_t* T, int cw, int i_org, int j_org, int x, int y) {
+  // T[(j - j_org) * kChromaPitch + (i - i_org)]: rows are clamped at load time, columns here
+  auto at = [&](int j, int i) { return static_cast<int>(T[(j - j_org) * kChromaPitch + (clampi(i, 0, cw - 1) - i_org)]); };
+  if (HS == 1 && VS == 1) return at(y, x);
+  if (HS == 2 && VS == 1) {                       // h2v1: 3/4 nearer + 1/4 further column
+    const int i = x >> 1;
+    if (x & 1) return i == cw - 1 ? at(y, i) : (3 * at(y, i) + at(y, i + 1) + 2) >> 2;
+    return i == 0 ? at(y, i) : (3 * at(y, i) + at(y, i - 1) + 1) >> 2;
   }
-  const uint32_t yy = *reinterpret_cast<const uint32_t*>(A.Y + static_cast<size_t>(y) * A.pitch_y + x0);   // (x0 % 4 == 0, pitch % 8 == 0)
-  // pixel k: own column own[k], neighbour nb[k], rounding 8 (even x) / 7 (odd x)
-  const int own[4] = {1, 1, 2, 2}, nb[4] = {0, 2, 1, 3}, rnd[4] = {8, 7, 8, 7};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int u = (cb[own[k]] * 3 + cb[nb[k]] + rnd[k]) >> 4, v = (cr[own[k]] * 3 + cr[nb[k]] + rnd[k]) >> 4;
-    px[k] = ycc_to_rgba(static_cast<int>((yy >> (8 * k)) & 255u), u - 128, v - 128);
+  if (HS == 1 && VS == 2) {                       // h1v2: 3/4 nearer + 1/4 further row
+    const int j = y >> 1, jn = (y & 1) ? j + 1 : j - 1;
+    return (3 * at(j, x) + at(jn, x) + ((y & 1) ? 2 : 1)) >> 2;
   }
+  // h2v2: vertical 3:1 first (unscaled), then horizontal 3:1, one final shift by 4; a clamped neighbour column reproduces the edge
+  // rule: (4 c + 8) >> 4 = (3 c + c + 8) >> 4
+  const int j = y >> 1, i = x >> 1, jn = (y & 1) ? j + 1 : j - 1;
+  const int cur = 3 * at(j, i) + at(jn, i);
+  const int in = (x & 1) ? i + 1 : i - 1;
+  return (cur * 3 + (3 * at(j, in) + at(jn, in)) + ((x & 1) ? 7 : 8)) >> 4;
 }
 
-// one thread per 4 output pixels
-__global__ __launch_bounds__(256) void ist_jpeg_color_kernel(const ColorArgs A) {
-  const int gx = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  const int y = blockIdx.y;
-  if (gx >= A.width) return;
-  uint32_t px[4];
-  if (A.ncomp == 3 && A.hs == 2 && A.vs == 2) color4_h2v2(A, gx, y, px);
-  else
+template <int HS, int VS, bool COLOUR>
+__global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) {
+  constexpr int TW = VS == 2 ? 128 : 256, TH = 8 * VS, YP = VS == 2 ? kTileYPitchNarrow : kTileYPitchWide;
+  constexpr int BW = TW / 8;                                             // luma blocks per block row of the tile
+  __shared__ int ws[kIdctBlocks * kIdctPitch];
+  __shared__ int q9[72];
+  __shared__ __attribute__((aligned(16))) uint8_t Ys[TH * YP];
+  __shared__ __attribute__((aligned(16))) uint8_t Cs[COLOUR ? 2 * kChromaRows * kChromaPitch : 16];
+  const int t = static_cast<int>(threadIdx.x);
+  const int x_org = static_cast<int>(blockIdx.x) * TW, y_org = static_cast<int>(blockIdx.y) * TH;
+  if (t < 64) q9[9 * (t >> 3) + (t & 7)] = A.q[t];
+  // the chroma tile: rows j_org .. j_org+9 (clamped to the plane), columns from i_org in dwords
+  const int i_org = x_org / HS - 4, j_org = y_org / VS - 1;
+  if (COLOUR) {
+    // dword d of tile row pr (= plane * 10 + row): 64 lanes x 4 row slots per pass.  Columns outside the plane are REPLICATED into
+    // the tile (a dword that straddles an edge is put together from clamped bytes), so the blends below never clamp.
+    constexpr int DW = (TW / HS + 8) / 4;                                // dwords per row: 4 columns of halo room on each side (<= 66)
+    for (int d = t & 63; d < DW; d += 64) {
+      const int i = i_org + 4 * d;
+      for (int pr = t >> 6; pr < 2 * kChromaRows; pr += 4) {
+        const int pl = pr >= kChromaRows ? 1 : 0, r = pr - pl * kChromaRows;
+        const uint8_t* row = (pl ? A.Cr : A.Cb) + static_cast<size_t>(clampi(j_org + r, 0, A.chh - 1)) * A.pitch_c;
+        uint32_t v;
+        if (i >= 0 && i + 3 <= A.cw - 1) v = *reinterpret_cast<const uint32_t*>(row + i);
+        else {
+          v = 0u;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int x = min(gx + k, A.width - 1);
-    const int Yv = A.Y[static_cast<size_t>(y) * A.pitch_y + x];
-    int r = Yv, g = Yv, b = Yv;
-    if (A.ncomp == 3) {
-      const int cb = chroma_at(A.Cb, A.pitch_c, A.cw, A.chh, A.hs, A.vs, x, y) - 128;
-      const int cr = chroma_at(A.Cr, A.pitch_c, A.cw, A.chh, A.hs, A.vs, x, y) - 128;
-      // 16-bit fixed point: FIX(1.40200)=91881, FIX(1.77200)=116130, FIX(0.71414)=46802, FIX(0.34414)=22554
-      r = Yv + ((91881 * cr + 32768) >> 16);
-      b = Yv + ((116130 * cb + 32768) >> 16);
-      g = Yv + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+          for (int k = 0; k < 4; ++k) v |= static_cast<uint32_t>(row[clampi(i + k, 0, A.cw - 1)]) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(Cs + pr * kChromaPitch + 4 * d) = v;
+      }
     }
-    px[k] = static_cast<uint32_t>(clampi(r, 0, 255)) | (static_cast<uint32_t>(clampi(g, 0, 255)) << 8) |
-            (static_cast<uint32_t>(clampi(b, 0, 255)) << 16) | 0xFF000000u;
   }
-  uint8_t* o = A.out + static_cast<size_t>(y) * A.out_pitch + static_cast<size_t>(gx) * 4;
-  const int nv = A.width - gx;
-  if (nv >= 4 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
-    uint4 v; v.x = px[0]; v.y = px[1]; v.z = px[2]; v.w = px[3];
-    *reinterpret_cast<uint4*>(o) = v;
-  } else {
-    for (int k = 0; k < 4 && k < nv; ++k) *reinterpret_cast<uint32_t*>(o + 4 * k) = px[k];
+  __syncthreads();
+  {
+    const int b = t >> 3, i = t & 7;
+    const int bx = x_org / 8 + (b % BW), by = y_org / 8 + (b / BW);
+    const bool live = bx < A.blocks_x && by < A.blocks_y;
+    const uint2 v = idct_rows_of_32_blocks(live ? A.coef_y + (static_cast<size_t>(by) * A.blocks_x + bx) * 64 : nullptr, q9, ws, t);
+    *reinterpret_cast<uint2*>(Ys + ((b / BW) * 8 + i) * YP + (b % BW) * 8) = v;
+  }
+  __syncthreads();
+  if (COLOUR && HS == 2 && VS == 2) {
+    // 4:2:0, the photo case: a thread converts 4 pixels x 2 rows (the rows 2j, 2j+1 that share chroma row j): per plane ONE
+    // two-dword LDS read per chroma row j-1, j, j+1 gives the four columns i-1 .. i+2 the eight pixels blend; the vertical 3:1 and the
+    // horizontal 3:1 run on pairs of 16-bit lanes in 32-bit registers (every term < 4096), the colour conversion on 24-bit
+    // multiply-adds (chroma < 256, constants < 2^17: exact).  Same integers as chroma_lds + ycc_to_rgba, a third of the instructions
+    // (the kernel is bound by instruction issue: rocprofv3 + ISA count).
+    const int gx = t & 31, jj = t >> 5;
+    const int lx = 4 * gx, ly = 2 * jj;
+    const int x0 = x_org + lx, y = y_org + ly;
+    if (x0 >= A.width || y >= A.height) return;
+    const int cb0 = 2 * gx + 3;                                          // tile column of chroma i - 1 (i = x0 / 2; the tile starts at i_org = x_org / 2 - 4)
+    const int al = cb0 & ~3, sh = 8 * (cb0 & 3);
+    uint32_t pcb[4], pcr[4];                                            // per output row r = 0, 1: [2r] = pixels 0,1 and [2r+1] = pixels 2,3, as (value << 4 | fraction) in 16-bit lanes
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      uint32_t lo[3], hi[3];                                            // columns (c0, c2) and (c1, c3) of rows j-1, j, j+1 in 16-bit lanes
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(Cs + (pl * kChromaRows + jj + r) * kChromaPitch + al);
+        const uint32_t w = static_cast<uint32_t>((static_cast<uint64_t>(q[0]) | (static_cast<uint64_t>(q[1]) << 32)) >> sh);
+        lo[r] = w & 0x00FF00FFu; hi[r] = (w >> 8) & 0x00FF00FFu;
+      }
+      const uint32_t l3 = lo[1] * 3u, h3 = hi[1] * 3u;                   // (lanes <= 765: no carry between them)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const uint32_t vl = l3 + lo[2 * r], vh = h3 + hi[2 * r];         // vertical: 3 * row j + row j -/+ 1 -> (c0, c2), (c1, c3), each <= 1020
+        const uint32_t b1 = __umul24(vh & 0xFFFFu, 0x00030003u), b2 = __umul24(vl >> 16, 0x00030003u);      // 3 * c1, 3 * c2 in both lanes
+        const uint32_t p01 = b1 + vl + 0x00070008u, p23 = b2 + vh + 0x00070008u;      // pixel 0: 3 c1 + c0 + 8, 1: 3 c1 + c2 + 7, 2: 3 c2 + c1 + 8, 3: 3 c2 + c3 + 7
+        if (pl == 0) { pcb[2 * r] = p01; pcb[2 * r + 1] = p23; } else { pcr[2 * r] = p01; pcr[2 * r + 1] = p23; }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (y + r >= A.height) break;
+      const uint32_t yy = *reinterpret_cast<const uint32_t*>(Ys + (ly + r) * YP + lx);
+      uint32_t px[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int cb = static_cast<int>((pcb[2 * r + (k >> 1)] >> (4 + 16 * (k & 1))) & 255u);      // (>> 4: the blend's final shift)
+        const int cr = static_cast<int>((pcr[2 * r + (k >> 1)] >> (4 + 16 * (k & 1))) & 255u);
+        const int y16 = static_cast<int>((((yy >> (8 * k)) & 255u) << 16) | 0x8000u);               // Y << 16 + the rounding half
+        // Y + ((K * (c - 128) + 32768) >> 16) = (Y << 16 + 32768 + K * c - 128 K) >> 16
+        // clamped BEFORE the shift (to [0, 2^24): byte 2 is the channel) and put together with a byte permute.  Written as
+        // clamp(x >> 16, 0, 255) the compiler (ROCm 7.2) forms v_ashr_pk_u8_i32, whose destination keeps its upper 16 bits - it then
+        // ORs the blue byte onto whatever the register held before (seen on the GPU: blue = right value | junk, red and green right).
+        const uint32_t r_ = static_cast<uint32_t>(clampi(__mul24(cr, 91881) + (y16 - 128 * 91881), 0, 0x00FFFFFF));
+        const uint32_t b_ = static_cast<uint32_t>(clampi(__mul24(cb, 116130) + (y16 - 128 * 116130), 0, 0x00FFFFFF));
+        const uint32_t g_ = static_cast<uint32_t>(clampi(__mul24(cb, -22554) + __mul24(cr, -46802) + (y16 + 128 * (22554 + 46802)), 0, 0x00FFFFFF));
+        px[k] = __builtin_amdgcn_perm(g_, r_, 0x0c0c0602u) | (b_ & 0x00FF0000u) | 0xFF000000u;      // byte 0 = r[2], byte 1 = g[2]
+      }
+      uint8_t* o = A.out + static_cast<size_t>(y + r) * A.out_pitch + static_cast<size_t>(x0) * 4;
+      const int nv = A.width - x0;
+      if (nv >= 4 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+        uint4 v; v.x = px[0]; v.y = px[1]; v.z = px[2]; v.w = px[3];
+        *reinterpret_cast<uint4*>(o) = v;
+      } else {
+        for (int k = 0; k < 4 && k < nv; ++k) *reinterpret_cast<uint32_t*>(o + 4 * k) = px[k];
+      }
+    }
+    return;
+  }
+  // colour, the other samplings: groups of 4 pixels; a wave's 64 groups are consecutive in x (512 B - 1 KiB runs of a canvas row)
+  constexpr int GX = TW / 4;
+  for (int g = t; g < GX * TH; g += 256) {
+    const int ly = g / GX, lx = 4 * (g % GX);
+    const int x0 = x_org + lx, y = y_org + ly;
+    if (x0 >= A.width || y >= A.height) continue;
+    const uint32_t yy = *reinterpret_cast<const uint32_t*>(Ys + ly * YP + lx);
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int Yv = static_cast<int>((yy >> (8 * k)) & 255u);
+      if (COLOUR) {
+        const int x = min(x0 + k, A.width - 1);
+        const int cb = chroma_lds<HS, VS>(Cs, A.cw, i_org, j_org, x, y) - 128;
+        const int cr = chroma_lds<HS, VS>(Cs + kChromaRows * kChromaPitch, A.cw, i_org, j_org, x, y) - 128;
+        px[k] = ycc_to_rgba(Yv, cb, cr);
+      } else {
+        px[k] = static_cast<uint32_t>(Yv) * 0x010101u | 0xFF000000u;
+      }
+    }
+    uint8_t* o = A.out + static_cast<size_t>(y) * A.out_pitch + static_cast<size_t>(x0) * 4;
+    const int nv = A.width - x0;
+    if (nv >= 4 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+      uint4 v; v.x = px[0]; v.y = px[1]; v.z = px[2]; v.w = px[3];
+      *reinterpret_cast<uint4*>(o) = v;
+    } else {
+      for (int k = 0; k < 4 && k < nv; ++k) *reinterpret_cast<uint32_t*>(o + 4 * k) = px[k];
+    }
   }
 }
 
@@ -223,28 +327,40 @@ int jpeg_launch_scatter(const uint32_t* d_ent, const uint32_t* d_start, const ui
 
 int jpeg_launch_reconstruct(const JpegDeviceJob& J, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  {
+  if (J.ncomp == 3) {                                  // the chroma planes (the fused kernel blends their neighbours across tiles)
     IdctArgs a;
     std::memset(&a, 0, sizeof a);
     int wgs = 0;
-    for (int c = 0; c < 3; ++c) {
-      a.wg0[c] = wgs;                                  // (a component the image does not have: no workgroups, never selected)
-      if (c >= J.ncomp) { a.wg0[c] = 0x7fffffff; continue; }
-      IdctComp& C = a.comp[c];
+    a.wg0[0] = 0;                                      // component slot 0 of this launch = Cb, slot 1 = Cr, slot 2 unused
+    for (int c = 1; c < 3; ++c) {
+      IdctComp& C = a.comp[c - 1];
+      a.wg0[c - 1] = wgs;
       C.coef = J.d_coef[c]; C.plane = J.d_plane[c]; C.blocks_x = J.blocks_x[c]; C.n_blocks = J.blocks_x[c] * J.blocks_y[c];
       for (int k = 0; k < 64; ++k) C.q[k] = J.q_host[c] ? J.q_host[c][k] : 1;
-      wgs += (C.n_blocks + 127) / 128;
+      wgs += (C.n_blocks + kIdctBlocks - 1) / kIdctBlocks;
     }
-    if (wgs > 0) hipLaunchKernelGGL(ist_jpeg_idct_kernel, dim3(static_cast<unsigned>(wgs)), dim3(128), 0, stream, a);
+    a.wg0[2] = 0x7fffffff;
+    if (wgs > 0) hipLaunchKernelGGL(ist_jpeg_idct_kernel, dim3(static_cast<unsigned>(wgs)), dim3(256), 0, stream, a);
   }
   ColorArgs ca;
-  ca.Y = J.d_plane[0]; ca.Cb = J.ncomp == 3 ? J.d_plane[1] : nullptr; ca.Cr = J.ncomp == 3 ? J.d_plane[2] : nullptr;
-  ca.pitch_y = J.blocks_x[0] * 8; ca.pitch_c = J.ncomp == 3 ? J.blocks_x[1] * 8 : 0;
+  std::memset(&ca, 0, sizeof ca);
+  ca.coef_y = J.d_coef[0]; ca.blocks_x = J.blocks_x[0]; ca.blocks_y = J.blocks_y[0];
+  ca.Cb = J.ncomp == 3 ? J.d_plane[1] : nullptr; ca.Cr = J.ncomp == 3 ? J.d_plane[2] : nullptr;
+  ca.pitch_c = J.ncomp == 3 ? J.blocks_x[1] * 8 : 0;
   ca.width = J.width; ca.height = J.height;
   ca.hs = J.hmax; ca.vs = J.vmax;
   ca.cw = (J.width + J.hmax - 1) / J.hmax; ca.chh = (J.height + J.vmax - 1) / J.vmax;
   ca.ncomp = J.ncomp; ca.out = J.out; ca.out_pitch = J.out_pitch;
-  hipLaunchKernelGGL(ist_jpeg_color_kernel, dim3((J.width + 1023) / 1024, J.height), dim3(256), 0, stream, ca);
+  for (int k = 0; k < 64; ++k) ca.q[k] = J.q_host[0] ? J.q_host[0][k] : 1;
+  const int tw = J.vmax == 2 ? 128 : 256, th = 8 * J.vmax;
+  const dim3 grid(static_cast<unsigned>((J.blocks_x[0] * 8 + tw - 1) / tw), static_cast<unsigned>((J.blocks_y[0] * 8 + th - 1) / th));
+  if (grid.x > 0 && grid.y > 0) {
+    if (J.ncomp != 3) hipLaunchKernelGGL((ist_jpeg_fused_kernel<1, 1, false>), grid, dim3(256), 0, stream, ca);
+    else if (J.hmax == 2 && J.vmax == 2) hipLaunchKernelGGL((ist_jpeg_fused_kernel<2, 2, true>), grid, dim3(256), 0, stream, ca);
+    else if (J.hmax == 2) hipLaunchKernelGGL((ist_jpeg_fused_kernel<2, 1, true>), grid, dim3(256), 0, stream, ca);
+    else if (J.vmax == 2) hipLaunchKernelGGL((ist_jpeg_fused_kernel<1, 2, true>), grid, dim3(256), 0, stream, ca);
+    else hipLaunchKernelGGL((ist_jpeg_fused_kernel<1, 1, true>), grid, dim3(256), 0, stream, ca);
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(IST_E_HIP, std::string("JPEG reconstruct launch failed: ") + hipGetErrorString(e));
   return IST_OK;
