@@ -132,10 +132,15 @@ struct JpegDeviceJob {
   int h[3], v[3], blocks_x[3], blocks_y[3];
   const int16_t* d_coef[3];
   const uint16_t* q_host[3];           // quantisation tables (HOST memory, natural order): passed by value to the kernel
-  uint8_t* d_plane[3];                 // blocks_x*8 bytes per row
+  uint8_t* d_plane[3];                 // blocks_x*8 bytes per row (chroma only: the luma plane stays in LDS)
   uint8_t* out; size_t out_pitch;
+  bool chroma_done = false;            // jpeg_launch_chroma_idct has already made d_plane[1], d_plane[2] on this stream
 };
+// chroma planes (one launch: components 1, 2 -> sample planes), then luma IDCT fused with upsampling + colour conversion
 int jpeg_launch_reconstruct(const JpegDeviceJob& job, void* stream);
+// the chroma planes of SEVERAL images in one launch (per 18 components): what the file pipeline runs once behind the Huffman
+// batch, so that every image afterwards costs one (fused) launch
+int jpeg_launch_chroma_idct(const JpegDeviceJob* jobs, int n_jobs, void* stream);
 // d_coef (zeroed by the caller) <- the sparse entries of n_blocks blocks.  Asynchronous on `stream`.
 int jpeg_launch_scatter(const uint32_t* d_ent, const uint32_t* d_start, const uint8_t* d_cnt, int16_t* d_coef, int n_blocks, void* stream);
 // host-side expansion of one component to the dense form (tests, tools)

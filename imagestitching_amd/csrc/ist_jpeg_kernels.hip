@@ -61,13 +61,17 @@ __device__ __forceinline__ void idct8(const int in[8], int out[8], int shift, bo
 constexpr int kIdctBlocks = 32, kIdctPitch = 72;
 
 // q9: the quantisation table as int at [9 * y + x] (LDS).  Returns the eight samples of row i as two packed dwords.
-__device__ __forceinline__ uint2 idct_rows_of_32_blocks(const int16_t* blk, const int* q9, int* ws, int t) {
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// row i (= t & 7) of a block's coefficients: issued as early as possible, consumed by idct_rows_of_32_blocks
+__device__ __forceinline__ u32x4 load_coef_row(const int16_t* blk, int t) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (blk) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(blk) + (t & 7));      // (read once)
+  return v;
+}
+__device__ __forceinline__ uint2 idct_rows_of_32_blocks(u32x4 v, const int* q9, int* ws, int t) {
   const int b = t >> 3, i = t & 7;
   int* W = ws + b * kIdctPitch;
   {
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (blk) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(blk) + i);      // (read once)
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
@@ -97,20 +101,25 @@ __device__ __forceinline__ uint2 idct_rows_of_32_blocks(const int16_t* blk, cons
 // component it was three 5 us blit copies in front of every image's reconstruction)
 // Components -> sample planes, all of them in ONE launch (a workgroup belongs to one component: wg0[c] = its first workgroup).
 // The fused kernel below takes the luma blocks itself, so for a colour image this launch carries the two chroma planes only.
+// Up to kIdctComps components per launch - the chroma planes of nine photos are ONE launch behind the Huffman batch instead of nine
+// 9 us launches between the images' fused launches (152 bytes of arguments per component: 2.8 KB of the 4 KB a launch may carry).
+constexpr int kIdctComps = 18;
 struct IdctComp { const int16_t* coef; uint8_t* plane; int blocks_x, n_blocks; uint16_t q[64]; };
-struct IdctArgs { IdctComp comp[3]; int wg0[3]; };
+struct IdctArgs { IdctComp comp[kIdctComps]; int wg0[kIdctComps + 1]; };      // wg0[c] = first workgroup of component c; wg0[n] = the grid
 
 __global__ __launch_bounds__(256) void ist_jpeg_idct_kernel(const IdctArgs P) {
   __shared__ int ws[kIdctBlocks * kIdctPitch];
   __shared__ int q9[72];
   const int wg = static_cast<int>(blockIdx.x), t = static_cast<int>(threadIdx.x);
-  const int ci = wg >= P.wg0[2] ? 2 : (wg >= P.wg0[1] ? 1 : 0);             // (workgroup-uniform)
+  int ci = 0;
+  while (ci + 1 < kIdctComps && wg >= P.wg0[ci + 1]) ++ci;                 // (workgroup-uniform: scalar loads of the arguments)
   const IdctComp& A = P.comp[ci];
-  if (t < 64) q9[9 * (t >> 3) + (t & 7)] = A.q[t];
-  __syncthreads();
   const int b = (wg - P.wg0[ci]) * kIdctBlocks + (t >> 3);
   const bool live = b < A.n_blocks;
-  const uint2 v = idct_rows_of_32_blocks(live ? A.coef + static_cast<size_t>(b) * 64 : nullptr, q9, ws, t);
+  const u32x4 cf = load_coef_row(live ? A.coef + static_cast<size_t>(b) * 64 : nullptr, t);
+  if (t < 64) q9[9 * (t >> 3) + (t & 7)] = A.q[t];
+  __syncthreads();
+  const uint2 v = idct_rows_of_32_blocks(cf, q9, ws, t);
   if (!live) return;
   const int by = b / A.blocks_x, bx = b - by * A.blocks_x;
   *reinterpret_cast<uint2*>(A.plane + (static_cast<size_t>(by) * 8 + (t & 7)) * (static_cast<size_t>(A.blocks_x) * 8) + static_cast<size_t>(bx) * 8) = v;
@@ -191,6 +200,11 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
   __shared__ __attribute__((aligned(16))) uint8_t Cs[COLOUR ? 2 * kChromaRows * kChromaPitch : 16];
   const int t = static_cast<int>(threadIdx.x);
   const int x_org = static_cast<int>(blockIdx.x) * TW, y_org = static_cast<int>(blockIdx.y) * TH;
+  // the tile's coefficient rows are requested first: their trip to HBM runs beside the chroma tile's (one exposed latency per
+  // workgroup instead of two: 8 workgroups per CU live about as long as their loads take)
+  const int blk_b = t >> 3;
+  const int blk_x = x_org / 8 + (blk_b % BW), blk_y = y_org / 8 + (blk_b / BW);
+  const u32x4 cf = load_coef_row(blk_x < A.blocks_x && blk_y < A.blocks_y ? A.coef_y + static_cast<uint32_t>((blk_y * A.blocks_x + blk_x) * 64) : nullptr, t);
   if (t < 64) q9[9 * (t >> 3) + (t & 7)] = A.q[t];
   // the chroma tile: rows j_org .. j_org+9 (clamped to the plane), columns from i_org in dwords
   const int i_org = x_org / HS - 4, j_org = y_org / VS - 1;
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
       const int i = i_org + 4 * d;
       for (int pr = t >> 6; pr < 2 * kChromaRows; pr += 4) {
         const int pl = pr >= kChromaRows ? 1 : 0, r = pr - pl * kChromaRows;
-        const uint8_t* row = (pl ? A.Cr : A.Cb) + static_cast<size_t>(clampi(j_org + r, 0, A.chh - 1)) * A.pitch_c;
+        const uint8_t* row = (pl ? A.Cr : A.Cb) + static_cast<uint32_t>(clampi(j_org + r, 0, A.chh - 1) * A.pitch_c);      // (a plane is < 4 GB: 32-bit offsets)
         uint32_t v;
         if (i >= 0 && i + 3 <= A.cw - 1) v = *reinterpret_cast<const uint32_t*>(row + i);
         else {
@@ -216,11 +230,8 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
   }
   __syncthreads();
   {
-    const int b = t >> 3, i = t & 7;
-    const int bx = x_org / 8 + (b % BW), by = y_org / 8 + (b / BW);
-    const bool live = bx < A.blocks_x && by < A.blocks_y;
-    const uint2 v = idct_rows_of_32_blocks(live ? A.coef_y + (static_cast<size_t>(by) * A.blocks_x + bx) * 64 : nullptr, q9, ws, t);
-    *reinterpret_cast<uint2*>(Ys + ((b / BW) * 8 + i) * YP + (b % BW) * 8) = v;
+    const uint2 v = idct_rows_of_32_blocks(cf, q9, ws, t);
+    *reinterpret_cast<uint2*>(Ys + ((blk_b / BW) * 8 + (t & 7)) * YP + (blk_b % BW) * 8) = v;
   }
   __syncthreads();
   if (COLOUR && HS == 2 && VS == 2) {
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
       for (int k = 0; k < 4; ++k) {
         const int cb = static_cast<int>((pcb[2 * r + (k >> 1)] >> (4 + 16 * (k & 1))) & 255u);      // (>> 4: the blend's final shift)
         const int cr = static_cast<int>((pcr[2 * r + (k >> 1)] >> (4 + 16 * (k & 1))) & 255u);
-        const int y16 = static_cast<int>((((yy >> (8 * k)) & 255u) << 16) | 0x8000u);               // Y << 16 + the rounding half
+        const int y16 = static_cast<int>(__builtin_amdgcn_perm(0x00008000u, yy, 0x0c000504u | (static_cast<uint32_t>(k) << 16)));   // Y << 16 + the rounding half: byte 2 = Y_k, bytes 1, 0 = 0x80, 0x00
         // Y + ((K * (c - 128) + 32768) >> 16) = (Y << 16 + 32768 + K * c - 128 K) >> 16
         // clamped BEFORE the shift (to [0, 2^24): byte 2 is the channel) and put together with a byte permute.  Written as
         // clamp(x >> 16, 0, 255) the compiler (ROCm 7.2) forms v_ashr_pk_u8_i32, whose destination keeps its upper 16 bits - it then
@@ -273,7 +284,10 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
         const uint32_t g_ = static_cast<uint32_t>(clampi(__mul24(cb, -22554) + __mul24(cr, -46802) + (y16 + 128 * (22554 + 46802)), 0, 0x00FFFFFF));
         px[k] = __builtin_amdgcn_perm(g_, r_, 0x0c0c0602u) | (b_ & 0x00FF0000u) | 0xFF000000u;      // byte 0 = r[2], byte 1 = g[2]
       }
-      uint8_t* o = A.out + static_cast<size_t>(y + r) * A.out_pitch + static_cast<size_t>(x0) * 4;
+      // (the tile's first row on the scalar unit; a row pitch is < 2^24: the rows inside the tile with a 24-bit multiply)
+      uint8_t* o = A.out + static_cast<size_t>(y_org) * A.out_pitch + static_cast<uint32_t>(x0) * 4u;
+      if (A.out_pitch < (size_t{1} << 24)) o += __umul24(static_cast<uint32_t>(ly + r), static_cast<uint32_t>(A.out_pitch));      // (wave-uniform choice)
+      else o += static_cast<size_t>(ly + r) * A.out_pitch;
       const int nv = A.width - x0;
       if (nv >= 4 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
         uint4 v; v.x = px[0]; v.y = px[1]; v.z = px[2]; v.w = px[3];
@@ -325,22 +339,42 @@ int jpeg_launch_scatter(const uint32_t* d_ent, const uint32_t* d_start, const ui
   return IST_OK;
 }
 
+int jpeg_launch_chroma_idct(const JpegDeviceJob* jobs, int n_jobs, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  IdctArgs a;
+  int nc = 0, wgs = 0;
+  auto flush = [&]() -> int {
+    if (nc == 0) return IST_OK;
+    for (int c = nc; c <= kIdctComps; ++c) a.wg0[c] = c == nc ? wgs : 0x7fffffff;
+    hipLaunchKernelGGL(ist_jpeg_idct_kernel, dim3(static_cast<unsigned>(wgs)), dim3(256), 0, stream, a);
+    const hipError_t e = hipGetLastError();
+    nc = 0; wgs = 0;
+    if (e != hipSuccess) return fail(IST_E_HIP, std::string("JPEG chroma IDCT launch failed: ") + hipGetErrorString(e));
+    return IST_OK;
+  };
+  std::memset(&a, 0, sizeof a);
+  for (int k = 0; k < n_jobs; ++k) {
+    const JpegDeviceJob& J = jobs[k];
+    if (J.ncomp != 3) continue;
+    for (int c = 1; c < 3; ++c) {
+      const int n_blocks = J.blocks_x[c] * J.blocks_y[c];
+      if (n_blocks <= 0) continue;
+      IdctComp& C = a.comp[nc];
+      a.wg0[nc] = wgs;
+      C.coef = J.d_coef[c]; C.plane = J.d_plane[c]; C.blocks_x = J.blocks_x[c]; C.n_blocks = n_blocks;
+      for (int q = 0; q < 64; ++q) C.q[q] = J.q_host[c] ? J.q_host[c][q] : 1;
+      wgs += (n_blocks + kIdctBlocks - 1) / kIdctBlocks;
+      if (++nc == kIdctComps) { const int rc = flush(); if (rc) return rc; }
+    }
+  }
+  return flush();
+}
+
 int jpeg_launch_reconstruct(const JpegDeviceJob& J, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (J.ncomp == 3) {                                  // the chroma planes (the fused kernel blends their neighbours across tiles)
-    IdctArgs a;
-    std::memset(&a, 0, sizeof a);
-    int wgs = 0;
-    a.wg0[0] = 0;                                      // component slot 0 of this launch = Cb, slot 1 = Cr, slot 2 unused
-    for (int c = 1; c < 3; ++c) {
-      IdctComp& C = a.comp[c - 1];
-      a.wg0[c - 1] = wgs;
-      C.coef = J.d_coef[c]; C.plane = J.d_plane[c]; C.blocks_x = J.blocks_x[c]; C.n_blocks = J.blocks_x[c] * J.blocks_y[c];
-      for (int k = 0; k < 64; ++k) C.q[k] = J.q_host[c] ? J.q_host[c][k] : 1;
-      wgs += (C.n_blocks + kIdctBlocks - 1) / kIdctBlocks;
-    }
-    a.wg0[2] = 0x7fffffff;
-    if (wgs > 0) hipLaunchKernelGGL(ist_jpeg_idct_kernel, dim3(static_cast<unsigned>(wgs)), dim3(256), 0, stream, a);
+  if (J.ncomp == 3 && !J.chroma_done) {                // the chroma planes (the fused kernel blends their neighbours across tiles)
+    const int rc = jpeg_launch_chroma_idct(&J, 1, stream_);
+    if (rc) return rc;
   }
   ColorArgs ca;
   std::memset(&ca, 0, sizeof ca);

@@ -476,10 +476,26 @@ void jpeg_layout_sparse(const JpegImage& J, size_t* off, JpegDevLayout* L) {
 
 // H2D of the coefficients (sparse entries are scattered into a zeroed plane on the GPU) + the reconstruction launches
 // (the quantisation tables go to the kernels by value: no upload)
-int jpeg_enqueue(const JpegImage& J, uint8_t* d, uint8_t* d_ent, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch, hipStream_t stream, bool coef_on_device = false) {
+// what the reconstruction kernels need to know of an image whose coefficient planes are (or will be) in the arena at L
+JpegDeviceJob jpeg_device_job(const JpegImage& J, uint8_t* d, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch) {
   JpegDeviceJob job;
   job.width = J.width; job.height = J.height; job.ncomp = J.ncomp; job.hmax = J.hmax; job.vmax = J.vmax;
   for (int c = 0; c < 3; ++c) { job.d_coef[c] = nullptr; job.q_host[c] = nullptr; job.d_plane[c] = nullptr; job.h[c] = job.v[c] = 1; job.blocks_x[c] = job.blocks_y[c] = 0; }
+  for (int c = 0; c < J.ncomp; ++c) {
+    const JpegComp& C = J.comp[c];
+    job.d_coef[c] = reinterpret_cast<int16_t*>(d + L.coef[c]);
+    job.q_host[c] = C.q;
+    job.d_plane[c] = d + L.plane[c];
+    job.h[c] = C.h; job.v[c] = C.v; job.blocks_x[c] = C.blocks_x; job.blocks_y[c] = C.blocks_y;
+  }
+  job.out = d_out; job.out_pitch = out_pitch;
+  return job;
+}
+
+int jpeg_enqueue(const JpegImage& J, uint8_t* d, uint8_t* d_ent, const JpegDevLayout& L, uint8_t* d_out, size_t out_pitch, hipStream_t stream, bool coef_on_device = false,
+                 bool chroma_done = false) {
+  JpegDeviceJob job = jpeg_device_job(J, d, L, d_out, out_pitch);
+  job.chroma_done = chroma_done;
   for (int c = 0; c < J.ncomp; ++c) {
     const JpegComp& C = J.comp[c];
     const size_t nblk = static_cast<size_t>(C.blocks_x) * C.blocks_y;
@@ -498,12 +514,7 @@ int jpeg_enqueue(const JpegImage& J, uint8_t* d, uint8_t* d_ent, const JpegDevLa
       if (C.coef.size() != nblk * 64) return fail(IST_E_DECODE, "JPEG component without coefficients");
       IST_HIP(hipMemcpyAsync(d_coef, C.coef.data(), nblk * 128, hipMemcpyHostToDevice, stream));
     }
-    job.d_coef[c] = d_coef;
-    job.q_host[c] = C.q;
-    job.d_plane[c] = d + L.plane[c];
-    job.h[c] = C.h; job.v[c] = C.v; job.blocks_x[c] = C.blocks_x; job.blocks_y[c] = C.blocks_y;
   }
-  job.out = d_out; job.out_pitch = out_pitch;
   return jpeg_launch_reconstruct(job, stream);
 }
 }  // namespace
@@ -631,7 +642,8 @@ class FileDecoder {
  public:
   FileDecoder(ist_ctx* ctx, const uint8_t* const* files, const int64_t* lens, int n, Phases* ph)
       : ctx_(ctx), files_(files), lens_(lens), n_(n), ph_(ph), dec_(static_cast<size_t>(n)),
-        on_gpu_(static_cast<size_t>(n), 0), taken_(static_cast<size_t>(n), 0), uploaded_(static_cast<size_t>(n), 0), started_(static_cast<size_t>(n), 0), jo_(static_cast<size_t>(n)) {}
+        on_gpu_(static_cast<size_t>(n), 0), taken_(static_cast<size_t>(n), 0), uploaded_(static_cast<size_t>(n), 0), started_(static_cast<size_t>(n), 0),
+        chroma_done_(static_cast<size_t>(n), 0), jo_(static_cast<size_t>(n)) {}
   ~FileDecoder() {
     join_all();
     for (int i = 0; i < n_; ++i) if (started_[static_cast<size_t>(i)]) (void)hipStreamSynchronize(stream_of(i));
@@ -695,9 +707,11 @@ class FileDecoder {
     if (taken_[k]) return IST_OK;
     int rc = huffman_all(consumer);
     if (rc) return rc;
+    rc = chroma_all(consumer);
+    if (rc) return rc;
     Dec& D = dec_[k];
     taken_[k] = 1;
-    if (on_gpu_[k]) return jpeg_enqueue(D.J, arena_, nullptr, jo_[k], img_[i], pitch_[i], consumer, true);
+    if (on_gpu_[k]) return jpeg_enqueue(D.J, arena_, nullptr, jo_[k], img_[i], pitch_[i], consumer, true, chroma_done_[k] != 0);
     const size_t row = static_cast<size_t>(D.w) * 4;
     if (!D.jpeg) {                                  // PNG / BMP / GIF / WebP: decoded on the thread, uploaded here
       std::vector<RowsCopy> up;
@@ -766,6 +780,21 @@ class FileDecoder {
     }
     return IST_OK;
   }
+  // the chroma planes of every image the GPU decoded, in ONE launch behind the batch (the first take() runs it: part of the
+  // reconstruction phase): each image then costs one fused launch
+  int chroma_all(hipStream_t consumer) {
+    if (chroma_batch_done_) return IST_OK;
+    chroma_batch_done_ = true;
+    std::vector<JpegDeviceJob> chroma;
+    for (int i = 0; i < n_; ++i) {
+      const size_t k = static_cast<size_t>(i);
+      if (!on_gpu_[k] || dec_[k].J.ncomp != 3) continue;
+      chroma.push_back(jpeg_device_job(dec_[k].J, arena_, jo_[k], nullptr, 0));
+      chroma_done_[k] = 1;
+    }
+    if (!chroma.empty()) return jpeg_launch_chroma_idct(chroma.data(), static_cast<int>(chroma.size()), consumer);
+    return IST_OK;
+  }
   // container + host entropy stage of image i; a baseline JPEG's de-stuffed scan goes up on the image's own stream
   void worker(int i) {
     const size_t k = static_cast<size_t>(i);
@@ -823,10 +852,10 @@ class FileDecoder {
   ist_ctx* ctx_; const uint8_t* const* files_; const int64_t* lens_; int n_; Phases* ph_;
   std::vector<Dec> dec_;
   bool running_ = false;                                       // the context's worker pool is on this call's files
-  std::vector<char> on_gpu_, taken_, uploaded_, started_;      // started_: the image's stream carries uploads of this call
+  std::vector<char> on_gpu_, taken_, uploaded_, started_, chroma_done_;      // started_: the image's stream carries uploads of this call; chroma_done_: its chroma planes were made behind the Huffman batch
   std::vector<JpegDevLayout> jo_;
   uint8_t* arena_ = nullptr; uint8_t* const* img_ = nullptr; const size_t* pitch_ = nullptr;
-  bool gpu_huffman_ = true, huff_done_ = false;
+  bool gpu_huffman_ = true, huff_done_ = false, chroma_batch_done_ = false;
 };
 
 // One stitch cut into a background launch + one launch per draw (the same cut the device group uses, ist_shard_parts with a
