@@ -7,6 +7,7 @@
 // the IJG / libjpeg-turbo decoders use by default, so that the pixels agree with the witness the tests have (PIL).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "ist_internal.h"
@@ -143,6 +144,7 @@ struct ColorArgs {
   int hs, vs;                      // luma-to-chroma ratios (1 or 2)
   int ncomp;
   uint8_t* out; size_t out_pitch;
+  int exp;                         // 0 in production.  IST_TUNING=1 IST_JPEG_EXP=bits: ablations for the kernel trace (1: no global loads, 2: no IDCT arithmetic, 4: no colour stage / stores) - wrong pixels, right clock
   uint16_t q[64];                  // luma quantisation table
 };
 
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
   // workgroup instead of two: 8 workgroups per CU live about as long as their loads take)
   const int blk_b = t >> 3;
   const int blk_x = x_org / 8 + (blk_b % BW), blk_y = y_org / 8 + (blk_b / BW);
-  const u32x4 cf = load_coef_row(blk_x < A.blocks_x && blk_y < A.blocks_y ? A.coef_y + static_cast<uint32_t>((blk_y * A.blocks_x + blk_x) * 64) : nullptr, t);
+  const u32x4 cf = load_coef_row(blk_x < A.blocks_x && blk_y < A.blocks_y && !(A.exp & 1) ? A.coef_y + static_cast<uint32_t>((blk_y * A.blocks_x + blk_x) * 64) : nullptr, t);
   if (t < 64) q9[9 * (t >> 3) + (t & 7)] = A.q[t];
   // the chroma tile: rows j_org .. j_org+9 (clamped to the plane), columns from i_org in dwords
   const int i_org = x_org / HS - 4, j_org = y_org / VS - 1;
@@ -218,7 +220,8 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
         const int pl = pr >= kChromaRows ? 1 : 0, r = pr - pl * kChromaRows;
         const uint8_t* row = (pl ? A.Cr : A.Cb) + static_cast<uint32_t>(clampi(j_org + r, 0, A.chh - 1) * A.pitch_c);      // (a plane is < 4 GB: 32-bit offsets)
         uint32_t v;
-        if (i >= 0 && i + 3 <= A.cw - 1) v = *reinterpret_cast<const uint32_t*>(row + i);
+        if (A.exp & 1) v = 0x80808080u;
+        else if (i >= 0 && i + 3 <= A.cw - 1) v = *reinterpret_cast<const uint32_t*>(row + i);
         else {
           v = 0u;
 #pragma unroll
@@ -230,10 +233,13 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
   }
   __syncthreads();
   {
-    const uint2 v = idct_rows_of_32_blocks(cf, q9, ws, t);
+    uint2 v;
+    if (A.exp & 2) { v.x = cf.x ^ cf.y; v.y = cf.z ^ cf.w; }
+    else v = idct_rows_of_32_blocks(cf, q9, ws, t);
     *reinterpret_cast<uint2*>(Ys + ((blk_b / BW) * 8 + (t & 7)) * YP + (blk_b % BW) * 8) = v;
   }
   __syncthreads();
+  if (A.exp & 4) { if (t == 0 && Ys[5] == 77 && Cs[3] == 99) A.out[0] = 1; return; }
   if (COLOUR && HS == 2 && VS == 2) {
     // 4:2:0, the photo case: a thread converts 4 pixels x 2 rows (the rows 2j, 2j+1 that share chroma row j): per plane ONE
     // two-dword LDS read per chroma row j-1, j, j+1 gives the four columns i-1 .. i+2 the eight pixels blend; the vertical 3:1 and the
@@ -386,6 +392,8 @@ int jpeg_launch_reconstruct(const JpegDeviceJob& J, void* stream_) {
   ca.cw = (J.width + J.hmax - 1) / J.hmax; ca.chh = (J.height + J.vmax - 1) / J.vmax;
   ca.ncomp = J.ncomp; ca.out = J.out; ca.out_pitch = J.out_pitch;
   for (int k = 0; k < 64; ++k) ca.q[k] = J.q_host[0] ? J.q_host[0][k] : 1;
+  static const int exp = (tuning_mode() && std::getenv("IST_JPEG_EXP")) ? std::atoi(std::getenv("IST_JPEG_EXP")) : 0;
+  ca.exp = exp;
   const int tw = J.vmax == 2 ? 128 : 256, th = 8 * J.vmax;
   const dim3 grid(static_cast<unsigned>((J.blocks_x[0] * 8 + tw - 1) / tw), static_cast<unsigned>((J.blocks_y[0] * 8 + th - 1) / th));
   if (grid.x > 0 && grid.y > 0) {
