@@ -152,6 +152,7 @@ struct CompileKnobs {
   double stream_min_k = 2.0;           // stream for |ky| >= this
   int64_t stream_cap = 12288;          // LDS words per workgroup that decide the tile width
   int area_tile_h = 0;                 // AREA_STREAM: 0 = by the box height (see the cell classification); IST_AREA_TILE_H pins it
+  int xcd_rotate = 0;                  // tile table: rotate every tile row of a band so that tile column tc sits at a launch index = tc mod 8 (IST_XCD_ROTATE, see the table builder)
   int area_passes = 1;                 // AREA_STREAM: most 64-lane passes of a tile's x footprint (IST_AREA_PASSES).  Measured (tools/sweep_area.py,
                                        // 9 x 12 MP): one pass per tile 82 us on the Android plan against 164 us with two; iOS 125 / 124, 4x 86 / 84
 };
@@ -175,6 +176,7 @@ static CompileKnobs read_knobs() {
   if ((e = std::getenv("IST_AREA_PASSES")) != nullptr) k.area_passes = std::min(3, std::max(1, std::atoi(e)));
   if ((e = std::getenv("IST_STREAM_CAP")) != nullptr) k.stream_cap = std::max<int64_t>(1024, std::atoll(e) / 4);
   if ((e = std::getenv("IST_STREAM_H")) != nullptr) k.stream_h = std::min(64, std::max(4, std::atoi(e) & ~3));
+  if ((e = std::getenv("IST_XCD_ROTATE")) != nullptr) k.xcd_rotate = std::atoi(e);
   k.no_lds = std::getenv("IST_NO_LDS") != nullptr;
   k.no_bands = std::getenv("IST_NO_BANDS") != nullptr;
   k.no_tile_table = std::getenv("IST_NO_TILE_TABLE") != nullptr;
@@ -511,12 +513,24 @@ int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4],
     for (const DevBand& b : out->bands) {
       const DevCell& f = out->cells[b.first_cell];
       const int32_t rows = (f.Y1 - f.Y0 + f.tile_h - 1) / f.tile_h;
-      for (int32_t tr = 0; tr < rows; ++tr)
+      for (int32_t tr = 0; tr < rows; ++tr) {
+        const size_t row_at = out->tiles.size();
         for (int32_t k = 0; k < b.n_cells; ++k) {
           const DevCell& c = out->cells[b.first_cell + k];
           for (int32_t tc = 0; tc < c.tiles_x; ++tc)
             out->tiles.push_back(DevTile{b.first_cell + k, c.op, c.X0 + tc * c.tile_w, c.Y0 + tr * c.tile_h});
         }
+        // XCD-aware order (experiment, IST_XCD_ROTATE=1): workgroups are dealt to the 8 XCDs round-robin by launch index
+        // (MI355X_MICROARCH.md), each XCD with its own L2.  Vertically adjacent SAMPLE_LDS tiles read the same halo rows; with
+        // 99 tiles per row the tile under tile i is at index i + 99, on another XCD, so the halo is fetched from HBM twice.
+        // Rotating row tr by (its first launch index) mod 8 puts tile column tc at an index = tc (mod 8) in every row - all but
+        // the <= 7 wrapped tiles of a row - while the walk stays canvas-row-major.
+        if (knobs.xcd_rotate && b.tiles_per_row >= 16) {
+          const size_t n_row = out->tiles.size() - row_at;
+          const size_t s = row_at % 8;                  // launch index of the row's first tile, mod 8
+          if (s) std::rotate(out->tiles.begin() + static_cast<std::ptrdiff_t>(row_at), out->tiles.begin() + static_cast<std::ptrdiff_t>(row_at + n_row - s), out->tiles.end());
+        }
+      }
     }
   }
   info.canvas_w = canvas_w; info.canvas_h = canvas_h;
