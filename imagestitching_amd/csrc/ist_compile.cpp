@@ -6,6 +6,9 @@
 // pass + one pass per image = the output written twice), the op list is decomposed into CELLS — canvas rectangles
 // over which the paint stack is constant — so that one launch writes every output pixel exactly once.
 #include <algorithm>
+#include <utility>
+#include <string>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -159,6 +162,30 @@ struct CompileKnobs {
 bool tuning_mode() {
   static const bool on = [] { const char* e = std::getenv("IST_TUNING"); return e && *e && std::strcmp(e, "0") != 0; }();
   return on;
+}
+namespace {
+struct Timeline { bool on = false; std::chrono::steady_clock::time_point t0; std::vector<std::pair<double, std::string>> marks; };
+Timeline& tl() { thread_local Timeline t; return t; }
+bool tl_enabled() { static const bool on = tuning_mode() && std::getenv("IST_TIMELINE") != nullptr; return on; }
+}  // namespace
+void tl_begin() { if (!tl_enabled()) return; Timeline& t = tl(); t.on = true; t.marks.clear(); t.t0 = std::chrono::steady_clock::now(); }
+void tl_mark(const char* what, long a) {
+  if (!tl_enabled()) return;
+  Timeline& t = tl();
+  if (!t.on) return;
+  t.marks.emplace_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t.t0).count(), a >= 0 ? std::string(what) + " " + std::to_string(a) : std::string(what));
+}
+void tl_end(const char* what) {
+  if (!tl_enabled()) return;
+  Timeline& t = tl();
+  if (!t.on) return;
+  t.on = false;
+  const double total = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t.t0).count();
+  static const double slow_ms = std::getenv("IST_TIMELINE_SLOW_MS") ? std::atof(std::getenv("IST_TIMELINE_SLOW_MS")) : 0.0;
+  if (total < slow_ms * 1e3) return;
+  std::fprintf(stderr, "[ist timeline] ---- %s: %.1f us\n", what, total);
+  double prev = 0.0;
+  for (const auto& m : t.marks) { std::fprintf(stderr, "[ist timeline] %9.1f us  (+%8.1f)  %s\n", m.first, m.first - prev, m.second.c_str()); prev = m.first; }
 }
 static CompileKnobs read_knobs() {
   CompileKnobs k;

@@ -108,6 +108,13 @@ void dev_free(void* p);
 
 // true when the process was started with IST_TUNING=1 (decided once): only then are tuning knobs read from the environment
 bool tuning_mode();
+// Host-side marks of ONE call (IST_TUNING=1 IST_TIMELINE=1 processes only; no-ops otherwise): tl_begin() starts the call's clock,
+// tl_mark() notes a point (microseconds from the start, thread-local), tl_end() prints the list to stderr - only when the call took
+// at least IST_TIMELINE_SLOW_MS milliseconds (default 0: every call), so that a run of hundreds of calls names what the RARE slow
+// call waited for without printing the others.
+void tl_begin();
+void tl_mark(const char* what, long a = -1);
+void tl_end(const char* what);
 
 // resolve + cell decomposition (host, pure CPU).  Returns IST_OK or an error code (g_last_error set).
 int compile_ops(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,

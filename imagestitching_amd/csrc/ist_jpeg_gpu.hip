@@ -668,6 +668,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     *h_flag = 1u;
     JG_HIP(hipMemcpyAsync(const_cast<uint32_t*>(h_flag), d_flag, 4, hipMemcpyDeviceToHost, stream));
     JG_HIP(hipStreamSynchronize(stream));
+    tl_mark("huffman: synchronisation launch done, pass", static_cast<long>(pass));
     if (!*h_flag) { converged = true; break; }
   }
   if (timing) std::fprintf(stderr, "[ist timing] GPU Huffman: %d subsequences of %d bits, %s after %d launches\n", ns, kSubBits, converged ? "fixed point" : "NO fixed point", passes_run);
@@ -683,6 +684,7 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
   JG_HIP(hipMemcpyAsync(h_half, d_half, 16 * static_cast<size_t>(n_half), hipMemcpyDeviceToHost, stream));
   JG_HIP(hipMemcpyAsync(h_err, d + o_err, 4 * n_unit, hipMemcpyDeviceToHost, stream));
   JG_HIP(hipStreamSynchronize(stream));
+  tl_mark("huffman: writing pass done, validation read back");
   for (size_t k = 0; k < n_img; ++k) {
     bool good = !skip[k];
     for (size_t w = first_unit[k]; w < first_unit[k + 1]; ++w) {              // every restart interval holds exactly its MCUs

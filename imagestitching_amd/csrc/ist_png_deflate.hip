@@ -681,6 +681,7 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
     A.dbg = d_dbg;
     hipLaunchKernelGGL(ist_png_deflate_kernel, dim3(static_cast<unsigned>(cn)), dim3(256), 0, st, A);
     PNG_HIP(hipGetLastError());
+    tl_mark("png:   compression launched, slab", static_cast<long>(s));
     PNG_HIP(hipEventCreateWithFlags(&evs.ev[s], hipEventDisableTiming));
     PNG_HIP(hipEventRecord(evs.ev[s], st));
     return IST_OK;
@@ -737,8 +738,9 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
   };
   for (size_t s = 0; s < n_slabs; ++s) {
     const size_t c0 = slab_at[s], cn = slab_at[s + 1] - c0;
-    if (s + 1 < n_slabs) { const int rc = compress(s + 1); if (rc) return rc; }
+    if (s + 1 < n_slabs) { const int rc = compress(s + 1); if (rc) return rc; tl_mark("png: submitted the compression of slab", static_cast<long>(s + 1)); }
     PNG_HIP(hipEventSynchronize(evs.ev[s]));
+    tl_mark("png: compressed (event passed), slab", static_cast<long>(s));
     if (fail_at >= 0 && static_cast<size_t>(fail_at) == s) return fail(IST_E_HIP, "PNG deflate kernel returned an impossible chunk length (forced: IST_PNG_FAIL_AT)");
     const uint8_t* r = res.p + 20 * per_slab * s;
     const uint32_t* len16 = reinterpret_cast<const uint32_t*>(r);
@@ -785,14 +787,17 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
     // (Tried and dropped: the gather writing straight into the pinned file image with a small grid, no device image and no
     // copy - 4-byte-aligned 16-byte stores over PCIe from 128 workgroups were slower than gather + the runtime's copy: the phase
     // went from 3.66 to 4.23 ms.)
+    tl_mark("png:   host layout done, slab", static_cast<long>(s));
     hipStream_t gs = host_out ? ((s & 1) ? stream2 : stream) : aux;
     GatherArgs G{scratch + o_slots, static_cast<uint8_t*>(out), dst, reinterpret_cast<const uint32_t*>(res.p + 20 * per_slab * s) - c0, static_cast<int64_t>(c0)};
     hipLaunchKernelGGL(ist_png_gather_kernel, dim3(static_cast<unsigned>(cn)), dim3(256), 0, gs, G);
     PNG_HIP(hipGetLastError());
+    tl_mark("png:   gather launched, slab", static_cast<long>(s));
     if (host_out) {
       PNG_HIP(hipEventCreateWithFlags(&gathered.ev[s], hipEventDisableTiming));
       PNG_HIP(hipEventRecord(gathered.ev[s], gs));
       PNG_HIP(hipStreamWaitEvent(aux, gathered.ev[s], 0));
+      tl_mark("png:   event created + recorded + aux ordered behind it, slab", static_cast<long>(s));
     }
     if (!host_out)                                     // (with a host sink the headers are written there, below)
       for (const Patch& pt : patches)
@@ -807,12 +812,23 @@ int png_encode_device_deflate(ist_ctx* ctx, const void* canvas, size_t pitch, in
         hipLaunchKernelGGL(ist_png_to_host_kernel, dim3(static_cast<unsigned>(copy_grid)), dim3(256), 0, aux, reinterpret_cast<const u32x4*>(static_cast<const uint8_t*>(out) + c_lo),
                            reinterpret_cast<u32x4*>(host_out + c_lo), (c_hi - c_lo) / 16);
         PNG_HIP(hipGetLastError());
-      } else if (!skip_d2h) PNG_HIP(hipMemcpyAsync(host_out + c_lo, static_cast<const uint8_t*>(out) + c_lo, static_cast<size_t>(c_hi - c_lo), hipMemcpyDeviceToHost, aux));
+      } else if (!skip_d2h) {
+        // (round 4, tools/exp_slow_call.py + the marks around this call: one call in 600 - 3000 loses 6.5 - 7.3 ms INSIDE this
+        // hipMemcpyAsync - the runtime's submission of one slab's device-to-host copy, slab 4, 8 or 9, on four different boxes; the
+        // only stall of the call that is neither a wait of ours nor host scheduling.  Bounding the copies queued on the aux stream to
+        // four - waiting for copy s-4's event before submitting copy s - did not remove it (1 and 3 such calls in 2 x 3000, against 2
+        // and 1 unbounded) and cost 0.15 - 0.2 ms of the median call: dropped.)
+        PNG_HIP(hipMemcpyAsync(host_out + c_lo, static_cast<const uint8_t*>(out) + c_lo, static_cast<size_t>(c_hi - c_lo), hipMemcpyDeviceToHost, aux));
+      }
+      tl_mark("png: laid out, gather + copy submitted, slab", static_cast<long>(s));
     }
   }
+  tl_mark("png: every slab submitted; waiting for the copies (aux stream)");
   PNG_HIP(hipStreamSynchronize(aux));
+  tl_mark("png: aux stream idle (the file is in host memory)");
   if (aux != stream) PNG_HIP(hipStreamSynchronize(stream));
   if (stream2 != stream) PNG_HIP(hipStreamSynchronize(stream2));
+  tl_mark("png: encoder streams idle");
   drain.armed = false;                                 // the streams are idle
   if (d_dbg) {
     std::vector<unsigned long long> hdbg(8 * n);

@@ -754,7 +754,9 @@ class FileDecoder {
   // every worker has returned; ONE Huffman batch over the eligible images on `consumer`, behind their scan uploads
   int huffman_all(hipStream_t consumer) {
     if (huff_done_) return IST_OK;
+    tl_mark("decoder: waiting for the per-image host work");
     join_all();
+    tl_mark("decoder: host work of every image done");
     int rc = first_error();
     if (rc) return rc;
     huff_done_ = true;
@@ -992,9 +994,9 @@ int stitch_files_png_locked(ist_ctx* ctx, const uint8_t* const* files, const int
   DeviceGuard g(ctx->device);
   Phases ph(ctx);
   // (IST_TUNING=1 IST_TIMELINE=1: host-side marks of one call on stderr, microseconds from its start)
-  static const bool timeline = tuning_mode() && std::getenv("IST_TIMELINE") != nullptr;
-  const auto tl0 = std::chrono::steady_clock::now();
-  auto mark = [&](const char* what) { if (timeline) std::fprintf(stderr, "[ist timeline] %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl0).count(), what); };
+  tl_begin();
+  struct TlEnd { ~TlEnd() { tl_end("ist_stitch_files_png"); } } tl_end_guard;
+  auto mark = [&](const char* what) { tl_mark(what); };
   FileDecoder fd(ctx, files, lens, n, &ph);
   int rc = fd.headers();
   if (rc) return rc;
