@@ -169,6 +169,7 @@ Timeline& tl() { thread_local Timeline t; return t; }
 bool tl_enabled() { static const bool on = tuning_mode() && std::getenv("IST_TIMELINE") != nullptr; return on; }
 }  // namespace
 void tl_begin() { if (!tl_enabled()) return; Timeline& t = tl(); t.on = true; t.marks.clear(); t.t0 = std::chrono::steady_clock::now(); }
+bool tl_active() { return tl_enabled() && tl().on; }
 void tl_mark(const char* what, long a) {
   if (!tl_enabled()) return;
   Timeline& t = tl();

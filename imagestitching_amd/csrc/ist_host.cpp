@@ -258,12 +258,15 @@ void WorkerPool::run(int n, std::function<void(int)> fn) {
   if (n <= 0) return;
   {
     std::lock_guard<std::mutex> lock(mu_);
+    tl_mark("pool: queue locked");
     fn_ = std::move(fn);
     next_ = 0; done_ = 0; total_ = n;
     const size_t want = static_cast<size_t>(n < kMaxThreads ? n : kMaxThreads);
     while (th_.size() < want) th_.emplace_back([this]() { loop(); });
   }
+  tl_mark("pool: tasks posted");
   work_cv_.notify_all();
+  tl_mark("pool: workers notified");
 }
 
 void WorkerPool::wait() {

@@ -113,6 +113,7 @@ bool tuning_mode();
 // at least IST_TIMELINE_SLOW_MS milliseconds (default 0: every call), so that a run of hundreds of calls names what the RARE slow
 // call waited for without printing the others.
 void tl_begin();
+bool tl_active();                         // a call's clock is running on this thread
 void tl_mark(const char* what, long a = -1);
 void tl_end(const char* what);
 

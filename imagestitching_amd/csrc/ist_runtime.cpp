@@ -994,8 +994,9 @@ int stitch_files_png_locked(ist_ctx* ctx, const uint8_t* const* files, const int
   DeviceGuard g(ctx->device);
   Phases ph(ctx);
   // (IST_TUNING=1 IST_TIMELINE=1: host-side marks of one call on stderr, microseconds from its start)
-  tl_begin();
-  struct TlEnd { ~TlEnd() { tl_end("ist_stitch_files_png"); } } tl_end_guard;
+  const bool tl_outer = tl_active();                      // (ist_stitch_paths_png started the call's clock: its file reads are part of the call)
+  if (!tl_outer) tl_begin();
+  struct TlEnd { bool mine; ~TlEnd() { if (mine) tl_end("ist_stitch_files_png"); } } tl_end_guard{!tl_outer};
   auto mark = [&](const char* what) { tl_mark(what); };
   FileDecoder fd(ctx, files, lens, n, &ph);
   int rc = fd.headers();
@@ -1195,7 +1196,10 @@ int ist_stitch_paths_png(ist_ctx* ctx, const char* const* paths, int n_images, i
   // with plain loads, so a file that another process rewrites or truncates while it is mapped would change under them
   // (a different layout on the second read) or raise SIGBUS in a worker thread and take the host process down.
   // A short read - the file shrank between fstat and read - is an error of that image.
+  tl_begin();
+  struct TlEnd { ~TlEnd() { tl_end("ist_stitch_paths_png"); } } tl_end_guard;
   std::lock_guard<std::mutex> lock(ctx->mu);
+  tl_mark("paths: context locked");
   const size_t n = static_cast<size_t>(n_images);
   constexpr size_t kKeepFileBytes = size_t{64} << 20;
   if (ctx->file_bufs.size() < n) ctx->file_bufs.resize(n);
@@ -1234,8 +1238,11 @@ int ist_stitch_paths_png(ist_ctx* ctx, const char* const* paths, int n_images, i
   if (n_images == 1) read_one(0);
   else {
     if (!ctx->workers) ctx->workers.reset(new WorkerPool());
+    tl_mark("paths: files opened");
     ctx->workers->run(n_images, read_one);
+    tl_mark("paths: read tasks handed out");
     ctx->workers->wait();
+    tl_mark("paths: files read");
   }
   for (size_t i = 0; i < n; ++i) {
     if (bad[i] == 1) return fail(IST_E_NOMEM, "out of memory for the bytes of image " + std::to_string(i));
