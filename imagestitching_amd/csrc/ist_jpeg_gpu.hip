@@ -204,16 +204,52 @@ struct Tally { uint32_t blocks; int32_t dc[3]; };
 constexpr uint32_t kCheckBits = 256;
 struct Check { uint32_t p, cz; Tally t; };
 
+// THE COUNTING STEP'S OWN TABLE (round 4).  The synchronisation passes need of a symbol only what it does to the state: how many
+// bits it takes (code + magnitude bits) and where it leaves the zig-zag index.  For every look-ahead pattern that holds a whole code
+// (9 bits: ~98 % of a photo's symbols) that is one 16-bit entry, made from the scan's look-ahead tables when a workgroup stages them:
+//   bits 0-4   code length + magnitude bits         bits 5-9   what an AC symbol adds to the zig-zag index (run + 1; 16 for ZRL)
+//   bit 10     end of block                          bits 11-14 the code's own length (a DC symbol's value starts behind it)
+// 0 = the pattern is longer than the look-ahead, or no code: the general step (symbol<>) takes it.  The state a symbol leaves is
+// the same either way - it must be: the writing pass walks the stream with the general step from the states these passes agree on.
+// A lone lane's chain per symbol falls from ~70 dependent instructions to ~40 (it is latency, not issue, that paces these passes).
+constexpr uint32_t kFastEob = 0x400u;
+__device__ __forceinline__ uint16_t fast_entry(uint32_t e, bool isdc) {
+  if (!e) return 0;
+  const uint32_t L = e >> 8, rs = e & 255u;
+  if (isdc) {
+    const uint32_t sz = (rs > 0 && rs <= 15) ? rs : 0u;      // (symbol<>: the same rule)
+    return static_cast<uint16_t>((L + sz) | (1u << 5) | (L << 11));
+  }
+  const uint32_t r = rs >> 4, sz = rs & 15u;
+  if (sz == 0) return static_cast<uint16_t>(L | (r == 15 ? (16u << 5) : kFastEob) | (L << 11));
+  return static_cast<uint16_t>((L + sz) | ((r + 1) << 5) | (L << 11));
+}
+static_assert(kJpegDcLookBits == 9 && kJpegAcLookBits == 9, "fast table: 512 entries per table, code + magnitude bits <= 24 < 32");
+
 template <int THREADS>
-__device__ __forceinline__ Tally run_count(const WgShared<THREADS>* sh, uint32_t first_bit, State& S, uint32_t limit, uint32_t mid,
+__device__ __forceinline__ Tally run_count(const WgShared<THREADS>* sh, const uint16_t* fast, uint32_t first_bit, State& S, uint32_t limit, uint32_t mid,
                                            bool have_ref, uint32_t old_p, uint32_t old_cz, const Tally& old_t, Check& ck) {
   Tally T; T.blocks = 0; T.dc[0] = T.dc[1] = T.dc[2] = 0;
   const uint32_t slots = static_cast<uint32_t>(sh->img.slots);
   uint32_t tabs = sh->slot_tabs[S.c];
+  // (measured and dropped, round 4: keeping the bits at S.p in a register between symbols - one two-word LDS read per ~4 symbols
+  // instead of one per symbol - changed nothing: sync launch 817-894 us against 808-881 us)
   auto leg = [&](uint32_t until) {
     while (S.p < until) {
-      uint32_t at = 1; int val = 0; bool stored, bad;
-      symbol<false>(sh, first_bit, S, tabs, &at, &val, &stored, &bad);
+      const bool isdc = S.z == 0;
+      const uint64_t w = window(sh, first_bit, S.p);
+      const uint32_t f = fast[(((isdc ? 0u : 2u) + ((isdc ? tabs : (tabs >> 8)) & 1u)) << 9) + static_cast<uint32_t>(w >> 55)];
+      uint32_t at = 1; int val = 0; bool stored = false, bad;
+      if (f) {
+        const uint32_t tot = f & 31u;
+        if (isdc) {
+          const uint32_t L = (f >> 11) & 15u, sz = tot - L;
+          val = sz ? extend_bits(static_cast<uint32_t>((w << L) >> (64 - sz)), static_cast<int>(sz)) : 0;
+          at = 0; stored = true;
+          S.z = 1;
+        } else S.z = (f & kFastEob) ? 64u : S.z + ((f >> 5) & 31u);
+        S.p += tot;
+      } else symbol<false>(sh, first_bit, S, tabs, &at, &val, &stored, &bad);
       if (stored && at == 0) {
         const uint32_t comp = tabs >> 16;
         T.dc[0] += comp == 0 ? val : 0; T.dc[1] += comp == 1 ? val : 0; T.dc[2] += comp == 2 ? val : 0;
@@ -353,6 +389,7 @@ __global__ __launch_bounds__(kSyncBlock) void ist_jpeg_sync_kernel(const SyncArg
   static_assert(kSyncThreads % 128 == 0 && kHalves >= 1 && kHalves <= 2, "half totals");
   __shared__ uint32_t tot[kHalves][4];
   __shared__ WgShared<kSyncThreads + kGhosts> sh;
+  __shared__ uint16_t fast[4 << 9];                              // the counting step's table: DC 0, DC 1, AC 0, AC 1
   const int tid = threadIdx.x;
   const bool owned = tid < kSyncThreads;
   const int g0 = blockIdx.x * kSyncThreads;                      // (the grid is exactly the padded subsequence count / kSyncThreads)
@@ -394,6 +431,8 @@ __global__ __launch_bounds__(kSyncBlock) void ist_jpeg_sync_kernel(const SyncArg
   bool settled = !any;
   if (any) {
     load_stream(&sh, gimg, first_bit);
+    for (int k = tid; k < (4 << 9); k += kSyncBlock) fast[k] = fast_entry(k < (2 << 9) ? sh.tab.look_dc[k >> 9][k & 511] : sh.tab.look_ac[(k >> 9) - 2][k & 511], k < (2 << 9));
+    __syncthreads();
     for (int it = 0; it < kInnerPasses; ++it) {
       uint32_t sp = 0, scz = 0;
       if (live && i != 0) {                            // (the first subsequence of an image starts from the true state 0, 0, 0)
@@ -409,7 +448,7 @@ __global__ __launch_bounds__(kSyncBlock) void ist_jpeg_sync_kernel(const SyncArg
       const bool redo = live && !(have && st_p == sp && st_cz == scz);
       if (redo) {
         State S; S.p = sp; S.c = scz >> 8; S.z = scz & 255u;
-        T = run_count(&sh, first_bit, S, limit, i * static_cast<uint32_t>(kSubBits) + kCheckBits, have, my_p, my_cz, T, ck);
+        T = run_count(&sh, fast, first_bit, S, limit, i * static_cast<uint32_t>(kSubBits) + kCheckBits, have, my_p, my_cz, T, ck);
         my_p = S.p; my_cz = (S.c << 8) | S.z;
         st_p = sp; st_cz = scz; have = true;
       }
