@@ -233,7 +233,9 @@ __device__ __forceinline__ Tally run_count(const WgShared<THREADS>* sh, const ui
   const uint32_t slots = static_cast<uint32_t>(sh->img.slots);
   uint32_t tabs = sh->slot_tabs[S.c];
   // (measured and dropped, round 4: keeping the bits at S.p in a register between symbols - one two-word LDS read per ~4 symbols
-  // instead of one per symbol - changed nothing: sync launch 817-894 us against 808-881 us)
+  // instead of one per symbol - changed nothing: sync launch 817-894 us against 808-881 us; nor did a pad word per 32 words of the
+  // staged stream, which takes the lanes of a wave - 32 words apart - off each other's LDS bank: 801-893 us, writing pass 234-238
+  // against 229-237 us)
   auto leg = [&](uint32_t until) {
     while (S.p < until) {
       const bool isdc = S.z == 0;
