@@ -13,6 +13,8 @@ import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libimagestitch.so")
+if os.environ.get("IST_TUNING") == "1" and os.environ.get("IST_LIB_PATH"):      # experiments: a variant build of the library (tools/sweep_*.py)
+    LIB_PATH = os.environ["IST_LIB_PATH"]
 
 VERTICAL, HORIZONTAL = 0, 1
 MODE_MIN, MODE_MAX, MODE_ORIGINAL = 0, 1, 2

@@ -1053,8 +1053,11 @@ __global__ __launch_bounds__(256) void ist_stitch_kernel(const LaunchArgs A, con
 
 // the instantiation that carries the streamed box filter: held to 5 waves per SIMD (it compiled to 103 VGPRs, one register
 // past that step)
+#ifndef IST_AREA_WAVES          // (compile-time experiment switch: -DIST_AREA_WAVES=6 rebuilds the variant LAB_NOTES.md quotes)
+#define IST_AREA_WAVES 5
+#endif
 template <int PATHS, int V, bool PERSIST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void ist_stitch_area_kernel(const LaunchArgs A, const int64_t n_tiles) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IST_AREA_WAVES))) void ist_stitch_area_kernel(const LaunchArgs A, const int64_t n_tiles) {
   if (PERSIST) {
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) run_tile<PATHS, V>(A, t, false);
   } else {

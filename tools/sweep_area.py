@@ -38,8 +38,15 @@ for name, o in plans:
 print(json.dumps(out))
 ''' % ROOT
 
-ARMS = [("default", {}), ("h32", {"IST_AREA_TILE_H": "32"}), ("p2", {"IST_AREA_PASSES": "2"}),
-        ("per_pixel_general_path", {"IST_NO_LDS": "1"})]      # the last arm: what filter 'area' cost before the streamed path existed
+V = os.path.join(ROOT, "tools", "exp", "variants")
+ARMS = [("default (5 waves per SIMD, 96 VGPRs)", {}), ("h32", {"IST_AREA_TILE_H": "32"}), ("p2", {"IST_AREA_PASSES": "2"})]
+# variant builds of the library (make ... CXXFLAGS+=-DIST_AREA_WAVES=6 OUT=tools/exp/variants/libimagestitch_areaw6.so), when present
+for w in (6, 7):
+    lib = os.path.join(V, "libimagestitch_areaw%d.so" % w)
+    if os.path.exists(lib):
+        ARMS.append(("%d waves per SIMD (spills)" % w, {"IST_LIB_PATH": lib}))
+if "--with-general" in sys.argv:
+    ARMS.append(("per_pixel_general_path", {"IST_NO_LDS": "1"}))      # what filter 'area' cost before the streamed path existed
 for rnd in range(2):
     for name, env in ARMS:
         e = dict(os.environ, IST_TUNING="1", **env)
