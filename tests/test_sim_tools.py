@@ -27,6 +27,9 @@ def test_slot_sync_simulation_builds_and_runs(tmp_path):
     Image.fromarray(a.clip(0, 255).astype(np.uint8)).save(b, "JPEG", quality=90, subsampling=2)
     (tmp_path / "p.jpg").write_bytes(b.getvalue())
     out = subprocess.run([exe, str(tmp_path / "p.jpg")], check=True, capture_output=True, text=True, timeout=120).stdout
+    # round 4: the replay of the kernel's pass iteration, one start hypothesis per subsequence against two
+    m = re.search(r"one hypothesis: worst (\d+), two hypotheses: worst (\d+)", out)
+    assert m and 1 <= int(m.group(1)) <= 40 and 1 <= int(m.group(2)) <= 40, out
     rows = re.findall(r"exit true ([0-9.]+) \| slot wrong only ([0-9.]+) \| elsewhere ([0-9.]+)", out)
     assert len(rows) == 2, out
     for r in rows:

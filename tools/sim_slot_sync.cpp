@@ -85,6 +85,83 @@ int main(int argc, char** argv) {
     const St e = run(St{static_cast<int64_t>(i) * SUB, 0, 0}, lim);
     if (e.p == T1.p && e.z == T1.z) { if (e.c == T1.c) ++g_ok; else ++g_pz; } else ++g_bad;
   }
+  // ---- how many passes does a workgroup of the synchronisation kernel need?  (round 4)  Replays the kernel's iteration - 128 owned
+  // subsequences + up to 8 ghost lanes in front, pass 0 from guesses, pass k from the left neighbour's exit of pass k-1, a lane
+  // re-decodes only when its start state changed - for (A) the shipped scheme, one start hypothesis per lane, and (B) TWO: every lane
+  // keeps the exits of two different starts (pass 0: the guess with slot 0 and with the first chroma slot; pass k: both exits of
+  // its left neighbour) and the true chain is picked at the end.  A launch costs as much as its slowest workgroup.
+  {
+    const int WG = 128, GH = 8;
+    auto eq = [](const St& a, const St& b) { return a.p == b.p && a.c == b.c && a.z == b.z; };
+    int chroma_slot = 0;
+    for (int k = 0; k < G.slots; ++k) if (G.slot_comp[k] != G.slot_comp[0]) { chroma_slot = k; break; }
+    std::vector<int> hist_a(64, 0), hist_b(64, 0);
+    int worst_a = 0, worst_b = 0;
+    for (int g0 = 0; g0 < nsub; g0 += WG) {
+      const int first = std::max(0, g0 - GH), last = std::min(nsub, g0 + WG);        // lanes [first, last): ghosts, then owned
+      const int L = last - first;
+      // (A)
+      {
+        std::vector<St> start(static_cast<size_t>(L)), ex(static_cast<size_t>(L));
+        std::vector<char> have(static_cast<size_t>(L), 0);
+        int passes = 0;
+        for (int it = 0; it < 64; ++it) {
+          std::vector<St> nex = ex;
+          bool any = false;
+          for (int e = 0; e < L; ++e) {
+            const int i = first + e;
+            St sp;
+            if (i == 0) sp = St{0, 0, 0};
+            else if (it == 0 || e == 0) sp = St{static_cast<int64_t>(i) * SUB, 0, 0};
+            else sp = ex[static_cast<size_t>(e) - 1];
+            if (have[static_cast<size_t>(e)] && eq(start[static_cast<size_t>(e)], sp)) continue;
+            nex[static_cast<size_t>(e)] = run(sp, std::min<int64_t>((i + 1) * SUB, G.bits));
+            start[static_cast<size_t>(e)] = sp; have[static_cast<size_t>(e)] = 1; any = true;
+          }
+          ex = nex;
+          if (!any) break;
+          ++passes;
+        }
+        hist_a[static_cast<size_t>(std::min(passes, 63))]++; worst_a = std::max(worst_a, passes);
+      }
+      // (B)
+      {
+        struct Two { St s[2], x[2]; int n = 0; };
+        std::vector<Two> cur(static_cast<size_t>(L));
+        int passes = 0;
+        for (int it = 0; it < 64; ++it) {
+          std::vector<Two> nxt = cur;
+          bool any = false;
+          for (int e = 0; e < L; ++e) {
+            const int i = first + e;
+            St cand[2]; int nc = 0;
+            if (i == 0) { cand[nc++] = St{0, 0, 0}; }
+            else if (it == 0 || e == 0) { cand[nc++] = St{static_cast<int64_t>(i) * SUB, 0, 0}; cand[nc++] = St{static_cast<int64_t>(i) * SUB, chroma_slot, 0}; }
+            else { const Two& l = cur[static_cast<size_t>(e) - 1]; for (int k = 0; k < l.n; ++k) { bool dup = false; for (int q = 0; q < nc; ++q) dup = dup || eq(cand[q], l.x[k]); if (!dup) cand[nc++] = l.x[k]; } }
+            Two t; t.n = nc;
+            for (int k = 0; k < nc; ++k) {
+              t.s[k] = cand[k];
+              bool known = false;
+              for (int q = 0; q < cur[static_cast<size_t>(e)].n; ++q) if (eq(cur[static_cast<size_t>(e)].s[q], cand[k])) { t.x[k] = cur[static_cast<size_t>(e)].x[q]; known = true; }
+              if (!known) { t.x[k] = run(cand[k], std::min<int64_t>((i + 1) * SUB, G.bits)); any = true; }
+            }
+            nxt[static_cast<size_t>(e)] = t;
+          }
+          cur = nxt;
+          if (!any) break;
+          ++passes;
+        }
+        // the chain from the workgroup's first lane: is every owned lane's true exit among its candidates?  (it must be, once settled)
+        hist_b[static_cast<size_t>(std::min(passes, 63))]++; worst_b = std::max(worst_b, passes);
+      }
+    }
+    std::printf("passes a workgroup needs (first launch; %d subsequences + %d ghost lanes per workgroup): one hypothesis: worst %d, two hypotheses: worst %d\n", WG, GH, worst_a, worst_b);
+    std::printf("  histogram, one hypothesis :");
+    for (int k = 0; k < 64; ++k) if (hist_a[static_cast<size_t>(k)]) std::printf(" %d:%d", k, hist_a[static_cast<size_t>(k)]);
+    std::printf("\n  histogram, two hypotheses:");
+    for (int k = 0; k < 64; ++k) if (hist_b[static_cast<size_t>(k)]) std::printf(" %d:%d", k, hist_b[static_cast<size_t>(k)]);
+    std::printf("\n");
+  }
   const double t = static_cast<double>(same + pz_only + diff), tg = static_cast<double>(g_ok + g_pz + g_bad);
   std::printf("%d subsequences of %lld bits, %d blocks per MCU\n", nsub, static_cast<long long>(SUB), G.slots);
   std::printf("start = true (position, index), wrong slot:   exit true %.3f | slot wrong only %.3f | elsewhere %.3f\n", same / t, pz_only / t, diff / t);
