@@ -550,6 +550,8 @@ class Solo:
         if self.rank == 0:
             try:
                 res = fn()
+            except Exception as ex:          # an informational comparator never takes the line (or the other ranks) down
+                res = ({"error": repr(ex)}, 0)
             finally:
                 if self.store is not None:
                     self.store.set(key, "done")
@@ -609,23 +611,34 @@ def run_sharded(args):
     def sharded_suite(sizes, direction, split, want, steps, big):
         """one workload cut one way: its regions on all ranks.  Returns (regions, gather facts, seconds of `resident`)."""
         imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in sizes]
-        sh = D.ShardedStitch(imgs, direction, {"filter": "bilinear"}, rank, world, 0, split=split)
-        mp = sh.plan.canvas_w * sh.plan.canvas_h / 1e6
-        be = D.HipBackend(sh, local)
-        need = sh.rows_needed()
-        # this rank's holdings: only the source rows its parts sample (+ one spare row), in HBM and in pinned host memory
-        dsrc, hsrc = [None] * len(sizes), {}
-        for i, (a, b) in need.items():
-            if big:                                   # synthesised on the device (12.3 GB in numpy would take minutes)
-                t = device_noise(torch, b - a, sizes[i][0], dev)
-                hsrc[i] = torch.empty((b - a, sizes[i][0], 4), dtype=torch.uint8).pin_memory()
-                hsrc[i].copy_(t)
-            else:
-                t = D.alloc_rows(torch, b - a, sizes[i][0], dev)
-                hsrc[i] = torch.from_numpy(synth_np(i, *sizes[i])[a:b]).pin_memory()
-                t.copy_(hsrc[i])
-            dsrc[i] = D.SourceRows(t, a)
-        canvas = be.new_canvas() if rank == 0 else None
+        # SET-UP (no collective inside): a rank that cannot allocate says so, and ALL ranks leave the suite together - a rank that
+        # raised alone would leave the others in the next collective until the launch times out, and the line would be lost
+        err = None
+        try:
+            sh = D.ShardedStitch(imgs, direction, {"filter": "bilinear"}, rank, world, 0, split=split)
+            mp = sh.plan.canvas_w * sh.plan.canvas_h / 1e6
+            be = D.HipBackend(sh, local)
+            need = sh.rows_needed()
+            # this rank's holdings: only the source rows its parts sample (+ one spare row), in HBM and in pinned host memory
+            dsrc, hsrc = [None] * len(sizes), {}
+            for i, (a, b) in need.items():
+                if big:                                   # synthesised on the device (12.3 GB in numpy would take minutes)
+                    t = device_noise(torch, b - a, sizes[i][0], dev)
+                    hsrc[i] = torch.empty((b - a, sizes[i][0], 4), dtype=torch.uint8).pin_memory()
+                    hsrc[i].copy_(t)
+                else:
+                    t = D.alloc_rows(torch, b - a, sizes[i][0], dev)
+                    hsrc[i] = torch.from_numpy(synth_np(i, *sizes[i])[a:b]).pin_memory()
+                    t.copy_(hsrc[i])
+                dsrc[i] = D.SourceRows(t, a)
+            canvas = be.new_canvas() if rank == 0 else None
+        except Exception as ex:
+            err = repr(ex)
+        bad = torch.tensor([1 if err else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            torch.cuda.empty_cache()
+            return {"set-up": {"error": err or "another rank could not set this suite up"}}, {"split": split}, None
         regions = {}
 
         def upload():
@@ -720,6 +733,8 @@ def run_sharded(args):
     for split in ("image", "band"):
         r, g, t_res = sharded_suite(UNIFORM, "vertical", split, all_regions if split == "image" else all_regions - {"from_jpeg"}, args.steps, False)
         if split == "image":
+            if t_res is None:
+                raise SystemExit("bench.py: the headline suite could not be set up: %s" % r)
             value_sec = t_res
         for k, v in r.items():
             regions["%s/%s" % (k, split)] = v
@@ -756,7 +771,7 @@ def run_sharded(args):
                            "scaling": scaling_table({"%s/image" % k: v for k, v in r5.items()}, one5[0]) if one5 else {},
                            "what": "BASELINE configs[4]: 64 x 8000x6000 vertical -> 8000x384000 (3072 MP), image i on GPU i mod %d (%d per GPU), inputs synthesised on "
                                    "the devices; resident = bands gathered into GPU 0's canvas (%.2f GB over xGMI per step), host_in_host_out = every GPU uploads its "
-                                   "images and delivers its bands over its own PCIe link, no gather" % (world, (64 + world - 1) // world, g5["bytes_into_gpu0_per_step"] / 1e9)}
+                                   "images and delivers its bands over its own PCIe link, no gather" % (world, (64 + world - 1) // world, g5.get("bytes_into_gpu0_per_step", 0) / 1e9)}
 
     # informational: N independent replicas (every GPU stitches a whole 9 x 12 MP job; no exchange) = the layout a
     # stitching service would use when jobs are independent
