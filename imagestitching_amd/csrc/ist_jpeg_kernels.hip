@@ -167,13 +167,13 @@ __device__ __forceinline__ uint32_t ycc_to_rgba(int Yv, int cb, int cr) {
 // chroma samples (+ halo, from L2) in, 4 B of RGBA out; the chroma planes cost their own 1 B + 0.5 B in the launch before: 8 B in
 // all against 10 B of the unfused pair (coefficients 3, planes out and in 1.5 + 1.5, RGBA 4), and every global access is a whole
 // 16-byte lane.  The arithmetic is unchanged (bit-exact against libjpeg-turbo's defaults, tests/test_gpu_jpeg.py).
-constexpr int kTileYPitchNarrow = 144, kTileYPitchWide = 272;      // bytes per luma tile row (128 / 256 px): 16 mod 128 keeps the row writes of step 3 off each other's banks
-constexpr int kChromaRows = 10, kChromaPitch = 272;                 // rows j0-1 .. j0+8; columns i0-4 .. i0+267 (dword aligned origin)
+constexpr bool kFusedHalfTiles = false;   // 16 instead of 32 luma blocks per workgroup of the fused kernel (IST_JPEG_NB=16|32 overrides in tuning mode)
+constexpr int kChromaRows = 10;                                      // chroma tile rows j0-1 .. j0+8; its columns start at i0-4 (dword aligned origin)
 
-template <int HS, int VS>
+template <int HS, int VS, int CP>
 __device__ __forceinline__ int chroma_lds(const uint8_t* T, int cw, int i_org, int j_org, int x, int y) {
-  // T[(j - j_org) * kChromaPitch + (i - i_org)]: rows are clamped at load time, columns here
-  auto at = [&](int j, int i) { return static_cast<int>(T[(j - j_org) * kChromaPitch + (clampi(i, 0, cw - 1) - i_org)]); };
+  // T[(j - j_org) * CP + (i - i_org)]: rows are clamped at load time, columns here
+  auto at = [&](int j, int i) { return static_cast<int>(T[(j - j_org) * CP + (clampi(i, 0, cw - 1) - i_org)]); };
   if (HS == 1 && VS == 1) return at(y, x);
   if (HS == 2 && VS == 1) {                       // h2v1: 3/4 nearer + 1/4 further column
     const int i = x >> 1;
@@ -192,14 +192,17 @@ __device__ __forceinline__ int chroma_lds(const uint8_t* T, int cw, int i_org, i
   return (cur * 3 + (3 * at(j, in) + at(jn, in)) + ((x & 1) ? 7 : 8)) >> 4;
 }
 
-template <int HS, int VS, bool COLOUR>
-__global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) {
-  constexpr int TW = VS == 2 ? 128 : 256, TH = 8 * VS, YP = VS == 2 ? kTileYPitchNarrow : kTileYPitchWide;
+// NB = luma blocks per workgroup (8 lanes each): 32 (256 threads) or 16 (128 threads, half as wide a tile).
+template <int HS, int VS, bool COLOUR, int NB>
+__global__ __launch_bounds__(NB * 8) void ist_jpeg_fused_kernel(const ColorArgs A) {
+  constexpr int NT = NB * 8;                                             // threads
+  constexpr int TW = NB * 8 / VS, TH = 8 * VS, YP = TW + 16;             // tile; bytes per luma tile row: 16 mod 128 keeps the row writes of step 3 off each other's banks
   constexpr int BW = TW / 8;                                             // luma blocks per block row of the tile
-  __shared__ int ws[kIdctBlocks * kIdctPitch];
+  constexpr int CP = ((TW / HS + 8) + 15) & ~15;                         // bytes per chroma tile row (the tile's columns + 4 of halo room on each side)
+  __shared__ int ws[NB * kIdctPitch];
   __shared__ int q9[72];
   __shared__ __attribute__((aligned(16))) uint8_t Ys[TH * YP];
-  __shared__ __attribute__((aligned(16))) uint8_t Cs[COLOUR ? 2 * kChromaRows * kChromaPitch : 16];
+  __shared__ __attribute__((aligned(16))) uint8_t Cs[COLOUR ? 2 * kChromaRows * CP : 16];
   const int t = static_cast<int>(threadIdx.x);
   const int x_org = static_cast<int>(blockIdx.x) * TW, y_org = static_cast<int>(blockIdx.y) * TH;
   // the tile's coefficient rows are requested first: their trip to HBM runs beside the chroma tile's (one exposed latency per
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
     constexpr int DW = (TW / HS + 8) / 4;                                // dwords per row: 4 columns of halo room on each side (<= 66)
     for (int d = t & 63; d < DW; d += 64) {
       const int i = i_org + 4 * d;
-      for (int pr = t >> 6; pr < 2 * kChromaRows; pr += 4) {
+      for (int pr = t >> 6; pr < 2 * kChromaRows; pr += NT / 64) {
         const int pl = pr >= kChromaRows ? 1 : 0, r = pr - pl * kChromaRows;
         const uint8_t* row = (pl ? A.Cr : A.Cb) + static_cast<uint32_t>(clampi(j_org + r, 0, A.chh - 1) * A.pitch_c);      // (a plane is < 4 GB: 32-bit offsets)
         uint32_t v;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
 #pragma unroll
           for (int k = 0; k < 4; ++k) v |= static_cast<uint32_t>(row[clampi(i + k, 0, A.cw - 1)]) << (8 * k);
         }
-        *reinterpret_cast<uint32_t*>(Cs + pr * kChromaPitch + 4 * d) = v;
+        *reinterpret_cast<uint32_t*>(Cs + pr * CP + 4 * d) = v;
       }
     }
   }
@@ -246,7 +249,8 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
     // horizontal 3:1 run on pairs of 16-bit lanes in 32-bit registers (every term < 4096), the colour conversion on 24-bit
     // multiply-adds (chroma < 256, constants < 2^17: exact).  Same integers as chroma_lds + ycc_to_rgba, a third of the instructions
     // (the kernel is bound by instruction issue: rocprofv3 + ISA count).
-    const int gx = t & 31, jj = t >> 5;
+    constexpr int GXF = TW / 4;                                          // groups of 4 pixels across the tile (32 or 16)
+    const int gx = t & (GXF - 1), jj = t / GXF;
     const int lx = 4 * gx, ly = 2 * jj;
     const int x0 = x_org + lx, y = y_org + ly;
     if (x0 >= A.width || y >= A.height) return;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
       uint32_t lo[3], hi[3];                                            // columns (c0, c2) and (c1, c3) of rows j-1, j, j+1 in 16-bit lanes
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(Cs + (pl * kChromaRows + jj + r) * kChromaPitch + al);
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(Cs + (pl * kChromaRows + jj + r) * CP + al);
         const uint32_t w = static_cast<uint32_t>((static_cast<uint64_t>(q[0]) | (static_cast<uint64_t>(q[1]) << 32)) >> sh);
         lo[r] = w & 0x00FF00FFu; hi[r] = (w >> 8) & 0x00FF00FFu;
       }
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
   }
   // colour, the other samplings: groups of 4 pixels; a wave's 64 groups are consecutive in x (512 B - 1 KiB runs of a canvas row)
   constexpr int GX = TW / 4;
-  for (int g = t; g < GX * TH; g += 256) {
+  for (int g = t; g < GX * TH; g += NT) {
     const int ly = g / GX, lx = 4 * (g % GX);
     const int x0 = x_org + lx, y = y_org + ly;
     if (x0 >= A.width || y >= A.height) continue;
@@ -317,8 +321,8 @@ __global__ __launch_bounds__(256) void ist_jpeg_fused_kernel(const ColorArgs A) 
       const int Yv = static_cast<int>((yy >> (8 * k)) & 255u);
       if (COLOUR) {
         const int x = min(x0 + k, A.width - 1);
-        const int cb = chroma_lds<HS, VS>(Cs, A.cw, i_org, j_org, x, y) - 128;
-        const int cr = chroma_lds<HS, VS>(Cs + kChromaRows * kChromaPitch, A.cw, i_org, j_org, x, y) - 128;
+        const int cb = chroma_lds<HS, VS, CP>(Cs, A.cw, i_org, j_org, x, y) - 128;
+        const int cr = chroma_lds<HS, VS, CP>(Cs + kChromaRows * CP, A.cw, i_org, j_org, x, y) - 128;
         px[k] = ycc_to_rgba(Yv, cb, cr);
       } else {
         px[k] = static_cast<uint32_t>(Yv) * 0x010101u | 0xFF000000u;
@@ -394,14 +398,20 @@ int jpeg_launch_reconstruct(const JpegDeviceJob& J, void* stream_) {
   for (int k = 0; k < 64; ++k) ca.q[k] = J.q_host[0] ? J.q_host[0][k] : 1;
   static const int exp = (tuning_mode() && std::getenv("IST_JPEG_EXP")) ? std::atoi(std::getenv("IST_JPEG_EXP")) : 0;
   ca.exp = exp;
-  const int tw = J.vmax == 2 ? 128 : 256, th = 8 * J.vmax;
+  static const int nb_knob = (tuning_mode() && std::getenv("IST_JPEG_NB")) ? std::atoi(std::getenv("IST_JPEG_NB")) : 0;      // A/B: blocks per workgroup
+  const bool half = nb_knob ? nb_knob == 16 : kFusedHalfTiles;
+  const int nb = half ? 16 : 32;
+  const int tw = nb * 8 / J.vmax, th = 8 * J.vmax;
   const dim3 grid(static_cast<unsigned>((J.blocks_x[0] * 8 + tw - 1) / tw), static_cast<unsigned>((J.blocks_y[0] * 8 + th - 1) / th));
   if (grid.x > 0 && grid.y > 0) {
-    if (J.ncomp != 3) hipLaunchKernelGGL((ist_jpeg_fused_kernel<1, 1, false>), grid, dim3(256), 0, stream, ca);
-    else if (J.hmax == 2 && J.vmax == 2) hipLaunchKernelGGL((ist_jpeg_fused_kernel<2, 2, true>), grid, dim3(256), 0, stream, ca);
-    else if (J.hmax == 2) hipLaunchKernelGGL((ist_jpeg_fused_kernel<2, 1, true>), grid, dim3(256), 0, stream, ca);
-    else if (J.vmax == 2) hipLaunchKernelGGL((ist_jpeg_fused_kernel<1, 2, true>), grid, dim3(256), 0, stream, ca);
-    else hipLaunchKernelGGL((ist_jpeg_fused_kernel<1, 1, true>), grid, dim3(256), 0, stream, ca);
+#define IST_FUSED(HS, VS, C) do { if (half) hipLaunchKernelGGL((ist_jpeg_fused_kernel<HS, VS, C, 16>), grid, dim3(128), 0, stream, ca); \
+                                  else hipLaunchKernelGGL((ist_jpeg_fused_kernel<HS, VS, C, 32>), grid, dim3(256), 0, stream, ca); } while (0)
+    if (J.ncomp != 3) IST_FUSED(1, 1, false);
+    else if (J.hmax == 2 && J.vmax == 2) IST_FUSED(2, 2, true);
+    else if (J.hmax == 2) IST_FUSED(2, 1, true);
+    else if (J.vmax == 2) IST_FUSED(1, 2, true);
+    else IST_FUSED(1, 1, true);
+#undef IST_FUSED
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(IST_E_HIP, std::string("JPEG reconstruct launch failed: ") + hipGetErrorString(e));

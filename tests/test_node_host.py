@@ -170,7 +170,7 @@ def test_node_png_export(tmp_path):
 
 @needs_node
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices,split", [([0], "image"), ([0, 0, 0], "image"), ([0, 0], "band")])
+@pytest.mark.parametrize("devices,split", [([0], "image"), ([0, 0, 0], "image"), ([0, 0], "band"), ([0, 0, 0], "rows"), ([0] * 4, "auto")])
 def test_node_stitch_on_a_device_list(devices, split, tmp_path):
     """opts.devices: the Node host shards the stitch over a device list through ist_stitch_rgba8_multi; on a
     one-GPU box the listed device serves every slot and the result is the single-device result, bit for bit"""
