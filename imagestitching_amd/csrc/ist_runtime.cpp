@@ -1219,6 +1219,8 @@ int ist_stitch_paths_png(ist_ctx* ctx, const char* const* paths, int n_images, i
     struct stat st;
     if (fds[i] < 0 || fstat(fds[i], &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0)
       return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常: " + (fds[i] < 0 ? "cannot open the file" : "empty file, or not a regular file"));
+    // (an image file of more than 1 GiB is no photo: refuse it before a block of that size is allocated for it)
+    if (st.st_size > (off_t{1} << 30)) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常: the file is larger than 1 GiB");
     lens[i] = static_cast<int64_t>(st.st_size);
   }
   auto read_one = [&](int k) {
