@@ -54,10 +54,16 @@ def _seeds(d):
     return out
 
 
+@pytest.fixture(scope="module")
+def fuzz_bin(tmp_path_factory):
+    """the sanitizer build of the decoder harness: compiled by the first test that runs it, reused by the others (20 s each time)"""
+    return str(tmp_path_factory.mktemp("fuzzbin") / "fuzz")
+
+
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++ for the sanitizer build")
-def test_decoders_survive_mutated_files(tmp_path):
+def test_decoders_survive_mutated_files(tmp_path, fuzz_bin):
     seeds = _seeds(str(tmp_path))
-    env = dict(os.environ, IST_FUZZ_BIN=str(tmp_path / "fuzz"))
+    env = dict(os.environ, IST_FUZZ_BIN=fuzz_bin, IST_FUZZ_REUSE="1")
     r = subprocess.run([os.path.join(ROOT, "tools", "run_fuzz.sh"), "400"] + seeds, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "0 crashes" in r.stdout
@@ -76,7 +82,7 @@ def test_compiler_invariants_under_hostile_op_lists(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
-def test_progressive_jpeg_gives_the_coefficients_of_its_sequential_twin(tmp_path):
+def test_progressive_jpeg_gives_the_coefficients_of_its_sequential_twin(tmp_path, fuzz_bin):
     """PIL writes the same quantised coefficients whether a file is saved sequential or progressive; the host entropy
     decoder must recover the same planes from both (the GPU stages after it are shared)."""
     rng = np.random.default_rng(7)
@@ -90,7 +96,7 @@ def test_progressive_jpeg_gives_the_coefficients_of_its_sequential_twin(tmp_path
             p = str(tmp_path / ("%s_%s.jpg" % (name, tag)))
             img.save(p, "JPEG", quality=83, **dict(kw or {}, **extra))
             files.append(p)
-    env = dict(os.environ, IST_FUZZ_BIN=str(tmp_path / "fuzz"))
+    env = dict(os.environ, IST_FUZZ_BIN=fuzz_bin, IST_FUZZ_REUSE="1")
     r = subprocess.run([os.path.join(ROOT, "tools", "run_fuzz.sh"), "coefs"] + files, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     rows = [l.split() for l in r.stdout.strip().splitlines()]
@@ -101,7 +107,7 @@ def test_progressive_jpeg_gives_the_coefficients_of_its_sequential_twin(tmp_path
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++ for the sanitizer build")
-def test_a_scan_with_too_few_restart_intervals_is_not_eligible_for_the_gpu_decoder(tmp_path):
+def test_a_scan_with_too_few_restart_intervals_is_not_eligible_for_the_gpu_decoder(tmp_path, fuzz_bin):
     """a DRI scan that ends (EOI) at an RSTn boundary after k < n intervals must not reach the GPU entropy
     decoder - its block count is per interval, and the MCUs nobody writes would keep an earlier call's coefficients.  The
     harness aborts when an eligible scan's intervals do not tile the frame's MCUs; it runs that check on files the host
@@ -120,7 +126,7 @@ def test_a_scan_with_too_few_restart_intervals_is_not_eligible_for_the_gpu_decod
         p.write_bytes(good[:cut] + b"\xff\xd9")
         files.append(str(p))
     (tmp_path / "whole.jpg").write_bytes(good)
-    env = dict(os.environ, IST_FUZZ_BIN=str(tmp_path / "fuzz"))
+    env = dict(os.environ, IST_FUZZ_BIN=fuzz_bin, IST_FUZZ_REUSE="1")
     r = subprocess.run([os.path.join(ROOT, "tools", "run_fuzz.sh"), "0", str(tmp_path / "whole.jpg")] + files, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "0 crashes" in r.stdout

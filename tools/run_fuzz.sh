@@ -11,6 +11,9 @@ if [ "$1" = compile ]; then
   shift
   g++ $FLAGS "$HERE/fuzz_compile.cpp" "$C/ist_compile.cpp" "$C/ist_plan.cpp" -o "$OUT"
 else
-  g++ $FLAGS "$HERE/fuzz_decoders.cpp" "$C/ist_png_decode.cpp" "$C/ist_image_misc.cpp" "$C/ist_jpeg.cpp" "$C/ist_webp.cpp" "$C/ist_webp_vp8.cpp" "$C/ist_plan.cpp" -lz -o "$OUT"
+  # (IST_FUZZ_REUSE=1: keep a binary that is already there - the tests build the harness once per session)
+  if [ -z "$IST_FUZZ_REUSE" ] || [ ! -x "$OUT" ]; then
+    g++ $FLAGS "$HERE/fuzz_decoders.cpp" "$C/ist_png_decode.cpp" "$C/ist_image_misc.cpp" "$C/ist_jpeg.cpp" "$C/ist_webp.cpp" "$C/ist_webp_vp8.cpp" "$C/ist_plan.cpp" -lz -o "$OUT"
+  fi
 fi
 "$OUT" "$@"
