@@ -398,3 +398,46 @@ def test_host_sink_of_a_horizontal_strip_by_rows(world, tmp_path):
     assert (covered == 1).all()
     ref, _, _ = U.oracle_stitch(pixels, "horizontal", opts)
     assert np.array_equal(got, ref)
+
+
+def test_row_cuts_properties():
+    """ist_shard_row_cuts: monotone, every inner cut on a multiple of 8 rows, ends at 0 and canvas_h, the root never empty, no slot more
+    than 8 rows over the even share"""
+    from imagestitching_amd import dist as D
+    rng = np.random.default_rng(77)
+    for _ in range(400):
+        h = int(rng.integers(1, 400000)) if rng.random() < 0.7 else int(rng.integers(1, 300))
+        n = int(rng.integers(1, 65))
+        cuts = D.row_cuts(h, n)
+        assert len(cuts) == n + 1 and cuts[0] == 0 and cuts[-1] == h
+        assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+        assert all(c % 8 == 0 or c == h for c in cuts[1:-1])
+        assert cuts[1] > 0
+        assert max(b - a for a, b in zip(cuts, cuts[1:])) <= -(-h // n) + 8
+
+
+def test_rows_split_parts_tile_every_draw_exactly_once():
+    """property, random plans (sizes, modes, gaps, directions, worlds): under the rows split the pieces (slot's rows x one draw's box) of a
+    draw tile its box exactly once, every piece lies inside its slot's band, and names source rows inside its image"""
+    from imagestitching_amd import dist as D
+    rng = np.random.default_rng(78)
+    for trial in range(60):
+        n = int(rng.integers(1, 10))
+        imgs = [{"width": int(rng.integers(8, 900)), "height": int(rng.integers(8, 900))} for _ in range(n)]
+        direction = "vertical" if rng.random() < 0.5 else "horizontal"
+        opts = {"mode": ["min", "max", "original"][int(rng.integers(0, 3))], "gap": int(rng.integers(0, 21)), "filter": ["nearest", "bilinear"][int(rng.integers(0, 2))]}
+        world = int(rng.integers(1, 12))
+        sh = D.ShardedStitch(imgs, direction, opts, 0, world, 0, split="rows")
+        cuts = D.row_cuts(sh.plan.canvas_h, world)
+        assert [(b.Y0, b.Y1) for b in sh.parts] == [(a, c) for a, c in zip(cuts, cuts[1:]) if c > a]
+        by_op = {}
+        for p in sh.pieces:
+            assert cuts[p.slot] <= p.Y0 < p.Y1 <= cuts[p.slot + 1]
+            assert 0 <= p.sy0 < p.sy1 <= imgs[p.image]["height"]
+            by_op.setdefault(p.op, []).append(p)
+        for op, ps in by_op.items():
+            ps.sort(key=lambda q: q.Y0)
+            assert all(a.Y1 == b.Y0 and (a.X0, a.X1) == (b.X0, b.X1) for a, b in zip(ps, ps[1:])), (trial, op)
+            r = sh.plan.rects[ps[0].image]
+            # the pieces span the draw's box (the rect clipped to the canvas, pixel-centre coverage)
+            assert ps[0].Y0 == max(0, int(np.ceil(r["dy"] - 0.5))) and ps[-1].Y1 == min(sh.plan.canvas_h, int(np.ceil(r["dy"] + r["dh"] - 0.5))), (trial, op)
