@@ -577,7 +577,25 @@ def run_sharded(args):
         raise SystemExit("bench.py: rank %d needs GPU %d but only %d are visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # RCCL, or - SURVEY 8e "fallback: if RCCL init fails -> replicas only" - gloo for the control plane: the regions that exchange
+    # nothing between GPUs (host_in_host_out: every GPU delivers its own bands) and the replicas leg still run, the gather regions
+    # are reported as unavailable, and `value` is the replicas' aggregate.  (--force-gloo rehearses this path.)
+    rccl, rccl_error = True, None
+    try:
+        if args.force_gloo:
+            raise RuntimeError("forced by --force-gloo")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.barrier()                                     # the first collective makes (and proves) the communicator
+    except Exception as ex:
+        rccl, rccl_error = False, repr(ex)
+        sys.stderr.write("bench.py: rank %d: RCCL is not usable (%s): gloo control plane, no gather regions\n" % (rank, rccl_error))
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctl = dev if rccl else torch.device("cpu")             # where the control tensors of the collectives live
     ranks_seen = gather_ranks(dist, rank, local, torch)
     solo = Solo(dist, rank)
 
@@ -594,7 +612,7 @@ def run_sharded(args):
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
-        dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dt = torch.tensor([time.perf_counter() - t0], device=ctl, dtype=torch.float64)
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         return float(dt.item()) / steps
 
@@ -634,7 +652,7 @@ def run_sharded(args):
             canvas = be.new_canvas() if rank == 0 else None
         except Exception as ex:
             err = repr(ex)
-        bad = torch.tensor([1 if err else 0], device=dev, dtype=torch.int32)
+        bad = torch.tensor([1 if err else 0], device=ctl, dtype=torch.int32)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if int(bad.item()):
             torch.cuda.empty_cache()
@@ -647,8 +665,13 @@ def run_sharded(args):
 
         def resident():
             D.run_step(sh, be, dsrc, canvas, dist)
-        t_res = timed(resident, steps, max(args.warmup, 3 if big else 20))     # (>= 20 untimed steps: every rank's chip reaches its sustained clock)
-        regions["resident"] = {"ms_per_step": round(t_res * 1e3, 4), "MPs": round(mp / t_res, 1)}
+        t_res = None
+        if rccl or not sh.remote:
+            t_res = timed(resident, steps, max(args.warmup, 3 if big else 20))     # (>= 20 untimed steps: every rank's chip reaches its sustained clock)
+            regions["resident"] = {"ms_per_step": round(t_res * 1e3, 4), "MPs": round(mp / t_res, 1)}
+        else:
+            regions["resident"] = {"unavailable": "the gather needs RCCL: " + str(rccl_error)}
+            want = want - {"from_pinned_host", "from_jpeg"}                       # (they end in the same gather)
         few = max(3, steps // 10)
         if "from_pinned_host" in want:
             t = timed(lambda: (upload(), resident()), few, 2)
@@ -733,7 +756,7 @@ def run_sharded(args):
     for split in ("image", "band"):
         r, g, t_res = sharded_suite(UNIFORM, "vertical", split, all_regions if split == "image" else all_regions - {"from_jpeg"}, args.steps, False)
         if split == "image":
-            if t_res is None:
+            if t_res is None and rccl:
                 raise SystemExit("bench.py: the headline suite could not be set up: %s" % r)
             value_sec = t_res
         for k, v in r.items():
@@ -755,14 +778,14 @@ def run_sharded(args):
     if not args.no_config5:
         per_rank = 2 * max(sum(w * h * 4 for k, (w, h) in enumerate(CONFIG5) if k % world == s) for s in range(world))
         need0 = per_rank + sum(w * h * 4 for w, h in CONFIG5)                     # the root also holds the canvas
-        free = torch.tensor([torch.cuda.mem_get_info(dev)[0]], device=dev, dtype=torch.float64)
+        free = torch.tensor([torch.cuda.mem_get_info(dev)[0]], device=ctl, dtype=torch.float64)
         dist.all_reduce(free, op=dist.ReduceOp.MIN)
         if float(free.item()) < need0 * 1.2:
             config5 = {"skipped": "needs %.1f GB of HBM on the root, %.1f GB free on the fullest GPU" % (need0 / 1e9, float(free.item()) / 1e9)}
         else:
             r5, g5, _ = sharded_suite(CONFIG5, "vertical", "image", {"host_in_host_out"}, 10, True)
             need1 = 2 * sum(w * h * 4 for w, h in CONFIG5)
-            fits = torch.tensor([1 if torch.cuda.mem_get_info(dev)[0] >= need1 * 1.15 else 0], device=dev, dtype=torch.int32)
+            fits = torch.tensor([1 if torch.cuda.mem_get_info(dev)[0] >= need1 * 1.15 else 0], device=ctl, dtype=torch.int32)
             dist.broadcast(fits, 0)                                               # (rank 0 decides for everybody: solo() is collective)
             one5 = solo(lambda: single_suite(CONFIG5, "vertical", {"host_in_host_out"} if not args.no_config5_host else set(), 10, True)) if int(fits.item()) else None
             if rank == 0:
@@ -784,13 +807,21 @@ def run_sharded(args):
     t_rep = timed(lambda: job_full.launch(full_src, full_out), args.steps, 20)
     B_full = int(job_full.info["algorithmic_bytes"])
     if rank == 0:
+        if value_sec is None:                              # RCCL unavailable: replicas only
+            headline = {"value": round(world * mp / t_rep, 1), "ms_per_step": round(t_rep * 1e3, 5), "scaling": "weak",
+                        "workload": "REPLICAS ONLY - RCCL is not usable on this node (%s): every GPU stitches its own whole 9 x 4032x3024 job; the gather regions "
+                                    "are unavailable, host_in_host_out (no exchange) is reported in extra.regions" % rccl_error,
+                        "timed_region": "one fused launch per GPU per step, inputs resident; aggregate over the GPUs"}
+        else:
+            headline = {"value": round(mp / value_sec, 1), "ms_per_step": round(value_sec * 1e3, 5), "scaling": "strong",
+                        "workload": "BASELINE configs[3]: 9 x 4032x3024 vertical stitch, image i on GPU i mod %d, bands gathered to "
+                                    "GPU 0 with one grouped RCCL send/recv batch (%d bands received in place)" % (world, gather["image"]["bands_in_place"]),
+                        "timed_region": "per-rank band launches + gather + root launch; inputs resident in each owner's HBM.  " + SCALING_NOTE}
         line = {
-            "metric": "stitched megapixels/sec (9x12 MP vertical)", "value": round(mp / value_sec, 1), "unit": "MP/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(value_sec * 1e3, 5),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[3]: 9 x 4032x3024 vertical stitch, image i on GPU i mod %d, bands gathered to "
-                                   "GPU 0 with one grouped RCCL send/recv batch (%d bands received in place)" % (world, gather["image"]["bands_in_place"]),
-                       "timed_region": "per-rank band launches + gather + root launch; inputs resident in each owner's HBM.  " + SCALING_NOTE},
+            "metric": "stitched megapixels/sec (9x12 MP vertical)", "value": headline["value"], "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": headline["ms_per_step"],
+            "higher_is_better": True, "scaling": headline["scaling"], "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": headline["workload"], "timed_region": headline["timed_region"]},
             # the dominant kernel is the one of the N = 1 line; here it is timed on the whole 9 x 12 MP job that every rank
             # launches in the replicas leg (wall time per launch of back-to-back launches, MAX over ranks; no PMC at N > 1)
             "roofline": {"bound": "hbm", "achieved": round(B_full / t_rep / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
@@ -798,7 +829,8 @@ def run_sharded(args):
                          "kernel_us": round(t_rep * 1e6, 2), "algorithmic_bytes_per_launch": B_full,
                          "what": "per GPU, from the replicas leg (each rank launches the whole job); slowest rank"},
             "cpu_baseline": None,
-            "extra": {"ranks_seen": ranks_seen, "world_size": dist.get_world_size(), "regions": regions, "gather": gather,
+            "extra": {"ranks_seen": ranks_seen, "world_size": dist.get_world_size(), "collectives": "rccl" if rccl else "gloo (RCCL unavailable: %s)" % rccl_error,
+                      "regions": regions, "gather": gather,
                       "one_gpu_same_lease": {"vertical": one[0], "horizontal": one_h[0],
                                              "what": "the ONE-GPU form of every region (one fused launch; everything over GPU 0's one PCIe link), timed by rank 0 "
                                                      "alone in this process while the other ranks block on the rendezvous store"},
@@ -846,7 +878,7 @@ def free_port():
 def child_argv(args, extra=()):
     a = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
     for flag, on in (("--no-cpu", args.no_cpu), ("--quick", args.quick), ("--kernels-only", args.kernels_only), ("--dry-launch", args.dry_launch),
-                     ("--no-config5", args.no_config5), ("--no-config5-host", args.no_config5_host)):
+                     ("--no-config5", args.no_config5), ("--no-config5-host", args.no_config5_host), ("--force-gloo", args.force_gloo)):
         if on:
             a.append(flag)
     return a + list(extra)
@@ -1215,6 +1247,7 @@ def main():
     ap.add_argument("--kernels-only", action="store_true", help="only the resident-input kernel configurations (what the rocprofv3 passes run)")
     ap.add_argument("--print-kernel-sha", action="store_true")
     ap.add_argument("--dry-launch", action="store_true", help="N ranks on CPU (gloo, stub render): exercises the rank launch and the line, no GPU")
+    ap.add_argument("--force-gloo", action="store_true", help="rehearse the fallback taken when RCCL cannot be initialised (gloo control plane, no gather regions, replicas-only value)")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] (64 x 8000x6000) legs")
     ap.add_argument("--no-config5-host", action="store_true", help="configs[4]: skip the one-GPU host_in_host_out comparator (24.6 GB of pinned host memory on rank 0)")
     ap.add_argument("--launch-timeout", type=int, default=1500, help="seconds the self-started ranks may take")

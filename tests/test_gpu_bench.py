@@ -104,3 +104,16 @@ def test_the_sharded_line_on_a_world_of_one():
     assert "skipped" not in c5 and {"resident/image", "host_in_host_out/image"} <= set(c5["regions"]) <= set(c5["scaling"]) | set(c5["regions"])
     assert set(c5["scaling"]) == {"resident/image", "host_in_host_out/image"}
     assert "CANNOT scale" in line["config"]["timed_region"]
+
+
+def test_the_sharded_line_without_rccl_falls_back_to_gloo():
+    """SURVEY 8e fallback: when RCCL cannot be initialised the ranks keep a gloo control plane (timing brackets, flags on CPU tensors), the
+    regions that exchange nothing still run, and the line says which collectives it used.  --force-gloo rehearses it on a world of one."""
+    env = dict(os.environ, IST_BENCH_FORCE_SHARDED="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29674")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "10", "--warmup", "2", "--no-cpu", "--kernels-only", "--no-config5", "--force-gloo"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["extra"]["collectives"].startswith("gloo") and "forced by --force-gloo" in line["extra"]["collectives"]
+    assert _errors(line) == []
+    assert line["extra"]["regions"]["host_in_host_out/band"]["ms_per_step"] > 0 and line["value"] > 0
