@@ -169,7 +169,14 @@ def cpu_baseline(budget_s=10.0):
     t1 = time.perf_counter()
     O.render(pd, rl, descs, px, "bilinear", 1, out=out)                # single-thread figure on one repetition, for the record
     st = time.perf_counter() - t1
-    res = {"value": round(mp / dt, 1), "unit": "MP/s", "cores": threads, "kind": "port", "build": build,
+    quota = None                                   # the container's CPU-time quota, if any (cgroup v2 cpu.max = "<quota us> <period us>")
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        pass
+    res = {"value": round(mp / dt, 1), "unit": "MP/s", "cores": threads, "cpu_time_quota_cpus": quota, "kind": "port", "build": build,
            "sample": "%d x the full 9x4032x3024 vertical bilinear stitch (109.7 MP each), oracle/ist_oracle.c, %d threads by row bands" % (reps, threads),
            "single_thread_MPs": round(mp / st, 1)}
     res["cairo"] = cairo_leg(px)
