@@ -238,11 +238,46 @@ def cairo_leg(px, budget_s=4.0):
         return {"error": repr(ex)}
 
 
+def canvas_pitch_leg(st, dev, torch):
+    """Informational: the three plans that are not a flat copy, with the caller's canvas rows padded to the next multiple of 4 KiB (the
+    canvas pitch is the caller's choice, ist_job_launch takes it as it is; INTEGRATION.md "Row pitch").  A workgroup's 1 KiB stores are
+    cheapest when they start on 256-byte boundaries and sit a multiple of 4 KiB apart (tools/exp/hbm_ceiling.cpp, tools/exp_canvas_pitch.py);
+    a 25 320-pixel canvas row (101 280 bytes) offers neither."""
+    out = {"what": "same jobs and sources as extra.<plan>, canvas rows padded to a multiple of 4096 bytes; kernel_us by events, 40 launches, median of 5"}
+    for name, sizes, direction in (("uniform_horizontal", UNIFORM, "horizontal"), ("mixed_vertical", MIXED, "vertical"), ("mixed_horizontal", MIXED, "horizontal")):
+        imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in sizes]
+        p, job = st.compile(imgs, direction, {"filter": "bilinear"})
+        srcs = [synth(k, w, h, dev) for k, (w, h) in enumerate(sizes)]
+        pitch = (p.canvas_w * 4 + 4095) // 4096 * 4096
+        raw = torch.empty((p.canvas_h * pitch + 4096,), dtype=torch.uint8, device=dev)
+        off = (-raw.data_ptr()) % 4096
+        canvas = raw[off:off + p.canvas_h * pitch].view(p.canvas_h, pitch // 4, 4)[:, :p.canvas_w]
+        for _ in range(PREROLL_LAUNCHES):
+            job.launch(srcs, canvas)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(40):
+                job.launch(srcs, canvas)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / 40)
+        us = sorted(ts)[2]
+        out[name] = {"canvas_row_bytes": pitch, "dense_row_bytes": p.canvas_w * 4, "kernel_us": round(us, 2),
+                     "frac": round(job.info["algorithmic_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        del srcs, raw, canvas, job
+        torch.cuda.empty_cache()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------- N = 1
 def run_single(args):
     import numpy as np
     import torch
     import imagestitching_amd as ist
+    from imagestitching_amd import _lib as L
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     st = ist.Stitcher(0)
@@ -258,19 +293,22 @@ def run_single(args):
         sets = [[synth(9 * s + k, w, h, dev) for k, (w, h) in enumerate(sizes)] for s in range(nsets)]
         outs = [torch.empty((p.canvas_h, p.canvas_w, 4), dtype=torch.uint8, device=dev) for _ in range(nsets)]
         steps = args.steps if name == "uniform_vertical" else max(10, args.steps // 2)
+        flat0 = L.lib.ist_debug_flat_launches()
         wall, ev_ms = time_job(job, sets, outs, steps, args.warmup, torch)
+        flat = L.lib.ist_debug_flat_launches() - flat0 == PREROLL_LAUNCHES + args.warmup + steps
         mp = p.canvas_w * p.canvas_h / 1e6
         k_us = ev_ms * 1e3 / steps
         results[name] = {"canvas": [p.canvas_w, p.canvas_h], "out_MP": round(mp, 3), "steps": steps,
                          "ms_per_step": wall * 1e3 / steps, "kernel_us": k_us, "MPs": mp / (wall / steps),
                          "algorithmic_bytes": job.info["algorithmic_bytes"],
                          "GBs": job.info["algorithmic_bytes"] / (k_us * 1e-6) / 1e9,
-                         "tiles": {k: job.info[k] for k in ("tiles_fill", "tiles_copy", "tiles_sample", "tiles_general")}}
+                         "tiles": {k: job.info[k] for k in ("tiles_fill", "tiles_copy", "tiles_sample", "tiles_general")},
+                         "rows_walked": "flat form: the strip's bytes as rows of 32 KiB (dense rows on both sides; DESIGN.md section 3)" if flat else "the canvas's rows"}
         del sets, outs, job
         torch.cuda.empty_cache()
     head = results["uniform_vertical"]
     extra = {k: {"MPs": round(v["MPs"], 1), "kernel_us": round(v["kernel_us"], 2), "GBs": round(v["GBs"], 1),
-                 "frac": round(v["GBs"] / HBM_PEAK_GBS, 4), "canvas": v["canvas"], "tiles": v["tiles"]} for k, v in results.items()}
+                 "frac": round(v["GBs"] / HBM_PEAK_GBS, 4), "canvas": v["canvas"], "tiles": v["tiles"], "rows_walked": v["rows_walked"]} for k, v in results.items()}
     yard = cpu = None
     if not args.kernels_only:
         yard = d2d_yardstick(head["algorithmic_bytes"] // 2, dev, torch)
@@ -278,6 +316,10 @@ def run_single(args):
             extra["regions"] = single_gpu_regions(st, ist, dev, torch, head)
         except Exception as ex:      # informational legs never take the headline down
             extra["regions"] = {"error": repr(ex)}
+        try:
+            extra["canvas_rows_padded_to_4KiB"] = canvas_pitch_leg(st, dev, torch)
+        except Exception as ex:
+            extra["canvas_rows_padded_to_4KiB"] = {"error": repr(ex)}
         try:
             extra["config5_single_gpu"] = config5_single_leg(st, dev, torch)
         except Exception as ex:

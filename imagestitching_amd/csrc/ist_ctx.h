@@ -61,22 +61,13 @@ struct DevTables {
   int32_t* stacks = nullptr;
   DevTile* tiles = nullptr;
 };
-// The same job walked as rows of kFlatPitch bytes (ist_runtime.cpp, build_flat_twin): when every op of a job covers whole canvas rows at
-// unit scale, the launch moves contiguous byte ranges as long as the caller's rows are dense (pitch = 4 * width on both sides), and the
-// rows the kernel walks need not be the image's.  A 32 KiB pitch is what the memory system likes best (LAB_NOTES.md section 1.8).
-constexpr size_t kFlatPitch = 32768;
-struct FlatTwin {
-  Compiled host;                         // the op list re-expressed on a canvas kFlatPitch / 4 pixels wide
-  DevTables dt;
-  struct Src { int32_t image; int64_t delta; };   // virtual image k = the caller's image `image`, base moved by delta bytes
-  std::vector<Src> src;
-};
 }  // namespace ist
 
 struct ist_job {
   ist_ctx* ctx = nullptr;
   ist::Compiled host;
-  std::unique_ptr<ist::FlatTwin> flat;   // or none: the job is not made of whole dense rows
+  std::unique_ptr<ist::FlatTwin> flat;   // or none: the job is not made of whole dense rows (ist_internal.h)
+  ist::DevTables flat_dt;
   uint8_t* d_tables = nullptr;           // ONE device allocation holding the five tables below
   size_t d_tables_bytes = 0;
   // the streams the job was launched on since it was created (ist_job_destroy waits for THOSE before it hands the tables to

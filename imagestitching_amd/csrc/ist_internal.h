@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -100,6 +101,21 @@ struct Compiled {
   std::vector<int32_t> img_w, img_h;   // bitmap sizes per image (for launch-time validation)
   ist_job_info info{};
 };
+
+// The same job walked as rows of kFlatPitch bytes (ist_compile.cpp, compile_flat_twin): when every op of a job covers whole canvas rows at
+// unit scale, the launch moves contiguous byte ranges as long as the caller's rows are dense (pitch = 4 * width on both sides), and the
+// rows the kernel walks need not be the image's.  A workgroup's eight 1 KiB stores are cheapest when their addresses are congruent mod
+// 16 KiB; 32 KiB rows measured best (LAB_NOTES.md section 1.8, tools/exp/hbm_ceiling.cpp, tools/exp_flat.py).
+constexpr size_t kFlatPitch = 32768;
+struct FlatTwin {
+  Compiled host;                         // the op list re-expressed on a canvas kFlatPitch / 4 pixels wide
+  struct Src { int32_t image; int64_t delta; };   // virtual image k = the caller's image `image`, base moved by delta bytes
+  std::vector<Src> src;
+  int64_t dst_delta = 0;                 // the wide canvas starts at the rendered region's first row: dst + ry0 * 4 * canvas_w
+};
+// nothing when the job does not qualify (ist_compile.cpp)
+std::unique_ptr<FlatTwin> compile_flat_twin(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,
+                                            const ist_image_desc* images, int n_images, int filter, const Compiled& primary);
 
 // every device allocation of the library goes through these two (counted: ist_debug_device_allocs).  dev_malloc returns
 // the hipError_t as an int (0 = hipSuccess) so that this header needs nothing of HIP.

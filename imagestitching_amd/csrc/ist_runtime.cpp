@@ -201,90 +201,7 @@ void ist_ctx_destroy(ist_ctx* ctx) {
   delete ctx;
 }
 
-extern "C++" {
-namespace {
-
-std::atomic<int64_t> g_flat_launches{0};
-
-bool whole(double v) { return v == std::floor(v) && std::fabs(v) < 9.0e15; }
-
-// The op list on a canvas kFlatPitch / 4 pixels wide, when that is the same copy (ist_ctx.h, FlatTwin).  A job qualifies when every
-// op - fills, draws and holes alike - covers whole canvas rows under the identity transform and every draw takes whole rows of a bitmap
-// as wide as the canvas at unit scale: its destination (and source) is then ONE byte range of a dense buffer, which becomes a head
-// row, whole rows and a tail row of the wide canvas.  Returns nothing for every other job - and for one whose rows are already a
-// multiple of 4 KiB or whose canvas is too small for the row pitch to matter.
-std::unique_ptr<FlatTwin> build_flat_twin(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,
-                                          const ist_image_desc* images, int n_images, int filter, const Compiled& primary) {
-  static const bool off = tuning_mode() && std::getenv("IST_FLAT") && std::atoi(std::getenv("IST_FLAT")) == 0;
-  if (off || primary.kernel_kind != 0) return nullptr;
-  const int64_t row = canvas_w * 4, P = static_cast<int64_t>(kFlatPitch), vw = P / 4;
-  const int64_t total = row * canvas_h;
-  if (row % 4096 == 0 || total < 64 * P) return nullptr;
-  std::vector<ist_op> vops;
-  std::vector<ist_image_desc> vimg;
-  std::unique_ptr<FlatTwin> t(new FlatTwin);
-  for (int i = 0; i < n_ops; ++i) {
-    const ist_op& o = ops[i];
-    if (o.kind != IST_OP_FILL && o.kind != IST_OP_DRAW && o.kind != IST_OP_HOLE) return nullptr;
-    if (o.m[0] != 1.0 || o.m[1] != 0.0 || o.m[2] != 0.0 || o.m[3] != 1.0 || o.m[4] != 0.0 || o.m[5] != 0.0) return nullptr;
-    if (!whole(o.d[1]) || !whole(o.d[3]) || o.d[0] != 0.0 || o.d[2] != static_cast<double>(canvas_w)) return nullptr;
-    const int64_t dy = static_cast<int64_t>(o.d[1]), dh = static_cast<int64_t>(o.d[3]);
-    if (dy < 0 || dh < 1 || dy + dh > canvas_h) return nullptr;
-    int vi = -1;
-    if (o.kind == IST_OP_DRAW) {
-      if (o.image < 0 || o.image >= n_images || static_cast<int>(vimg.size()) >= kMaxImages) return nullptr;
-      const ist_image_desc& im = images[o.image];
-      const int64_t iw = im.bmp_width > 0 ? im.bmp_width : im.width, ih = im.bmp_height > 0 ? im.bmp_height : im.height;
-      if (iw != canvas_w || o.s[0] != 0.0 || o.s[2] != static_cast<double>(canvas_w) || !whole(o.s[1]) || o.s[3] != o.d[3]) return nullptr;
-      const int64_t sy = static_cast<int64_t>(o.s[1]);
-      if (sy < 0 || sy + dh > ih) return nullptr;
-      vi = static_cast<int>(vimg.size());
-      t->src.push_back(FlatTwin::Src{o.image, sy * row - (dy * row) % P});
-    }
-    // the byte range [D, D + L) of the canvas as rectangles of the wide canvas
-    const int64_t D = dy * row, Lpx = dh * canvas_w, hx = (D % P) / 4, y0 = D / P;
-    int64_t left = Lpx, y = 0;
-    auto piece = [&](int64_t x, int64_t yy, int64_t w, int64_t h) {
-      ist_op v = o;
-      v.image = vi;
-      v.s[0] = static_cast<double>(x); v.s[1] = static_cast<double>(yy); v.s[2] = static_cast<double>(w); v.s[3] = static_cast<double>(h);
-      v.d[0] = static_cast<double>(x); v.d[1] = static_cast<double>(y0 + yy); v.d[2] = static_cast<double>(w); v.d[3] = static_cast<double>(h);
-      vops.push_back(v);
-    };
-    if (hx) { const int64_t w = std::min(vw - hx, left); piece(hx, 0, w, 1); left -= w; y = 1; }
-    if (left >= vw) { piece(0, y, vw, left / vw); y += left / vw; left %= vw; }
-    if (left) { piece(0, y, left, 1); ++y; }
-    if (vi >= 0) {
-      ist_image_desc d = images[o.image];
-      d.width = d.bmp_width = static_cast<int32_t>(vw);
-      d.height = d.bmp_height = static_cast<int32_t>(y);
-      d.orientation = 1;
-      vimg.push_back(d);
-    }
-  }
-  const int64_t vh = (total + P - 1) / P;
-  if (total % P) {                                    // the wide canvas's last row ends past the caller's buffer: never written
-    ist_op h;
-    std::memset(&h, 0, sizeof(h));
-    h.kind = IST_OP_HOLE; h.image = -1;
-    h.m[0] = h.m[3] = 1.0;
-    h.d[0] = static_cast<double>((total % P) / 4); h.d[1] = static_cast<double>(vh - 1); h.d[2] = static_cast<double>(vw - (total % P) / 4); h.d[3] = 1.0;
-    vops.push_back(h);
-  }
-  const std::string keep_msg = g_last_error;
-  const int keep_code = g_last_code;
-  ist_image_desc none;
-  std::memset(&none, 0, sizeof(none));
-  if (compile_ops(vw, vh, clear_rgba, vops.data(), static_cast<int>(vops.size()), vimg.empty() ? &none : vimg.data(), static_cast<int>(vimg.size()),
-                  filter, nullptr, &t->host) != IST_OK || t->host.kernel_kind != 0) {
-    g_last_error = keep_msg; g_last_code = keep_code;             // the twin is an optimisation: its failure is nobody's error
-    return nullptr;
-  }
-  return t;
-}
-
-}  // namespace
-}  // extern "C++"
+static std::atomic<int64_t> g_flat_launches{0};
 
 int64_t ist_debug_flat_launches(void) { return g_flat_launches.load(); }
 
@@ -300,11 +217,11 @@ ist_job* ist_job_create(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const 
                   clip, &job->host) != IST_OK)
     return nullptr;
   for (const DevOp& o : job->host.ops) job->max_image = std::max(job->max_image, o.image);
-  if (!clip) job->flat = build_flat_twin(canvas_w, canvas_h, clear_rgba ? clear_rgba : transparent, ops, n_ops, images, n_images, filter, job->host);
+  job->flat = compile_flat_twin(canvas_w, canvas_h, clear_rgba ? clear_rgba : transparent, ops, n_ops, images, n_images, filter, job->host);
   DeviceGuard g(ctx->device);
   // the tables (the job's five and, when it has one, its flat twin's five) travel as ONE allocation and ONE copy (256-byte aligned sections)
   const Compiled* hs[2] = {&job->host, job->flat ? &job->flat->host : nullptr};
-  DevTables* dts[2] = {&job->dt, job->flat ? &job->flat->dt : nullptr};
+  DevTables* dts[2] = {&job->dt, job->flat ? &job->flat_dt : nullptr};
   size_t bytes[2][5], at[2][5], total = 0;
   const void* from[2][5];
   for (int t = 0; t < 2; ++t) {
@@ -382,11 +299,11 @@ int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch
   if ((reinterpret_cast<uintptr_t>(dst) & 3) != 0) return fail(IST_E_INVALID, "dst must be 4-byte aligned");
   // dense rows on both sides: the job's flat twin moves the same bytes as rows of kFlatPitch (validated above on the caller's own table)
   const Compiled& run = dense ? job->flat->host : h;
-  const DevTables& dt = dense ? job->flat->dt : job->dt;
+  const DevTables& dt = dense ? job->flat_dt : job->dt;
   if (dense) {
     LaunchArgs f;
     std::memset(&f, 0, sizeof(f));
-    f.dst = a.dst;
+    f.dst = a.dst + job->flat->dst_delta;
     f.dst_pitch = kFlatPitch;
     for (size_t k = 0; k < job->flat->src.size(); ++k) {
       f.src[k] = a.src[job->flat->src[k].image] + job->flat->src[k].delta;

@@ -68,8 +68,11 @@ def test_no_informational_leg_of_the_full_line_failed():
     line = _run(["--no-cpu", "--steps", "20", "--warmup", "2"], timeout=1500)
     assert _errors(line) == []
     ex = line["extra"]
-    for key in ("uniform_vertical", "uniform_horizontal", "mixed_vertical", "mixed_horizontal", "regions", "end_to_end_host_path", "file_pipeline", "config5_single_gpu"):
+    for key in ("uniform_vertical", "uniform_horizontal", "mixed_vertical", "mixed_horizontal", "regions", "end_to_end_host_path", "file_pipeline", "config5_single_gpu",
+                "canvas_rows_padded_to_4KiB"):
         assert key in ex, key
+    assert ex["uniform_vertical"]["rows_walked"].startswith("flat form") and ex["mixed_horizontal"]["rows_walked"] == "the canvas's rows"
+    assert 0.3 < ex["canvas_rows_padded_to_4KiB"]["mixed_horizontal"]["frac"] <= 1.0 and ex["canvas_rows_padded_to_4KiB"]["mixed_horizontal"]["canvas_row_bytes"] % 4096 == 0
     assert set(ex["file_pipeline"]["stage_rooflines"]) == {"entropy_gpu", "reconstruct", "stitch", "png"}
     for st in ex["file_pipeline"]["stage_rooflines"].values():
         assert st["bound_ms"] > 0 and st["achieved_ms"] > 0 and 0 < st["frac"] <= 1.5

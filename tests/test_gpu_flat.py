@@ -1,4 +1,4 @@
-"""The flat form of a job (ist_runtime.cpp build_flat_twin): a strip whose every op covers whole canvas rows at unit
+"""The flat form of a job (ist_compile.cpp compile_flat_twin): a strip whose every op covers whole canvas rows at unit
 scale is a copy of contiguous byte ranges when the caller's rows are dense, and the launch then walks the same bytes as rows of 32 KiB.
 Same pixels as the oracle and as the row form; never a byte outside the canvas; only when it applies.  Reference anchor of the
 workload: the vertical strip of equal-width photos, pages/index/index.js:1251-1581 (BASELINE configs[1], configs[4])."""
@@ -164,3 +164,29 @@ def test_headline_geometry_in_both_forms():
     raw2, out2, guard2 = _guarded_canvas(p.canvas_h, p.canvas_w, pitch_px=w + 32)
     assert _launch(job, srcs, out2) == 0 and _guards_intact(raw2, guard2)
     assert torch.equal(out2, out)
+
+
+def test_a_clip_of_whole_rows_is_a_shorter_flat_canvas():
+    """the band jobs of a device group and of the file pipeline: ist_job_create with a clip that takes whole rows, launched on a compact
+    band buffer (dst biased by the clip's origin, ist_job_launch's contract)"""
+    w, heights = 612, [500, 450, 450]
+    px = [U.rand_image(150 + i, h, w, opaque=(i != 1)) for i, h in enumerate(heights)]
+    ref, pd, _ = U.oracle_stitch(px, "vertical", {"filter": "nearest"})
+    st = ist.Stitcher(0)
+    imgs = [{"width": w, "height": h, "opaque": i != 1} for i, h in enumerate(heights)]
+    p = ist.plan(imgs, "vertical", {"filter": "nearest"})
+    ops, n_ops = p.ops()
+    srcs = [_dense(a) for a in px]
+    for (y0, y1, flat) in ((200, 1150, 1), (0, 900, 1), (501, 1400, 1), (600, 700, 0)):
+        job = st.compile_ops(p.canvas_w, p.canvas_h, ops, n_ops, p._descs, 3, "nearest", clear=(0, 0, 0, 0), clip=(0, y0, w, y1 - y0))
+        raw, band, guard = _guarded_canvas(y1 - y0, w)
+        before = _flat()
+        job.launch_ptrs([t.data_ptr() for t in srcs], [t.stride(0) for t in srcs], band.data_ptr() - y0 * w * 4, w * 4, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert _flat() - before == flat, (y0, y1)
+        assert np.array_equal(band.cpu().numpy(), ref[y0:y1]) and _guards_intact(raw, guard), (y0, y1)
+    # a clip that does not take whole rows keeps the row form
+    job = st.compile_ops(p.canvas_w, p.canvas_h, ops, n_ops, p._descs, 3, "nearest", clear=(0, 0, 0, 0), clip=(10, 0, w - 10, 1400))
+    out = torch.zeros((1400, w, 4), dtype=torch.uint8, device=DEV)
+    assert _launch(job, srcs, out) == 0
+    assert np.array_equal(out.cpu().numpy()[:, 10:], ref[:, 10:])

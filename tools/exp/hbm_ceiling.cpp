@@ -1,0 +1,93 @@
+// What does this chip's memory system deliver to the simplest kernels?  (tools/exp: measurement aid, not product.)
+//   hipcc --offload-arch=gfx950 -O3 -o tools/exp/hbm_ceiling.bin tools/exp/hbm_ceiling.cpp && tools/exp/hbm_ceiling.bin
+// Read-only (every lane loads 16-byte vectors and keeps an XOR), write-only (16-byte stores of a constant) and copy, over the headline's
+// byte count (9 x 4032 x 3024 x 4 = 438 939 648 per side), with the workgroup shape of the stitch kernel's COPY tile: 256 threads, eight
+// 1 KiB wave-rows, two in flight per wave.  A workgroup's eight wave-rows sit `stride` bytes apart ("rows" of a tile) and consecutive
+// workgroups are 1 KiB apart inside a block of 8 x stride bytes - stride 1024 is the plain linear walk, 32768 the flat form the library
+// uses, 16128 the 4032-pixel row.  Rates are reported against 8 TB/s; copy counts bytes read + bytes written.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <vector>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+// byte offset of wave-row `item` (0..7) of workgroup `wg`: blocks of 8 * stride bytes, stride / 1024 workgroups per block
+// (a stride that is no multiple of 1 KiB has a partial last column, like the last tile of a 4032-pixel row; ~size_t(0) = lane idle)
+__device__ inline size_t item_offset(size_t wg, int item, size_t stride, int lane) {
+  const size_t per = (stride + 1023) >> 10;
+  const size_t block = wg / per, col = wg - block * per;
+  if (col * 1024 + static_cast<size_t>(lane) * 16 + 16 > stride) return ~static_cast<size_t>(0) - 64;
+  return block * 8 * stride + static_cast<size_t>(item) * stride + col * 1024 + static_cast<size_t>(lane) * 16;
+}
+template <int MODE>   // 0 read, 1 write, 2 copy
+__global__ __launch_bounds__(256) void k(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t bytes, size_t stride, uint32_t* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32x4 acc = {0, 0, 0, 0};
+  {
+    u32x4 v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t o = item_offset(blockIdx.x, u * 4 + wave, stride, lane);
+      if (MODE != 1 && o < bytes && o + 16 <= bytes) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + o));
+      else v[u] = u32x4{1u, 2u, 3u, 4u};
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t o = item_offset(blockIdx.x, u * 4 + wave, stride, lane);
+      if (MODE == 0) acc ^= v[u];
+      else if (o < bytes && o + 16 <= bytes) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(dst + o));
+    }
+  }
+  if (MODE == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) sink[0] = 1;      // (never, on random data: keeps the loads alive)
+}
+
+int main(int argc, char** argv) {
+  const size_t bytes = 438939648;
+  const size_t cap = bytes + (8u << 20);
+  uint8_t *a, *b;
+  uint32_t* sink;
+  CK(hipMalloc(&a, cap)); CK(hipMalloc(&b, cap)); CK(hipMalloc(&sink, 256));
+  std::vector<uint32_t> h(cap / 4);
+  uint32_t x = 12345;
+  for (auto& w : h) { x = x * 1664525u + 1013904223u; w = x; }
+  CK(hipMemcpy(a, h.data(), cap, hipMemcpyHostToDevice));
+  CK(hipMemset(b, 0, cap));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  std::vector<size_t> strides = {1024, 4096, 16128, 16384, 32000, 32768, 65536};
+  if (argc > 1) {                                   // hbm_ceiling.bin stride [stride ...]
+    strides.clear();
+    for (int i = 1; i < argc; ++i) strides.push_back(static_cast<size_t>(std::atoll(argv[i])));
+  }
+  const char* names[] = {"read ", "write", "copy "};
+  for (int mode = 0; mode < 3; ++mode)
+    for (size_t stride : strides) {
+      const size_t block = 8 * stride, blocks = (bytes + block - 1) / block;
+      const unsigned grid = static_cast<unsigned>(blocks * ((stride + 1023) >> 10));
+      auto launch = [&]() {
+        if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, a, b, bytes, stride, sink);
+        else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, a, b, bytes, stride, sink);
+        else hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, a, b, bytes, stride, sink);
+      };
+      for (int i = 0; i < 300; ++i) launch();
+      CK(hipDeviceSynchronize());
+      std::vector<float> ts;
+      for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 40; ++i) launch();
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ts.push_back(ms * 1000.0f / 40);
+      }
+      std::sort(ts.begin(), ts.end());
+      const double moved = (mode == 2 ? 2.0 : 1.0) * static_cast<double>(bytes);
+      std::printf("%s stride %6zu B: %8.1f us  %7.1f GB/s  %.3f of 8 TB/s\n", names[mode], stride, ts[2], moved / ts[2] * 1e-3, moved / (ts[2] * 1e-6) / 8e12);
+      std::fflush(stdout);
+    }
+  return 0;
+}
