@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <string>
 #include <vector>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
@@ -44,16 +45,39 @@ __global__ __launch_bounds__(256) void k(const uint8_t* __restrict__ src, uint8_
   if (MODE == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) sink[0] = 1;      // (never, on random data: keeps the loads alive)
 }
 
+// "comb": a workgroup's eight wave-rows sit 16 KiB apart inside ONE row of `rowbytes` bytes (columns [0, 128 KiB) of every row are walked;
+// what a horizontal strip's canvas would need: its rows are no multiple of 16 KiB apart, but 16 KiB steps along a row are)
+template <int MODE>
+__global__ __launch_bounds__(256) void kcomb(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t rowbytes, uint32_t* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t y = blockIdx.x >> 4, tc = blockIdx.x & 15;
+  u32x4 acc = {0, 0, 0, 0};
+  u32x4 v[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const size_t o = y * rowbytes + tc * 1024 + static_cast<size_t>(u * 4 + wave) * 16384 + static_cast<size_t>(lane) * 16;
+    if (MODE != 1) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + o));
+    else v[u] = u32x4{1u, 2u, 3u, 4u};
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const size_t o = y * rowbytes + tc * 1024 + static_cast<size_t>(u * 4 + wave) * 16384 + static_cast<size_t>(lane) * 16;
+    if (MODE == 0) acc ^= v[u];
+    else __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(dst + o));
+  }
+  if (MODE == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) sink[0] = 1;
+}
+
 int main(int argc, char** argv) {
   const size_t bytes = 438939648;
   const size_t cap = bytes + (8u << 20);
-  uint8_t *a, *b;
+  uint8_t *a_, *b;
   uint32_t* sink;
-  CK(hipMalloc(&a, cap)); CK(hipMalloc(&b, cap)); CK(hipMalloc(&sink, 256));
+  CK(hipMalloc(&a_, cap)); CK(hipMalloc(&b, cap)); CK(hipMalloc(&sink, 256));
   std::vector<uint32_t> h(cap / 4);
   uint32_t x = 12345;
   for (auto& w : h) { x = x * 1664525u + 1013904223u; w = x; }
-  CK(hipMemcpy(a, h.data(), cap, hipMemcpyHostToDevice));
+  CK(hipMemcpy(a_, h.data(), cap, hipMemcpyHostToDevice));
   CK(hipMemset(b, 0, cap));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -63,14 +87,45 @@ int main(int argc, char** argv) {
     for (int i = 1; i < argc; ++i) strides.push_back(static_cast<size_t>(std::atoll(argv[i])));
   }
   const char* names[] = {"read ", "write", "copy "};
+  if (argc > 2 && std::string(argv[1]) == "comb") {          // hbm_ceiling.bin comb rowbytes [rowbytes ...]
+    for (int a = 2; a < argc; ++a) {
+      const size_t rowbytes = static_cast<size_t>(std::atoll(argv[a]));
+      const size_t rows = bytes / rowbytes;
+      const unsigned grid = static_cast<unsigned>(rows * 16);
+      for (int mode = 0; mode < 3; ++mode) {
+        auto launch = [&]() {
+          if (mode == 0) hipLaunchKernelGGL(kcomb<0>, dim3(grid), dim3(256), 0, 0, a_, b, rowbytes, sink);
+          else if (mode == 1) hipLaunchKernelGGL(kcomb<1>, dim3(grid), dim3(256), 0, 0, a_, b, rowbytes, sink);
+          else hipLaunchKernelGGL(kcomb<2>, dim3(grid), dim3(256), 0, 0, a_, b, rowbytes, sink);
+        };
+        for (int i = 0; i < 300; ++i) launch();
+        CK(hipDeviceSynchronize());
+        std::vector<float> ts;
+        for (int r = 0; r < 5; ++r) {
+          CK(hipEventRecord(e0, 0));
+          for (int i = 0; i < 40; ++i) launch();
+          CK(hipEventRecord(e1, 0));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          ts.push_back(ms * 1000.0f / 40);
+        }
+        std::sort(ts.begin(), ts.end());
+        const double moved = (mode == 2 ? 2.0 : 1.0) * static_cast<double>(rows) * 131072.0;
+        std::printf("%s comb, rows of %7zu B (%zu rows x 128 KiB walked): %8.1f us  %7.1f GB/s  %.3f of 8 TB/s\n", names[mode], rowbytes, rows, ts[2], moved / ts[2] * 1e-3, moved / (ts[2] * 1e-6) / 8e12);
+        std::fflush(stdout);
+      }
+    }
+    return 0;
+  }
   for (int mode = 0; mode < 3; ++mode)
     for (size_t stride : strides) {
       const size_t block = 8 * stride, blocks = (bytes + block - 1) / block;
       const unsigned grid = static_cast<unsigned>(blocks * ((stride + 1023) >> 10));
       auto launch = [&]() {
-        if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, a, b, bytes, stride, sink);
-        else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, a, b, bytes, stride, sink);
-        else hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, a, b, bytes, stride, sink);
+        if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, a_, b, bytes, stride, sink);
+        else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, a_, b, bytes, stride, sink);
+        else hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), 0, 0, a_, b, bytes, stride, sink);
       };
       for (int i = 0; i < 300; ++i) launch();
       CK(hipDeviceSynchronize());
