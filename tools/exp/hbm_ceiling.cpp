@@ -23,21 +23,25 @@ __device__ inline size_t item_offset(size_t wg, int item, size_t stride, int lan
   if (col * 1024 + static_cast<size_t>(lane) * 16 + 16 > stride) return ~static_cast<size_t>(0) - 64;
   return block * 8 * stride + static_cast<size_t>(item) * stride + col * 1024 + static_cast<size_t>(lane) * 16;
 }
+// g_swz (set from the command line, "xcd" as first argument): workgroup ids are dealt round-robin over the 8 XCDs; with the swizzle XCD x walks
+// the x-th eighth of the buffer front to back instead of every eighth workgroup of the whole
+__constant__ int g_swz;
 template <int MODE>   // 0 read, 1 write, 2 copy
 __global__ __launch_bounds__(256) void k(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t bytes, size_t stride, uint32_t* sink) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t wg_ = g_swz ? static_cast<size_t>(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   u32x4 acc = {0, 0, 0, 0};
   {
     u32x4 v[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const size_t o = item_offset(blockIdx.x, u * 4 + wave, stride, lane);
+      const size_t o = item_offset(wg_, u * 4 + wave, stride, lane);
       if (MODE != 1 && o < bytes && o + 16 <= bytes) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + o));
       else v[u] = u32x4{1u, 2u, 3u, 4u};
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const size_t o = item_offset(blockIdx.x, u * 4 + wave, stride, lane);
+      const size_t o = item_offset(wg_, u * 4 + wave, stride, lane);
       if (MODE == 0) acc ^= v[u];
       else if (o < bytes && o + 16 <= bytes) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(dst + o));
     }
@@ -108,9 +112,12 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   std::vector<size_t> strides = {1024, 4096, 16128, 16384, 32000, 32768, 65536};
-  if (argc > 1) {                                   // hbm_ceiling.bin stride [stride ...]
+  int first = 1;
+  if (argc > 1 && std::string(argv[1]) == "xcd") { const int one = 1; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_swz), &one, sizeof(one))); first = 2; std::printf("XCD swizzle on\n"); }
+  else { const int zero = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_swz), &zero, sizeof(zero))); }
+  if (argc > first) {                                   // hbm_ceiling.bin [xcd] stride [stride ...]
     strides.clear();
-    for (int i = 1; i < argc; ++i) strides.push_back(static_cast<size_t>(std::atoll(argv[i])));
+    for (int i = first; i < argc; ++i) strides.push_back(static_cast<size_t>(std::atoll(argv[i])));
   }
   const char* names[] = {"read ", "write", "copy "};
   if (argc > 1 && std::string(argv[1]) == "hstrip") {
@@ -171,7 +178,7 @@ int main(int argc, char** argv) {
   for (int mode = 0; mode < 3; ++mode)
     for (size_t stride : strides) {
       const size_t block = 8 * stride, blocks = (bytes + block - 1) / block;
-      const unsigned grid = static_cast<unsigned>(blocks * ((stride + 1023) >> 10));
+      const unsigned grid = (static_cast<unsigned>(blocks * ((stride + 1023) >> 10)) + 7u) & ~7u;
       auto launch = [&]() {
         if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), 0, 0, a_, b, bytes, stride, sink);
         else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), 0, 0, a_, b, bytes, stride, sink);
