@@ -213,6 +213,19 @@ struct Check { uint32_t p, cz; Tally t; };
 // the same either way - it must be: the writing pass walks the stream with the general step from the states these passes agree on.
 // A lone lane's chain per symbol falls from ~70 dependent instructions to ~40 (it is latency, not issue, that paces these passes).
 constexpr uint32_t kFastEob = 0x400u;
+// Two rewrites of the counting step, measured on one box against the step that ships (0 / 0) and NOT taken (LAB_NOTES 1.2, "what paces a pass"):
+// IST_HUFF_STEP=1 - branch-free (selects instead of a dozen exec-mask regions; the slot's tables from a 64-bit scalar instead of LDS): launch
+// 850-870 us against 778-805; IST_HUFF_PAIRS=1 (needs STEP=1) - two AC symbols per look-up where an 11-bit pattern holds both: loop trips of the
+// busiest lane 214 -> 144, first pass 114 -> 104 us, launch 821-837 us.  Kept as compile-time switches with the instrumented build (IST_SYNC_DEBUG).
+#ifndef IST_HUFF_STEP
+#define IST_HUFF_STEP 0
+#endif
+#ifndef IST_HUFF_PAIRS
+#define IST_HUFF_PAIRS 0
+#endif
+#if IST_HUFF_PAIRS && !IST_HUFF_STEP
+#error "IST_HUFF_PAIRS needs IST_HUFF_STEP=1"
+#endif
 __device__ __forceinline__ uint16_t fast_entry(uint32_t e, bool isdc) {
   if (!e) return 0;
   const uint32_t L = e >> 8, rs = e & 255u;
@@ -226,18 +239,109 @@ __device__ __forceinline__ uint16_t fast_entry(uint32_t e, bool isdc) {
 }
 static_assert(kJpegDcLookBits == 9 && kJpegAcLookBits == 9, "fast table: 512 entries per table, code + magnitude bits <= 24 < 32");
 
+// TWO AC SYMBOLS PER LOOK-UP (round 4).  A counting pass is a chain of dependent steps - ~1250 cycles per loop trip, 214 trips for the busiest lane
+// of a workgroup's first pass (instrumented build, LAB_NOTES 1.2) - so what shortens it is fewer trips.  A photo's symbols average 5.4 bits: an
+// 11-bit look-ahead pattern often holds two whole AC symbols (codes and magnitude bits).  pair[] has one 16-bit entry per AC table and pattern:
+//   bit 15 = 1   bits 0-3 = the bits both symbols take   bits 4-9 = what both add to the zig-zag index (63: the second is the end of block)
+//   bits 10-14 = what the FIRST adds (the pair is used only while that keeps the index inside the block)          0 = no pair in this pattern
+// The first symbol is never an end of block, and a pair is taken only when it ENDS no later than the leg's limit, so the state a leg leaves
+// is bit for bit the one the single steps leave (tools/sim_slot_sync.cpp: 0.69 loop trips per symbol on the bench's photos).
+#if IST_HUFF_PAIRS
+constexpr int kPairBits = 11;
+__device__ __forceinline__ uint16_t pair_entry(const uint16_t* look_ac_tab, uint32_t pat) {
+  const uint32_t e1 = look_ac_tab[pat >> (kPairBits - kJpegAcLookBits)];
+  if (!e1) return 0;
+  const uint32_t L1 = e1 >> 8, r1 = (e1 >> 4) & 15u, s1 = e1 & 15u;
+  if (s1 == 0 && r1 != 15) return 0;                                  // end of block first: nothing to pair
+  const uint32_t tot1 = L1 + s1, adv1 = s1 == 0 ? 16u : r1 + 1u;
+  if (tot1 + 2 > static_cast<uint32_t>(kPairBits)) return 0;          // (a code has at least two bits)
+  const uint32_t R = kPairBits - tot1;
+  const uint32_t pat2 = (pat << tot1) & ((1u << kPairBits) - 1u);      // the rest of the pattern, left-aligned, zero-filled
+  const uint32_t e2 = look_ac_tab[pat2 >> (kPairBits - kJpegAcLookBits)];
+  if (!e2) return 0;
+  const uint32_t L2 = e2 >> 8, r2 = (e2 >> 4) & 15u, s2 = e2 & 15u;
+  if (L2 + s2 > R) return 0;                                          // the second symbol's code or magnitude bits reach past the pattern
+  const uint32_t advt = s2 == 0 ? (r2 == 15 ? adv1 + 16u : 63u) : adv1 + r2 + 1u;
+  return static_cast<uint16_t>(0x8000u | (tot1 + L2 + s2) | (advt << 4) | (adv1 << 10));
+}
+#endif
+
 template <int THREADS>
-__device__ __forceinline__ Tally run_count(const WgShared<THREADS>* sh, const uint16_t* fast, uint32_t first_bit, State& S, uint32_t limit, uint32_t mid,
-                                           bool have_ref, uint32_t old_p, uint32_t old_cz, const Tally& old_t, Check& ck) {
+__device__ __forceinline__ Tally run_count(const WgShared<THREADS>* sh, const uint16_t* fast, const uint16_t* pair, uint32_t first_bit, State& S, uint32_t limit, uint32_t mid,
+                                           bool have_ref, uint32_t old_p, uint32_t old_cz, const Tally& old_t, Check& ck
+#ifdef IST_SYNC_DEBUG
+                                           , uint32_t& g_dbg_iters
+#endif
+                                           ) {
   Tally T; T.blocks = 0; T.dc[0] = T.dc[1] = T.dc[2] = 0;
   const uint32_t slots = static_cast<uint32_t>(sh->img.slots);
-  uint32_t tabs = sh->slot_tabs[S.c];
   // (measured and dropped, round 4: keeping the bits at S.p in a register between symbols - one two-word LDS read per ~4 symbols
   // instead of one per symbol - changed nothing: sync launch 817-894 us against 808-881 us; nor did a pad word per 32 words of the
   // staged stream, which takes the lanes of a wave - 32 words apart - off each other's LDS bank: 801-893 us, writing pass 234-238
   // against 229-237 us)
+  // The step is BRANCH-FREE for every symbol the table holds (IST_HUFF_STEP=1, the default): DC and AC symbols, block ends and slot changes go
+  // through the same ~50 instructions with selects; the one branch left is the miss (a code longer than 9 bits), which takes the general step.
+  // The branchy form it replaces (IST_HUFF_STEP=0) spent a third of its ~75 instructions and a dozen exec-mask regions per symbol on
+  // "is it a DC symbol", "did it store", "did the block end" - each a VALU -> SGPR -> exec round trip - and read the next slot's tables from LDS;
+  // here the per-slot nibbles (DC table, AC table, component) of all ten slots sit in one 64-bit scalar.
+#if IST_HUFF_STEP
+  uint64_t packed = 0;
+  for (uint32_t k = 0; k < 10; ++k) {
+    const uint32_t t = sh->slot_tabs[k];
+    packed |= static_cast<uint64_t>((t & 1u) | (((t >> 8) & 1u) << 1) | (((t >> 16) & 3u) << 2)) << (4 * k);
+  }
+  uint32_t nib = static_cast<uint32_t>(packed >> (4 * S.c)) & 15u;
+#endif
   auto leg = [&](uint32_t until) {
+#if IST_HUFF_STEP
     while (S.p < until) {
+#ifdef IST_SYNC_DEBUG
+      ++g_dbg_iters;
+#endif
+      const bool isdc = S.z == 0;
+      const uint64_t w = window(sh, first_bit, S.p);
+      const uint32_t f = fast[((isdc ? (nib & 1u) : 2u + ((nib >> 1) & 1u)) << 9) + static_cast<uint32_t>(w >> 55)];
+#if IST_HUFF_PAIRS
+      // (both look-ups leave together: the pair's is not on the chain.  A DC lane reads an entry it ignores.)
+      const uint32_t e2 = pair[(((nib >> 1) & 1u) << kPairBits) + static_cast<uint32_t>(w >> (64 - kPairBits))];
+      const bool two = !isdc && e2 != 0u && S.z + ((e2 >> 10) & 31u) < 64u && S.p + (e2 & 15u) <= until;
+#else
+      const bool two = false; const uint32_t e2 = 0;
+#endif
+      if (__builtin_expect(f == 0u && !two, 0)) {                 // longer than the look-ahead, or no code: the general step
+#ifdef IST_SYNC_DEBUG
+        g_dbg_iters += 0x10000u;                                   // (high half: this lane's misses)
+#endif
+        uint32_t at = 1; int val = 0; bool stored = false, bad;
+        symbol<false>(sh, first_bit, S, sh->slot_tabs[S.c], &at, &val, &stored, &bad);
+        if (stored && at == 0) { const uint32_t comp = nib >> 2; T.dc[0] += comp == 0 ? val : 0; T.dc[1] += comp == 1 ? val : 0; T.dc[2] += comp == 2 ? val : 0; }
+        if (S.z >= 64) { S.z = 0; S.c = (S.c + 1 == slots) ? 0u : S.c + 1; ++T.blocks; nib = static_cast<uint32_t>(packed >> (4 * S.c)) & 15u; }
+        continue;
+      }
+      const uint32_t tot1 = f & 31u, L = (f >> 11) & 15u, sz = tot1 - L;
+      const uint32_t tot = two ? (e2 & 15u) : tot1;
+      // the DC difference (sz magnitude bits behind the code; 0 bits -> 0), computed for every symbol and kept for DC symbols only
+      const uint32_t raw = static_cast<uint32_t>(((w << L) >> 1) >> (63u - sz));
+      const int ext = (raw < ((1u << sz) >> 1)) ? static_cast<int>(raw) - (1 << sz) + 1 : static_cast<int>(raw);
+      const int val = isdc ? ext : 0;
+      const uint32_t comp = nib >> 2;
+      T.dc[0] += comp == 0 ? val : 0; T.dc[1] += comp == 1 ? val : 0; T.dc[2] += comp == 2 ? val : 0;
+      S.p += tot;
+      const uint32_t advt = (e2 >> 4) & 63u;
+      const uint32_t z = two ? (advt == 63u ? 64u : S.z + advt) : ((f & kFastEob) ? 64u : S.z + ((f >> 5) & 31u));      // (a DC entry advances by 1)
+      const bool fin = z >= 64u;
+      const uint32_t c1 = (S.c + 1 == slots) ? 0u : S.c + 1;
+      S.z = fin ? 0u : z;
+      S.c = fin ? c1 : S.c;
+      T.blocks += fin ? 1u : 0u;
+      nib = static_cast<uint32_t>(packed >> (4 * S.c)) & 15u;
+    }
+#else
+    uint32_t tabs = sh->slot_tabs[S.c];
+    while (S.p < until) {
+#ifdef IST_SYNC_DEBUG
+      ++g_dbg_iters;
+#endif
       const bool isdc = S.z == 0;
       const uint64_t w = window(sh, first_bit, S.p);
       const uint32_t f = fast[(((isdc ? 0u : 2u) + ((isdc ? tabs : (tabs >> 8)) & 1u)) << 9) + static_cast<uint32_t>(w >> 55)];
@@ -251,7 +355,12 @@ __device__ __forceinline__ Tally run_count(const WgShared<THREADS>* sh, const ui
           S.z = 1;
         } else S.z = (f & kFastEob) ? 64u : S.z + ((f >> 5) & 31u);
         S.p += tot;
-      } else symbol<false>(sh, first_bit, S, tabs, &at, &val, &stored, &bad);
+      } else {
+#ifdef IST_SYNC_DEBUG
+        g_dbg_iters += 0x10000u;
+#endif
+        symbol<false>(sh, first_bit, S, tabs, &at, &val, &stored, &bad);
+      }
       if (stored && at == 0) {
         const uint32_t comp = tabs >> 16;
         T.dc[0] += comp == 0 ? val : 0; T.dc[1] += comp == 1 ? val : 0; T.dc[2] += comp == 2 ? val : 0;
@@ -263,6 +372,7 @@ __device__ __forceinline__ Tally run_count(const WgShared<THREADS>* sh, const ui
         tabs = sh->slot_tabs[S.c];
       }
     }
+#endif
   };
   leg(min(mid, limit));
   const uint32_t cz = (S.c << 8) | S.z;
@@ -385,13 +495,29 @@ constexpr int kInnerPasses = 48;
 constexpr int kGhosts = IST_GHOSTS;
 constexpr int kSyncBlock = kSyncThreads + 64;
 
+#ifdef IST_SYNC_DEBUG          // measurement build only (tools/exp_huff.py with IST_LIB_PATH): per workgroup of the FIRST launch - passes, 10 ns ticks in all,
+__device__ uint32_t g_sync_dbg[8 * 8192];   // in staging, in pass 0, and the longest single later pass
+#endif
 __global__ __launch_bounds__(kSyncBlock) void ist_jpeg_sync_kernel(const SyncArgs A) {
+#ifdef IST_SYNC_DEBUG
+  const uint64_t dbg_t0 = wall_clock64();
+  uint64_t dbg_staged = dbg_t0, dbg_pass0 = dbg_t0, dbg_prev = dbg_t0, dbg_longest = 0;
+  uint32_t dbg_passes = 0, dbg_redo_lanes = 0, dbg_iters = 0, dbg_iters0 = 0;
+  uint64_t dbg_c0 = 0, dbg_c1 = 0;
+  __shared__ uint32_t dbg_max_iters, dbg_miss;
+  if (threadIdx.x == 0) { dbg_max_iters = 0; dbg_miss = 0; }
+#endif
   __shared__ uint32_t ex_p[kSyncThreads + kGhosts], ex_cz[kSyncThreads + kGhosts];
   constexpr int kHalves = kSyncThreads / 128;                    // groups of kWriteThreads subsequences per workgroup
   static_assert(kSyncThreads % 128 == 0 && kHalves >= 1 && kHalves <= 2, "half totals");
   __shared__ uint32_t tot[kHalves][4];
   __shared__ WgShared<kSyncThreads + kGhosts> sh;
   __shared__ uint16_t fast[4 << 9];                              // the counting step's table: DC 0, DC 1, AC 0, AC 1
+#if IST_HUFF_PAIRS
+  __shared__ uint16_t pair[2 << kPairBits];                      // ... and its pairs: AC 0, AC 1
+#else
+  const uint16_t* pair = nullptr;
+#endif
   const int tid = threadIdx.x;
   const bool owned = tid < kSyncThreads;
   const int g0 = blockIdx.x * kSyncThreads;                      // (the grid is exactly the padded subsequence count / kSyncThreads)
@@ -434,7 +560,14 @@ __global__ __launch_bounds__(kSyncBlock) void ist_jpeg_sync_kernel(const SyncArg
   if (any) {
     load_stream(&sh, gimg, first_bit);
     for (int k = tid; k < (4 << 9); k += kSyncBlock) fast[k] = fast_entry(k < (2 << 9) ? sh.tab.look_dc[k >> 9][k & 511] : sh.tab.look_ac[(k >> 9) - 2][k & 511], k < (2 << 9));
+#if IST_HUFF_PAIRS
+    for (int k = tid; k < (2 << kPairBits); k += kSyncBlock) pair[k] = pair_entry(sh.tab.look_ac[k >> kPairBits], static_cast<uint32_t>(k) & ((1u << kPairBits) - 1u));
+#endif
     __syncthreads();
+#ifdef IST_SYNC_DEBUG
+    dbg_staged = dbg_prev = wall_clock64();
+    dbg_c0 = clock64();
+#endif
     for (int it = 0; it < kInnerPasses; ++it) {
       uint32_t sp = 0, scz = 0;
       if (live && i != 0) {                            // (the first subsequence of an image starts from the true state 0, 0, 0)
@@ -450,14 +583,34 @@ __global__ __launch_bounds__(kSyncBlock) void ist_jpeg_sync_kernel(const SyncArg
       const bool redo = live && !(have && st_p == sp && st_cz == scz);
       if (redo) {
         State S; S.p = sp; S.c = scz >> 8; S.z = scz & 255u;
-        T = run_count(&sh, fast, first_bit, S, limit, i * static_cast<uint32_t>(kSubBits) + kCheckBits, have, my_p, my_cz, T, ck);
+        T = run_count(&sh, fast, pair, first_bit, S, limit, i * static_cast<uint32_t>(kSubBits) + kCheckBits, have, my_p, my_cz, T, ck
+#ifdef IST_SYNC_DEBUG
+                      , dbg_iters
+#endif
+                      );
         my_p = S.p; my_cz = (S.c << 8) | S.z;
         st_p = sp; st_cz = scz; have = true;
       }
       __syncthreads();                                 // every thread has read its neighbour's previous exit state
       if (live) { ex_p[e] = my_p; ex_cz[e] = my_cz; }
+#ifdef IST_SYNC_DEBUG
+      {
+        const uint64_t now = wall_clock64();
+        if (it == 0) { dbg_pass0 = now; dbg_c1 = clock64(); atomicMax(&dbg_max_iters, dbg_iters & 0xFFFFu); atomicAdd(&dbg_miss, dbg_iters >> 16); } else dbg_longest = max(dbg_longest, now - dbg_prev);
+        dbg_prev = now; ++dbg_passes;
+        dbg_redo_lanes += __syncthreads_count(redo ? 1 : 0);
+      }
+#endif
       if (!__syncthreads_or(redo ? 1 : 0)) { settled = true; break; }
     }
+#ifdef IST_SYNC_DEBUG
+    if (A.pass == 0 && tid == 0 && blockIdx.x < 8192) {
+      uint32_t* q = g_sync_dbg + 8 * blockIdx.x;
+      q[0] = dbg_passes; q[1] = static_cast<uint32_t>(wall_clock64() - dbg_t0); q[2] = static_cast<uint32_t>(dbg_staged - dbg_t0);
+      q[3] = static_cast<uint32_t>(dbg_pass0 - dbg_staged); q[4] = static_cast<uint32_t>(dbg_longest); q[5] = dbg_redo_lanes;
+      q[6] = static_cast<uint32_t>(dbg_c1 - dbg_c0); q[7] = dbg_max_iters | 0x80000000u | (min(dbg_miss, 0x7FFFu) << 16);
+    }
+#endif
   }
   // the tallies of each half of the workgroup, for the writing pass's bases (integer adds: order does not matter)
   if (live && owned) {
@@ -705,6 +858,21 @@ int jpeg_gpu_entropy_decode(const std::vector<JpegGpuItem>& items, std::vector<u
     hipLaunchKernelGGL(ist_jpeg_sync_kernel, dim3(static_cast<unsigned>(ns / kSyncThreads)), dim3(kSyncBlock), 0, stream, A);
     JG_HIP(hipGetLastError());
     cur ^= 1;
+#ifdef IST_SYNC_DEBUG
+    if (pass == 0) {
+      JG_HIP(hipStreamSynchronize(stream));
+      const unsigned nwg = std::min<unsigned>(8192u, static_cast<unsigned>(ns / kSyncThreads));
+      std::vector<uint32_t> dbg(8 * static_cast<size_t>(nwg));
+      JG_HIP(hipMemcpyFromSymbol(dbg.data(), HIP_SYMBOL(g_sync_dbg), dbg.size() * 4));
+      std::vector<uint32_t> tot, p0, st, passes, longest, cyc, iters; uint64_t redo = 0; uint32_t tmin = 0, tmax = 0;
+      for (unsigned w = 0; w < nwg; ++w) { const uint32_t* q = &dbg[8 * w]; if (!q[7]) continue; passes.push_back(q[0]); tot.push_back(q[1]); st.push_back(q[2]); p0.push_back(q[3]); longest.push_back(q[4]); redo += q[5];
+        cyc.push_back(q[6]); iters.push_back(q[7] & 0xFFFFu); tmax += (q[7] >> 16) & 0x7FFFu; }
+      auto pct = [](std::vector<uint32_t> v, double f) { std::sort(v.begin(), v.end()); return v.empty() ? 0u : v[static_cast<size_t>(f * (v.size() - 1))]; };
+      std::fprintf(stderr, "[sync debug] %zu workgroups; ticks of 10 ns.  total p50 %u p90 %u max %u | staging p50 %u max %u | pass 0 p50 %u p90 %u max %u | passes p50 %u p90 %u max %u | longest later pass p50 %u max %u | lane re-decodes %llu | pass 0: clock64 ticks p50 %u, loop trips of the busiest lane p50 %u; misses (general step, all lanes of all workgroups, pass 0) %u\n",
+                   tot.size(), pct(tot, .5), pct(tot, .9), pct(tot, 1.0), pct(st, .5), pct(st, 1.0), pct(p0, .5), pct(p0, .9), pct(p0, 1.0), pct(passes, .5), pct(passes, .9), pct(passes, 1.0),
+                   pct(longest, .5), pct(longest, 1.0), static_cast<unsigned long long>(redo), pct(cyc, .5), pct(iters, .5), tmax - tmin);
+    }
+#endif
     if (pass == 0) continue;                       // (the first launch starts from guesses: a second one always runs)
     *h_flag = 1u;
     JG_HIP(hipMemcpyAsync(const_cast<uint32_t*>(h_flag), d_flag, 4, hipMemcpyDeviceToHost, stream));

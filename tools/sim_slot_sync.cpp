@@ -162,6 +162,27 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 64; ++k) if (hist_b[static_cast<size_t>(k)]) std::printf(" %d:%d", k, hist_b[static_cast<size_t>(k)]);
     std::printf("\n");
   }
+  // ---- loop trips of a counting pass if ONE look-up resolved up to two AC symbols (an index of W bits holding both codes and their magnitude
+  // bits; never across a block end; the first symbol of a block - DC - always alone): trips per symbol along the true path of the scan
+  {
+    struct Sym { int bits; bool dc, ends; };
+    std::vector<Sym> syms;
+    St S{0, 0, 0};
+    while (S.p < G.bits) {
+      const St b = S;
+      S = run(St{b.p, b.c, b.z}, b.p + 1);                          // run() stops once p has moved: exactly one symbol
+      syms.push_back(Sym{static_cast<int>(S.p - b.p), b.z == 0, S.z == 0});
+    }
+    for (int W = 9; W <= 13; ++W) {
+      long trips = 0;
+      for (size_t k = 0; k < syms.size();) {
+        ++trips;
+        if (!syms[k].dc && !syms[k].ends && k + 1 < syms.size() && syms[k].bits + syms[k + 1].bits <= W) k += 2; else k += 1;
+      }
+      std::printf("two AC symbols per look-up, %2d-bit index: %.3f loop trips per symbol (%zu symbols, %.2f bits each)\n", W, static_cast<double>(trips) / syms.size(), syms.size(),
+                  static_cast<double>(G.bits) / syms.size());
+    }
+  }
   const double t = static_cast<double>(same + pz_only + diff), tg = static_cast<double>(g_ok + g_pz + g_bad);
   std::printf("%d subsequences of %lld bits, %d blocks per MCU\n", nsub, static_cast<long long>(SUB), G.slots);
   std::printf("start = true (position, index), wrong slot:   exit true %.3f | slot wrong only %.3f | elsewhere %.3f\n", same / t, pz_only / t, diff / t);
