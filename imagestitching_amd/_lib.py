@@ -64,6 +64,11 @@ class Part(C.Structure):
                 ("sx0", C.c_int32), ("sy0", C.c_int32), ("sx1", C.c_int32), ("sy1", C.c_int32), ("in_place", C.c_int32)]
 
 
+class FlatCell(C.Structure):
+    _fields_ = [("path", C.c_int32), ("image", C.c_int32), ("X0", C.c_int32), ("Y0", C.c_int32), ("X1", C.c_int32), ("Y1", C.c_int32),
+                ("src_offset", C.c_int64), ("bg", C.c_uint32), ("opaque", C.c_int32)]
+
+
 class JobInfo(C.Structure):
     _fields_ = [("canvas_w", C.c_int64), ("canvas_h", C.c_int64), ("n_ops", C.c_int32), ("n_cells", C.c_int32),
                 ("n_tiles", C.c_int64), ("out_pixels", C.c_int64), ("src_pixels_touched", C.c_int64),
@@ -87,6 +92,8 @@ SYMBOLS = [
     ("ist_plan_free", None, [C.POINTER(Plan)]),
     ("ist_plan_ops", C.c_int, [C.POINTER(Plan), C.POINTER(ImageDesc), C.c_int, C.POINTER(Op), C.POINTER(C.c_int)]),
     ("ist_op_box", C.c_int, [C.POINTER(Op), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int32)]),
+    ("ist_debug_flat_form", C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(Op), C.c_int, C.POINTER(ImageDesc), C.c_int, C.c_int,
+                                      C.POINTER(Region), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(FlatCell), C.c_int, C.POINTER(C.c_int)]),
     ("ist_shard_parts", C.c_int, [C.POINTER(Op), C.c_int, C.c_int64, C.c_int64, C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(Part), C.c_int, C.POINTER(C.c_int)]),
     ("ist_shard_row_cuts", C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_int32)]),

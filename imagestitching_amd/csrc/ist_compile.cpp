@@ -673,3 +673,39 @@ extern "C" int ist_op_box(const ist_op* op, int64_t canvas_w, int64_t canvas_h, 
   box[0] = r.X0; box[1] = r.Y0; box[2] = r.X1; box[3] = r.Y1;
   return rc;
 }
+
+// The flat form of a job as the kernel will walk it - pure CPU, for tests (tests/test_flat_form.py replays it in numpy against the op list):
+// one record per cell of the twin's table.  *n_cells = 0 (and IST_OK) when the job has no flat form.
+extern "C" int ist_debug_flat_form(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,
+                                   const ist_image_desc* images, int n_images, int filter, const ist_region* clip, int64_t* pitch,
+                                   int64_t* dst_offset, ist_flat_cell* cells, int max_cells, int* n_cells) {
+  if (!n_cells || (max_cells > 0 && !cells)) return ist::fail(IST_E_INVALID, "ist_debug_flat_form: NULL argument");
+  *n_cells = 0;
+  static const uint8_t transparent[4] = {0, 0, 0, 0};
+  ist::Compiled primary;
+  int rc = ist::compile_ops(canvas_w, canvas_h, clear_rgba ? clear_rgba : transparent, ops, n_ops, images, n_images, filter, clip, &primary);
+  if (rc != IST_OK) return rc;
+  const std::unique_ptr<ist::FlatTwin> t = ist::compile_flat_twin(canvas_w, canvas_h, clear_rgba ? clear_rgba : transparent, ops, n_ops, images, n_images, filter, primary);
+  if (!t) return IST_OK;
+  if (pitch) *pitch = static_cast<int64_t>(ist::kFlatPitch);
+  if (dst_offset) *dst_offset = t->dst_delta;
+  const int64_t P = static_cast<int64_t>(ist::kFlatPitch);
+  int n = 0;
+  for (const ist::DevCell& c : t->host.cells) {
+    if (n < max_cells) {
+      ist_flat_cell& o = cells[n];
+      std::memset(&o, 0, sizeof(o));
+      o.path = c.path; o.image = -1; o.X0 = c.X0; o.Y0 = c.Y0; o.X1 = c.X1; o.Y1 = c.Y1; o.bg = c.bg;
+      if (c.path == ist::PATH_COPY) {
+        const ist::DevOp& d = t->host.ops[static_cast<size_t>(c.op)];
+        const ist::FlatTwin::Src& v = t->src[static_cast<size_t>(d.image)];
+        o.image = v.image;
+        o.opaque = (d.flags & ist::OPF_OPAQUE) ? 1 : 0;
+        o.src_offset = v.delta + (static_cast<int64_t>(c.Y0) + static_cast<int64_t>(d.oy)) * P + (static_cast<int64_t>(c.X0) + static_cast<int64_t>(d.ox)) * 4;
+      }
+    }
+    ++n;
+  }
+  *n_cells = n;
+  return n > max_cells && max_cells > 0 ? ist::fail(IST_E_INVALID, "ist_debug_flat_form: more cells than max_cells") : IST_OK;
+}

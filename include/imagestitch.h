@@ -158,6 +158,21 @@ IST_API int ist_plan_ops(const ist_plan* plan, const ist_image_desc* images, int
  * `filter` (pixel centre, or every touched pixel with IST_FILTER_EDGE_AA).  Returns 1 when the op draws nothing.
  * Pure CPU; what the multi-GPU layer uses to cut a stitch into per-image bands. */
 IST_API int ist_op_box(const ist_op* op, int64_t canvas_w, int64_t canvas_h, int filter, int32_t box[4]);
+/* The flat form of an op list as the kernel will walk it (pure CPU, no GPU needed; a test aid): when every op covers whole canvas
+ * rows at unit scale, ist_job_launch on dense rows moves the same bytes as rows of *pitch bytes starting *dst_offset bytes into the
+ * destination.  One record per cell: rows Y0..Y1-1, pixels X0..X1-1 of that wide canvas; path 0 = fill with bg (packed R,G,B,A),
+ * 1 = copy from src[image] starting src_offset bytes into it (+ *pitch per row), source-over bg unless opaque.  *n_cells = 0 when
+ * the op list has no flat form.  tests/test_flat_form.py replays the records in numpy against the op list. */
+typedef struct ist_flat_cell {
+  int32_t path, image;
+  int32_t X0, Y0, X1, Y1;
+  int64_t src_offset;
+  uint32_t bg;
+  int32_t opaque;
+} ist_flat_cell;
+IST_API int ist_debug_flat_form(int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,
+                                const ist_image_desc* images, int n_images, int filter, const ist_region* clip, int64_t* pitch,
+                                int64_t* dst_offset, ist_flat_cell* cells, int max_cells, int* n_cells);
 
 /* ---- sharding: one stitch cut into parts for a group of GPUs (pure CPU) ----------------------------------------- */
 /* The per-image iterations of onStitch are independent once the cursor is planned (index.js:1439-1554).  A PART is a
