@@ -105,6 +105,7 @@ SYMBOLS = [
     ("ist_job_create", C.c_void_p, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_uint8), C.POINTER(Op), C.c_int,
                                     C.POINTER(ImageDesc), C.c_int, C.c_int, C.POINTER(Region)]),
     ("ist_job_info_get", C.c_int, [C.c_void_p, C.POINTER(JobInfo)]),
+    ("ist_job_preferred_dst_pitch", C.c_size_t, [C.c_void_p]),
     ("ist_job_launch", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("ist_job_destroy", None, [C.c_void_p]),
     ("ist_group_create", C.c_void_p, [C.POINTER(C.c_int), C.c_int]),

@@ -271,6 +271,12 @@ int ist_job_info_get(const ist_job* job, ist_job_info* out) {
   return IST_OK;
 }
 
+size_t ist_job_preferred_dst_pitch(const ist_job* job) {
+  if (!job) return 0;
+  const size_t row = static_cast<size_t>(job->host.rx1 - job->host.rx0) * 4;      // (a clipped job renders into a buffer as wide as its region)
+  return job->flat ? row : (row + 4095) & ~static_cast<size_t>(4095);
+}
+
 int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch, int n_images, void* dst,
                    size_t dst_pitch, void* stream) {
   if (!job || !dst) return fail(IST_E_INVALID, "ist_job_launch: NULL argument");

@@ -447,14 +447,29 @@ def encode_png_device(canvas, out=None, stream=None, device=None, level=None):
 class StitchJob:
     """A compiled op list on one device: re-launchable on new source / destination buffers with no upload."""
 
-    def __init__(self, ctx, handle, n_images):
-        self._ctx, self._h, self.n_images = ctx, handle, n_images
+    def __init__(self, ctx, handle, n_images, device=0):
+        self._ctx, self._h, self.n_images, self._device = ctx, handle, n_images, int(device)
         info = L.JobInfo()
         L.check(L.lib.ist_job_info_get(handle, C.byref(info)))
         self.info = {k: getattr(info, k) for k, _ in L.JobInfo._fields_}
         self.canvas_w, self.canvas_h = int(info.canvas_w), int(info.canvas_h)
         self._src = (C.c_void_p * max(1, n_images))()
         self._pitch = (C.c_size_t * max(1, n_images))()
+
+    @property
+    def preferred_pitch(self):
+        """bytes per canvas row this job runs fastest on (ist_job_preferred_dst_pitch): dense rows for a strip the library walks in its
+        flat form, otherwise rows padded to a multiple of 4 KiB"""
+        return int(L.lib.ist_job_preferred_dst_pitch(self._h))
+
+    def empty_canvas(self, device=None):
+        """an uninitialised canvas tensor (canvas_h x canvas_w x 4, uint8) on the job's device whose row pitch is preferred_pitch"""
+        import torch
+        dev = torch.device("cuda", self._device if device is None else device)
+        pitch = self.preferred_pitch
+        raw = torch.empty((self.canvas_h * pitch + 4096,), dtype=torch.uint8, device=dev)
+        off = (-raw.data_ptr()) % 4096
+        return raw[off:off + self.canvas_h * pitch].view(self.canvas_h, pitch // 4, 4)[:, :self.canvas_w]
 
     def launch_ptrs(self, src_ptrs, src_pitches, dst_ptr, dst_pitch, stream=0):
         for i, (p, q) in enumerate(zip(src_ptrs, src_pitches)):
@@ -499,7 +514,7 @@ class Stitcher:
                                  _FILTERS[filter] if isinstance(filter, str) else int(filter), region)
         if not h:
             raise L.StitchError(-1, L.last_error())
-        return StitchJob(self._ctx, h, n_images)
+        return StitchJob(self._ctx, h, n_images, self.device)
 
     def compile(self, images, direction, opts=None, only_images=None):
         """Plan + compile.  only_images: iterable of image indices this device renders (multi-GPU sharding);

@@ -229,6 +229,11 @@ IST_API ist_job* ist_job_create(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h
                                 const ist_op* ops, int n_ops, const ist_image_desc* images, int n_images,
                                 int filter, const ist_region* clip);
 IST_API int ist_job_info_get(const ist_job* job, ist_job_info* out);
+/* The destination row pitch (bytes) this job runs fastest on, for a host that allocates the canvas itself: 4 * canvas_w (dense rows)
+ * when the job has a flat form - a strip of whole rows at unit scale, which ist_job_launch then walks as rows of 32 KiB - otherwise
+ * 4 * canvas_w rounded up to a multiple of 4096 (measured: INTEGRATION.md "Row pitch").  Any pitch >= 4 * canvas_w that is a multiple
+ * of 4 stays legal.  0 on a NULL job. */
+IST_API size_t ist_job_preferred_dst_pitch(const ist_job* job);
 /* one fused launch: every canvas pixel (in clip) is written exactly once.  src[i] / dst are DEVICE pointers.
  * stream = hipStream_t (NULL = default stream).  Asynchronous: returns after enqueueing. */
 IST_API int ist_job_launch(ist_job* job, const void* const* src, const size_t* src_pitch, int n_images,

@@ -190,3 +190,22 @@ def test_a_clip_of_whole_rows_is_a_shorter_flat_canvas():
     out = torch.zeros((1400, w, 4), dtype=torch.uint8, device=DEV)
     assert _launch(job, srcs, out) == 0
     assert np.array_equal(out.cpu().numpy()[:, 10:], ref[:, 10:])
+
+
+def test_the_pitch_a_job_prefers():
+    """ist_job_preferred_dst_pitch: dense rows where the flat form applies, rows padded to 4 KiB where it does not; a canvas made with
+    it renders the oracle's pixels either way"""
+    st = ist.Stitcher(0)
+    same = [U.rand_image(160 + i, 400, 700) for i in range(3)]
+    p, job = st.compile([{"width": 700, "height": 400, "opaque": True}] * 3, "vertical", {"filter": "nearest"})
+    assert job.preferred_pitch == 700 * 4
+    out = job.empty_canvas()
+    assert out.stride(0) == 700 * 4 and _launch(job, [_dense(a) for a in same], out) == 1
+    assert np.array_equal(out.cpu().numpy(), U.oracle_stitch(same, "vertical", {"filter": "nearest"})[0])
+    p, job = st.compile([{"width": 700, "height": 400, "opaque": True}] * 3, "horizontal", {"filter": "nearest"})
+    assert job.preferred_pitch == 12288 and p.canvas_w == 2100      # 8400 bytes -> the next multiple of 4096
+    out = job.empty_canvas()
+    assert out.stride(0) == 3072 * 4 and out.shape == (400, 2100, 4) and out.data_ptr() % 4096 == 0
+    assert _launch(job, [_dense(a) for a in same], out) == 0
+    assert np.array_equal(out.cpu().numpy(), U.oracle_stitch(same, "horizontal", {"filter": "nearest"})[0])
+    assert L.lib.ist_job_preferred_dst_pitch(None) == 0
