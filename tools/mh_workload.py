@@ -15,8 +15,9 @@ import imagestitching_amd as ist  # noqa: E402
 
 MIXED = [(4032, 3024), (3024, 4032), (4000, 3000), (3840, 2160), (4032, 3024), (3024, 4032), (4000, 3000), (3840, 2160), (4032, 3024)]
 UNIFORM = [(4032, 3024)] * 9
+CONFIG5 = [(8000, 6000)] * 64            # BASELINE configs[4]: 24.6 GB moved per launch; run it with --sets 1 --preroll 20 --launches 10
 CONFIGS = {"mixed_horizontal": (MIXED, "horizontal"), "mixed_vertical": (MIXED, "vertical"),
-           "uniform_horizontal": (UNIFORM, "horizontal"), "uniform_vertical": (UNIFORM, "vertical"),
+           "uniform_horizontal": (UNIFORM, "horizontal"), "uniform_vertical": (UNIFORM, "vertical"), "config5": (CONFIG5, "vertical"),
            "exif6_scaled": (MIXED, "vertical"), "exif6_unit": (UNIFORM, "vertical")}     # every image quarter-turned (EXIF 6)
 
 
