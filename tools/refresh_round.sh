@@ -22,6 +22,7 @@ bash tools/profile_file_pipeline.sh $TAG > gpurun_out/${TAG}_file_pipeline.log 2
 bash tools/profile_decode.sh $TAG > gpurun_out/${TAG}_decode.log 2>&1 || echo "decode trace failed (see gpurun_out/${TAG}_decode.log)"
 COUNTERS="FETCH_SIZE WRITE_SIZE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" bash tools/profile_kernels_pmc.sh ${TAG}_reconstruct "ist_jpeg" tools/exp_huff.py 4 > gpurun_out/${TAG}_reconstruct_pmc.log 2>&1 || echo "decode counter passes failed"
 python3 tools/exp_config5.py > gpurun_out/${TAG}_config5_widths.txt 2>&1 || true      # configs[4]: working set and row pitch (un-profiled)
+bash tools/profile_config5.sh $TAG > gpurun_out/${TAG}_config5.log 2>&1 || echo "configs[4] passes failed (see gpurun_out/${TAG}_config5.log)"   # -> gpurun_out/${TAG}_config5.txt
 python3 - <<PY
 import json
 d = json.loads(open("gpurun_out/${TAG}_bench_line.json").read().strip().splitlines()[-1])
