@@ -640,6 +640,10 @@ std::unique_ptr<FlatTwin> compile_flat_twin(int64_t canvas_w, int64_t canvas_h, 
       vimg.push_back(d);
     }
   }
+  // Every op boundary that is no multiple of kFlatPitch costs a head and a tail row of tiles with one row in eight used.  Measured
+  // (tools/exp_thin.py, 400 MB strips): images of 1.6 / 4 / 8 / 16 MB each -> flat form -4.6 % / -2 % / 0 / +2.5 % against the row
+  // form; strips under ~64 MB run at the launch floor either way.  A large strip of small images keeps the row form.
+  if (total >= (64ll << 20) && total / std::max<int64_t>(1, static_cast<int64_t>(vimg.size())) < (8ll << 20)) return nullptr;
   const int64_t vh = (total + P - 1) / P;
   if (total % P) {                                    // the wide canvas's last row ends past the region: never written
     ist_op h;

@@ -145,3 +145,20 @@ def test_jobs_without_a_flat_form():
     assert not _flat_form(1024, 900, [_op(1, 0, 1024, 0, 900)], wide, 1)[2]           # rows of 4 KiB need no other walk
     small = [_op(0, -1, w, 0, 100, rgba=(1, 2, 3, 255)), _op(1, 0, w, 0, 100)]
     assert not _flat_form(w, 100, small, descs, 2)[2]                                  # too small for the pitch to matter
+
+
+def test_a_large_strip_of_small_images_keeps_the_row_form():
+    """every image boundary costs a head and a tail row of nearly empty tiles: measured (tools/exp_thin.py) the flat form loses below ~8 MB per
+    image on strips large enough to leave the launch floor (64 MB)"""
+    w = 2000
+
+    def strip(n, hh):
+        descs = (L.ImageDesc * n)()
+        for i in range(n):
+            descs[i].width, descs[i].height, descs[i].opaque = w, hh, 1
+        ops = [_op(0, -1, w, 0, n * hh, rgba=(255, 255, 255, 255))] + [_op(1, i, w, i * hh, hh) for i in range(n)]
+        return _flat_form(w, n * hh, ops, descs, n)[2]
+
+    assert not strip(100, 100)          # 80 MB of 0.8 MB images
+    assert strip(10, 1100)              # 88 MB of 8.8 MB images
+    assert strip(50, 100)               # 40 MB: under the floor both forms cost the same; the flat one stays

@@ -105,6 +105,11 @@ def test_jobs_it_does_not_apply_to_keep_the_row_form():
     assert run(mixed, "vertical", {"filter": "nearest", "mode": "original"}) == 0     # one image is narrower than the canvas
     small = [U.rand_image(120 + i, 100, 612) for i in range(3)]
     assert run(small, "vertical", {"filter": "nearest"}) == 0                         # under 64 rows of 32 KiB
+    st2 = ist.Stitcher(0)                                                             # a large strip of small images (tools/exp_thin.py)
+    p2, job2 = st2.compile([{"width": 2000, "height": 100, "opaque": True}] * 100, "vertical", {"filter": "nearest"})
+    thin = [torch.empty((100, 2000, 4), dtype=torch.uint8, device=DEV).random_(0, 256) for _ in range(100)]
+    out2 = torch.empty((p2.canvas_h, p2.canvas_w, 4), dtype=torch.uint8, device=DEV)
+    assert _launch(job2, thin, out2) == 0 and torch.equal(out2, torch.cat(thin, 0))
     aligned = [U.rand_image(130 + i, 300, 1024) for i in range(3)]
     assert run(aligned, "vertical", {"filter": "nearest"}) == 0                       # 4 KiB rows already
 
