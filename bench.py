@@ -248,10 +248,9 @@ def canvas_pitch_leg(st, dev, torch):
         imgs = [{"width": w, "height": h, "opaque": True} for (w, h) in sizes]
         p, job = st.compile(imgs, direction, {"filter": "bilinear"})
         srcs = [synth(k, w, h, dev) for k, (w, h) in enumerate(sizes)]
-        pitch = (p.canvas_w * 4 + 4095) // 4096 * 4096
-        raw = torch.empty((p.canvas_h * pitch + 4096,), dtype=torch.uint8, device=dev)
-        off = (-raw.data_ptr()) % 4096
-        canvas = raw[off:off + p.canvas_h * pitch].view(p.canvas_h, pitch // 4, 4)[:, :p.canvas_w]
+        canvas = job.empty_canvas()                  # the pitch the job itself asks for (ist_job_preferred_dst_pitch): here the next multiple of 4 KiB
+        pitch = canvas.stride(0)
+        assert pitch % 4096 == 0 and pitch >= p.canvas_w * 4
         for _ in range(PREROLL_LAUNCHES):
             job.launch(srcs, canvas)
         torch.cuda.synchronize()
@@ -267,7 +266,7 @@ def canvas_pitch_leg(st, dev, torch):
         us = sorted(ts)[2]
         out[name] = {"canvas_row_bytes": pitch, "dense_row_bytes": p.canvas_w * 4, "kernel_us": round(us, 2),
                      "frac": round(job.info["algorithmic_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-        del srcs, raw, canvas, job
+        del srcs, canvas, job
         torch.cuda.empty_cache()
     return out
 
