@@ -79,7 +79,7 @@ def _expected(w, h, ops, srcs2d, clip_rows):
 def test_replaying_the_flat_form_makes_the_op_lists_bytes(seed):
     rng = np.random.default_rng(4000 + seed)
     w = int(rng.integers(300, 2600))
-    if (w * 4) % 4096 == 0:
+    if (w * 4) % 16384 == 0:
         w += 1
     n_images = int(rng.integers(1, 5))
     heights = [int(rng.integers(1, 900)) for _ in range(n_images)]
@@ -141,8 +141,10 @@ def test_jobs_without_a_flat_form():
     assert not _flat_form(w, 2 * hh, base[:2] + [turned], descs, 2)[2]
     assert not _flat_form(w, 2 * hh, base, descs, 2, clip=(5, 0, w - 5, 2 * hh))[2]    # a clip that does not take whole rows
     wide = (L.ImageDesc * 1)()
-    wide[0].width, wide[0].height, wide[0].opaque = 1024, 900, 1
-    assert not _flat_form(1024, 900, [_op(1, 0, 1024, 0, 900)], wide, 1)[2]           # rows of 4 KiB need no other walk
+    wide[0].width, wide[0].height, wide[0].opaque = 4096, 900, 1
+    assert not _flat_form(4096, 900, [_op(1, 0, 4096, 0, 900)], wide, 1)[2]           # rows of 16 KiB need no other walk
+    wide[0].width = 1024
+    assert _flat_form(1024, 900, [_op(1, 0, 1024, 0, 900)], wide, 1)[2]               # rows of 4 KiB do (stores 4 KiB apart: 0.76, 32 KiB apart: 0.87)
     small = [_op(0, -1, w, 0, 100, rgba=(1, 2, 3, 255)), _op(1, 0, w, 0, 100)]
     assert not _flat_form(w, 100, small, descs, 2)[2]                                  # too small for the pitch to matter
 

@@ -110,8 +110,10 @@ def test_jobs_it_does_not_apply_to_keep_the_row_form():
     thin = [torch.empty((100, 2000, 4), dtype=torch.uint8, device=DEV).random_(0, 256) for _ in range(100)]
     out2 = torch.empty((p2.canvas_h, p2.canvas_w, 4), dtype=torch.uint8, device=DEV)
     assert _launch(job2, thin, out2) == 0 and torch.equal(out2, torch.cat(thin, 0))
-    aligned = [U.rand_image(130 + i, 300, 1024) for i in range(3)]
-    assert run(aligned, "vertical", {"filter": "nearest"}) == 0                       # 4 KiB rows already
+    aligned = [U.rand_image(130 + i, 100, 4096) for i in range(3)]
+    assert run(aligned, "vertical", {"filter": "nearest"}) == 0                       # 16 KiB rows already
+    kib4 = [U.rand_image(133 + i, 300, 1024) for i in range(3)]
+    assert run(kib4, "vertical", {"filter": "nearest"}) == 1                          # 4 KiB rows are not in the stores' best class
 
 
 def test_raw_op_lists_source_crops_holes_and_a_draw_over_a_draw():

@@ -7,7 +7,7 @@ import imagestitching_amd as ist
 from imagestitching_amd import _lib as L
 dev = torch.device("cuda", 0)
 st = ist.Stitcher(0)
-for (n, w, h) in ((128, 4032, 100), (100, 4032, 250), (50, 4032, 500), (25, 4032, 1000), (12, 4032, 2000), (128, 8000, 100), (64, 8000, 400), (120, 2000, 400), (60, 2000, 1600)):
+for (n, w, h) in ((9, 5120, 3000), (12, 3072, 3000), (20, 2048, 3000), (9, 4096, 3000), (128, 4032, 100), (100, 4032, 250), (50, 4032, 500), (25, 4032, 1000), (12, 4032, 2000), (128, 8000, 100), (64, 8000, 400), (120, 2000, 400), (60, 2000, 1600)):
     imgs = [{"width": w, "height": h, "opaque": True}] * n
     p, job = st.compile(imgs, "vertical", {"filter": "bilinear"})
     srcs = [torch.empty((h, w, 4), dtype=torch.uint8, device=dev).random_(0, 256) for _ in range(n)]
