@@ -473,7 +473,7 @@ def single_gpu_regions(st, ist, dev, torch, head, reps=8):
             "from_pinned_host": {"ms_per_step": round(t_host * 1e3, 3), "MPs": round(mp / t_host, 1), "h2d_bytes": int(sum(w * h * 4 for w, h in UNIFORM)),
                                  "what": "9 x 48.8 MB from pinned host memory over this GPU's PCIe link, then the launch"},
             "host_in_host_out": {"ms_per_step": round(t_sink * 1e3, 3), "MPs": round(mp / t_sink, 1),
-                                 "what": "pinned host in -> H2D, launch, D2H of the canvas into pinned host memory (the N = 1 point of host_in_host_out/*)"},
+                                 "what": "pinned host in -> H2D, launch, D2H of the canvas into pinned host memory, all on ONE stream: the two directions do not overlap (the N = 1 point of host_in_host_out/*, whose ranks do the same; the library's own host entry point overlaps them band by band: extra.end_to_end_host_path)"},
             "from_jpeg": {"ms_per_step": round(t_jpeg * 1e3, 3), "MPs": round(mp / t_jpeg, 1), "jpeg_bytes": int(sum(len(b) for b in blobs)),
                           "what": "nine 12 MP photo-like JPEGs (q90, 4:2:0) decoded on the GPU (Huffman + IDCT + colour), then the launch"}}
 
@@ -492,7 +492,7 @@ def host_path_leg(ist, np, reps=4):
         del r
     t = sorted(ts)[len(ts) // 2]
     return {"ms_per_stitch": round(t * 1e3, 2), "MPs": round(109.734912 / t, 1), "pcie_payload_GBs": round(2 * 438.939648e6 / t / 1e9, 2),
-            "what": "PCIe-inclusive: pageable numpy in -> plan -> H2D through the pinned ring -> launch -> one D2H into a pooled pinned block (never `value`)"}
+            "what": "PCIe-inclusive: pageable numpy in -> plan -> per image: packed into 32 MiB pinned pieces, H2D, its band launched, the band's rows D2H into a pooled pinned block while the next image goes up (never `value`)"}
 
 
 def file_pipeline_leg(ist, reps=5):

@@ -86,6 +86,7 @@ SYMBOLS = [
     ("ist_debug_direct_images", C.c_int64, []),
     ("ist_debug_host_sink_stitches", C.c_int64, []),
     ("ist_debug_flat_launches", C.c_int64, []),
+    ("ist_debug_duplex_stitches", C.c_int64, []),
     ("ist_limits_default", None, [C.c_int, C.POINTER(Limits)]),
     ("ist_limits_unlimited", None, [C.POINTER(Limits)]),
     ("ist_plan_compute", C.c_int, [C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Limits), C.POINTER(Plan)]),

@@ -131,6 +131,10 @@ Stager::~Stager() {
   int prev = -1;
   (void)hipGetDevice(&prev);
   if (hipSetDevice(device_) != hipSuccess) return;
+  if (big_.stream) (void)hipStreamSynchronize(big_.stream);
+  for (int s = 0; s < 2; ++s) { if (big_.done[s]) (void)hipEventDestroy(big_.done[s]); if (big_.piece[s]) (void)hipHostFree(big_.piece[s]); }
+  if (big_.tail) (void)hipEventDestroy(big_.tail);
+  if (big_.stream) (void)hipStreamDestroy(big_.stream);
   for (Lane& l : lanes_) release_lane(l);
   if (gate_) (void)hipEventDestroy(gate_);
   if (prev >= 0) (void)hipSetDevice(prev);
@@ -160,8 +164,64 @@ int Stager::ensure() {
   return IST_OK;
 }
 
+namespace { constexpr size_t kBigPiece = 32u << 20; constexpr int kBigPackers = 4; }
+
+int Stager::ensure_big() {
+  if (big_.stream) return IST_OK;
+  Big b;
+  bool ok = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&b.tail, hipEventDisableTiming) == hipSuccess;
+  for (int s = 0; s < 2 && ok; ++s)
+    ok = hipHostMalloc(&b.piece[s], kBigPiece, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&b.done[s], hipEventDisableTiming) == hipSuccess &&
+         hipEventRecord(b.done[s], b.stream) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    for (int s = 0; s < 2; ++s) { if (b.done[s]) (void)hipEventDestroy(b.done[s]); if (b.piece[s]) (void)hipHostFree(b.piece[s]); }
+    if (b.tail) (void)hipEventDestroy(b.tail);
+    if (b.stream) (void)hipStreamDestroy(b.stream);
+    return fail(IST_E_HIP, "allocating the large staging pieces failed");
+  }
+  big_ = b;
+  return IST_OK;
+}
+
+int Stager::upload_big(const std::vector<RowsCopy>& items, hipStream_t after, WorkerPool* pool) {
+  if (!pool) return upload(items, after);
+  std::vector<RowsCopy> small;                       // rows that do not fit a piece: the chunked path
+  bool any = false;
+  for (const RowsCopy& it : items) { if (it.row == 0 || it.rows == 0) continue; if (it.row > kBigPiece) small.push_back(it); else any = true; }
+  if (!small.empty()) { const int rc = upload(small, after); if (rc) return rc; }
+  if (!any) return IST_OK;
+  int rc = ensure_big();
+  if (rc) return rc;
+  for (const RowsCopy& it : items) {
+    if (it.row == 0 || it.rows == 0 || it.row > kBigPiece) continue;
+    const size_t per = std::max<size_t>(1, kBigPiece / it.row);
+    for (size_t r0 = 0; r0 < it.rows; r0 += per) {
+      const size_t nr = std::min(per, it.rows - r0);
+      const int s = static_cast<int>(big_.k++ & 1u);
+      if (hipEventSynchronize(big_.done[s]) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "host-to-device staging failed"); }   // the piece's previous copy has left
+      uint8_t* piece = static_cast<uint8_t*>(big_.piece[s]);
+      const int workers = static_cast<int>(std::min<size_t>(kBigPackers, std::max<size_t>(1, nr * it.row >> 20)));
+      const size_t share = (nr + static_cast<size_t>(workers) - 1) / static_cast<size_t>(workers);
+      auto part = [&](int w) {
+        const size_t a = static_cast<size_t>(w) * share, b = std::min(nr, a + share);
+        if (a >= b) return;
+        const uint8_t* src = static_cast<const uint8_t*>(it.host_src) + (r0 + a) * it.host_pitch;
+        if (it.host_pitch == it.row) std::memcpy(piece + a * it.row, src, (b - a) * it.row);
+        else for (size_t r = a; r < b; ++r) std::memcpy(piece + r * it.row, src + (r - a) * it.host_pitch, it.row);
+      };
+      if (workers > 1) { pool->run(workers, part); pool->wait(); } else part(0);
+      if (hipMemcpyAsync(static_cast<uint8_t*>(it.dev) + r0 * it.row, piece, nr * it.row, hipMemcpyHostToDevice, big_.stream) != hipSuccess ||
+          hipEventRecord(big_.done[s], big_.stream) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "host-to-device staging failed"); }
+    }
+  }
+  if (hipEventRecord(big_.tail, big_.stream) != hipSuccess || hipStreamWaitEvent(after, big_.tail, 0) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "ordering the uploads before the launch failed"); }
+  return IST_OK;
+}
+
 int Stager::sync() {
   bool ok = true;
+  if (big_.stream) ok = hipStreamSynchronize(big_.stream) == hipSuccess;
   for (Lane& l : lanes_) if (l.stream) ok = (hipStreamSynchronize(l.stream) == hipSuccess) && ok;
   return ok ? IST_OK : fail(IST_E_HIP, "hipStreamSynchronize failed");
 }

@@ -52,6 +52,11 @@ class Stager {
   // caller's buffers are complete.
   int download(const std::vector<RowsCopy>& items, hipStream_t before);
   int sync();                             // waits for every lane's stream
+  // The same as upload(), for an upload that shares PCIe with downloads in flight: ONE stream and two pinned pieces of 32 MiB, each
+  // packed by up to four of `pool`'s parked threads and sent as ONE copy.  (Measured, tools/exp/duplex.cpp + duplex2.cpp: 4 MiB copies on
+  // four streams against concurrent 48 MB downloads fall to 12.7 GB/s each way; pieces of >= 16 MiB on one stream hold 48 GB/s each
+  // way.)  `pool` must be idle; rows longer than a piece go through upload().
+  int upload_big(const std::vector<RowsCopy>& items, hipStream_t after, class WorkerPool* pool);
 
  private:
   struct Lane { hipStream_t stream = nullptr; void* chunk[2] = {nullptr, nullptr}; hipEvent_t done[2] = {nullptr, nullptr}; hipEvent_t tail = nullptr; };
@@ -61,6 +66,8 @@ class Stager {
   int device_;
   std::vector<Lane> lanes_;
   hipEvent_t gate_ = nullptr;
+  struct Big { hipStream_t stream = nullptr; void* piece[2] = {nullptr, nullptr}; hipEvent_t done[2] = {nullptr, nullptr}; hipEvent_t tail = nullptr; unsigned k = 0; } big_;
+  int ensure_big();
 };
 
 

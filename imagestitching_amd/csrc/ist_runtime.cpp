@@ -202,6 +202,7 @@ void ist_ctx_destroy(ist_ctx* ctx) {
 }
 
 static std::atomic<int64_t> g_flat_launches{0};
+static std::atomic<int64_t> g_duplex_stitches{0};
 
 int64_t ist_debug_flat_launches(void) { return g_flat_launches.load(); }
 
@@ -1308,6 +1309,103 @@ int ist_png_encode_rgba8(ist_ctx* ctx, const uint8_t* pixels, size_t pitch, int6
   return png_to_host(ctx, ctx->scratch_dst, row, w, h, nullptr, out_png, out_len);
 }
 
+// The host path with both directions of PCIe busy (round 4).  A strip whose draws are disjoint row bands in canvas order - a vertical
+// strip, index.js:1522-1538 - is rendered band by band: image k goes up in 32 MiB pieces on the staging stream (Stager::upload_big), band k is
+// launched behind it, and its rows - with any background rows above them - go down into the pinned result on the aux stream while image
+// k + 1 goes up.  Upload-all, launch, download-all costs 8.1 + 7.5 ms for nine 12 MP images; overlapped the two directions hold 48 GB/s
+// each (tools/exp/duplex2.cpp).  An earlier banded attempt (round 2) sent the uploads as 4 MiB chunks on four streams, which collapses
+// to 12.7 GB/s each way as soon as downloads are in flight (tools/exp/duplex.cpp) - the piece size was the problem, not the idea.
+// *done = false: not applicable (small stitch, overlapping or side-by-side draws), nothing was queued and the caller takes the one-shot path.
+static int stitch_banded_duplex(ist_ctx* ctx, const ist_plan* plan, const ist_op* ops, int n_ops, const ist_image_desc* images,
+                                const uint8_t* const* src, const size_t* src_pitch, int n_images, int filter, uint8_t** out_pixels, bool* done) {
+  *done = false;
+  static const bool off = tuning_mode() && std::getenv("IST_HOST_DUPLEX") && std::atoi(std::getenv("IST_HOST_DUPLEX")) == 0;
+  const int64_t cw = plan->canvas_w, ch = plan->canvas_h;
+  const size_t row = static_cast<size_t>(cw) * 4, total = row * static_cast<size_t>(ch);
+  if (off || total < (32u << 20) || n_images < 2) return IST_OK;
+  static const uint8_t transparent[4] = {0, 0, 0, 0};
+  static const bool print = std::getenv("IST_TIMING") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) { if (print) std::fprintf(stderr, "[ist timing] host stitch: %-34s at %7.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count()); };
+  BandedJobs bj;
+  int rc = compile_banded(ctx, cw, ch, transparent, ops, n_ops, images, n_images, filter, &bj);
+  if (rc) return rc;
+  if (!bj.ok) return IST_OK;
+  lap("band jobs compiled");
+  const size_t nb = bj.parts.size();
+  for (size_t k = 0; k + 1 < nb; ++k) if (bj.parts[k].Y1 > bj.parts[k + 1].Y0) return IST_OK;      // (side by side, or interleaved: one shot)
+  // device scratch: the images the bands draw, and the canvas
+  auto bw = [&](int i) { return static_cast<size_t>(images[i].bmp_width > 0 ? images[i].bmp_width : images[i].width); };
+  auto bh = [&](int i) { return static_cast<size_t>(images[i].bmp_height > 0 ? images[i].bmp_height : images[i].height); };
+  std::vector<size_t> at(static_cast<size_t>(n_images), 0);
+  std::vector<char> used(static_cast<size_t>(n_images), 0), up(static_cast<size_t>(n_images), 0);
+  for (const ist_part& p : bj.parts) used[static_cast<size_t>(p.image)] = 1;
+  size_t src_bytes = 0;
+  for (int i = 0; i < n_images; ++i) {
+    if (!used[static_cast<size_t>(i)]) continue;
+    if (!src || !src[i]) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常");
+    if (src_pitch && src_pitch[i] < bw(i) * 4) return fail(IST_E_INVALID, "src_pitch too small");
+    at[static_cast<size_t>(i)] = src_bytes;
+    src_bytes += (bw(i) * 4 * bh(i) + 255) & ~static_cast<size_t>(255);
+  }
+  rc = grow_device(&ctx->scratch_src, &ctx->scratch_src_bytes, src_bytes ? src_bytes : 256);
+  if (rc) return rc;
+  rc = grow_device(&ctx->scratch_dst, &ctx->scratch_dst_bytes, total);
+  if (rc) return rc;
+  rc = ensure_aux(ctx);
+  if (rc) return rc;
+  if (!ctx->workers) ctx->workers.reset(new WorkerPool());
+  std::vector<const void*> dsrc(static_cast<size_t>(n_images), nullptr);
+  std::vector<size_t> dpitch(static_cast<size_t>(n_images), 0);
+  for (int i = 0; i < n_images; ++i)
+    if (used[static_cast<size_t>(i)]) { dsrc[static_cast<size_t>(i)] = static_cast<uint8_t*>(ctx->scratch_src) + at[static_cast<size_t>(i)]; dpitch[static_cast<size_t>(i)] = bw(i) * 4; }
+  uint8_t* canvas = static_cast<uint8_t*>(ctx->scratch_dst);
+  uint8_t* host = static_cast<uint8_t*>(pool_take(total));
+  if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
+  std::vector<hipEvent_t> ev(nb, nullptr);
+  hipStream_t R = ctx->stream, D = ctx->aux;
+  // (whatever happens below, the streams are idle before the pinned block or the jobs' tables are given back)
+  auto finish = [&](int code) {
+    (void)hipStreamSynchronize(R); (void)hipStreamSynchronize(D); (void)stager_of(ctx).sync();
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    if (code != IST_OK) pool_give(host);
+    return code;
+  };
+  lap("scratch, pinned result");
+  rc = ist_job_launch(bj.bg, dsrc.data(), dpitch.data(), n_images, canvas, row, R);
+  if (rc) return finish(rc);
+  int64_t prev_end = 0;
+  for (size_t k = 0; k < nb; ++k) {
+    const ist_part& p = bj.parts[k];
+    const int i = p.image;
+    if (!up[static_cast<size_t>(i)]) {
+      const std::vector<RowsCopy> one{RowsCopy{const_cast<void*>(dsrc[static_cast<size_t>(i)]), src[i], nullptr, src_pitch ? src_pitch[i] : bw(i) * 4, bw(i) * 4, bh(i)}};
+      rc = stager_of(ctx).upload_big(one, R, ctx->workers.get());
+      if (rc) return finish(rc);
+      up[static_cast<size_t>(i)] = 1;
+    }
+    rc = ist_job_launch(bj.band[k], dsrc.data(), dpitch.data(), n_images, canvas, row, R);
+    if (rc) return finish(rc);
+    const int64_t y_end = k + 1 < nb ? p.Y1 : ch;        // rows above band k that no band owns were painted by the background launch, earlier on R
+    if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[k], R) != hipSuccess || hipStreamWaitEvent(D, ev[k], 0) != hipSuccess ||
+        hipMemcpyAsync(host + static_cast<size_t>(prev_end) * row, canvas + static_cast<size_t>(prev_end) * row, static_cast<size_t>(y_end - prev_end) * row, hipMemcpyDeviceToHost, D) != hipSuccess) {
+      (void)hipGetLastError();
+      return finish(fail(IST_E_HIP, "queueing a band's readback failed"));
+    }
+    prev_end = y_end;
+    if (k == 0) lap("first band queued");
+  }
+  lap("last band queued");
+  if (hipStreamSynchronize(D) != hipSuccess || hipStreamSynchronize(R) != hipSuccess) { (void)hipGetLastError(); return finish(fail(IST_E_HIP, "result readback failed")); }
+  lap("last band in host memory");
+  g_duplex_stitches.fetch_add(1, std::memory_order_relaxed);
+  *out_pixels = host;
+  *done = true;
+  return finish(IST_OK);
+}
+
+int64_t ist_debug_duplex_stitches(void) { return g_duplex_stitches.load(); }
+
 int ist_stitch_rgba8(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch,
                      int n_images, int direction, int mode, double gap, const ist_limits* limits, int filter,
                      ist_plan* out_plan, uint8_t** out_pixels) {
@@ -1326,14 +1424,15 @@ int ist_stitch_rgba8(ist_ctx* ctx, const ist_image_desc* images, const uint8_t* 
   {
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard g(ctx->device);
-    rc = render_to_scratch(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, images, src, src_pitch,
-                           n_images, filter, nullptr, nullptr, nullptr);
-    // the export (index.js:1577-1579): the whole canvas in one DMA into a pinned block of the pool.
-    // (Tried and dropped: rendering a vertical strip band by band so that band k's rows go down on a second stream while band
-    // k+1's sources go up.  With both directions busy the copy engines did not sustain full duplex: either the uploads or the
-    // downloads fell to ~16 GB/s, 13-48 ms per stitch against a steady 16.5 ms for upload-all, launch, download-all.)
-    if (rc == IST_OK)
-      rc = read_back_pooled(ctx->scratch_dst, static_cast<size_t>(out_plan->canvas_w) * 4 * static_cast<size_t>(out_plan->canvas_h), ctx->stream, out_pixels);
+    bool done = false;
+    rc = stitch_banded_duplex(ctx, out_plan, ops.data(), n_ops, images, src, src_pitch, n_images, filter, out_pixels, &done);
+    if (rc == IST_OK && !done) {
+      rc = render_to_scratch(ctx, out_plan->canvas_w, out_plan->canvas_h, transparent, ops.data(), n_ops, images, src, src_pitch,
+                             n_images, filter, nullptr, nullptr, nullptr);
+      // the export (index.js:1577-1579): the whole canvas in one DMA into a pinned block of the pool
+      if (rc == IST_OK)
+        rc = read_back_pooled(ctx->scratch_dst, static_cast<size_t>(out_plan->canvas_w) * 4 * static_cast<size_t>(out_plan->canvas_h), ctx->stream, out_pixels);
+    }
   }
   if (rc != IST_OK) { ist_plan_free(out_plan); return rc; }
   return IST_OK;

@@ -143,6 +143,9 @@ IST_API int64_t ist_debug_host_sink_stitches(void);
 /* launches (ist_job_launch, any caller) that took a job's flat form: every op covers whole canvas rows at unit scale and the caller's
  * rows were dense on both sides, so the same bytes were moved as rows of 32 KiB */
 IST_API int64_t ist_debug_flat_launches(void);
+/* ist_stitch_rgba8 calls delivered band by band with uploads and downloads overlapped (a strip of disjoint row bands >= 32 MB; DESIGN.md
+ * section 4 "Host <-> device"); the others took upload-all, launch, download-all */
+IST_API int64_t ist_debug_duplex_stitches(void);
 
 /* ---- planner: pure CPU, bit-exact to index.js:1211-1216, 1251-1386, 1432-1433, 1522-1554 -------------------- */
 IST_API void ist_limits_default(int platform, ist_limits* out);        /* index.js:126-156 fallback branch */

@@ -144,3 +144,30 @@ def test_two_threads_on_two_contexts():
         ref, _, _ = U.oracle_stitch(px, direction, opts)
         tol = 0 if opts["filter"] == "nearest" else 1
         assert got.shape == ref.shape and U.max_abs_diff(got, ref) <= tol, (tid, it)
+
+
+def test_a_vertical_strip_goes_up_and_comes_down_at_the_same_time():
+    """ist_stitch_rgba8, round 4: a strip of disjoint row bands (>= 32 MB) is rendered band by band, image k + 1 going up in 32 MiB pieces
+    while band k comes down (ist_debug_duplex_stitches counts them); side-by-side bands and small stitches take the one-shot path.  Same
+    pixels either way: gaps, mixed widths (resampled bands), a pitched source, translucent pixels over the white fill."""
+    from imagestitching_amd import _lib as L
+    sizes = [(2000, 1500), (1800, 1400), (2000, 1600), (1500, 1100)]
+    px = [U.rand_image(300 + i, h, w, opaque=(i != 2)) for i, (w, h) in enumerate(sizes)]
+    for opts in ({"filter": "nearest", "gap": 9, "mode": "max"}, {"filter": "bilinear", "gap": 0, "mode": "min"}, {"filter": "nearest", "gap": 3, "mode": "original"}):
+        ref, pd, _ = U.oracle_stitch(px, "vertical", opts)
+        before = L.lib.ist_debug_duplex_stitches()
+        got = ist.stitch(U.hip_images(px), "vertical", opts)
+        assert L.lib.ist_debug_duplex_stitches() - before == (1 if ref.size >= (32 << 20) else 0), opts
+        assert got["data"].shape == ref.shape and U.max_abs_diff(got["data"], ref) <= (0 if opts["filter"] == "nearest" else 1), opts
+    ref, _, _ = U.oracle_stitch(px, "horizontal", {"filter": "nearest", "mode": "max"})
+    before = L.lib.ist_debug_duplex_stitches()
+    got = ist.stitch(U.hip_images(px), "horizontal", {"filter": "nearest", "mode": "max"})
+    assert L.lib.ist_debug_duplex_stitches() == before and np.array_equal(got["data"], ref)          # bands side by side: one shot
+    # a pitched source (a view into a wider buffer) through the big pieces
+    wide = np.zeros((1500, 2100, 4), np.uint8)
+    wide[:, :2000] = px[0]
+    imgs = U.hip_images(px)
+    imgs[0]["data"] = wide[:, :2000]
+    ref, _, _ = U.oracle_stitch(px, "vertical", {"filter": "nearest", "mode": "max"})
+    got = ist.stitch(imgs, "vertical", {"filter": "nearest", "mode": "max"})
+    assert np.array_equal(got["data"], ref)
