@@ -1309,46 +1309,66 @@ int ist_png_encode_rgba8(ist_ctx* ctx, const uint8_t* pixels, size_t pitch, int6
   return png_to_host(ctx, ctx->scratch_dst, row, w, h, nullptr, out_png, out_len);
 }
 
-// The host path with both directions of PCIe busy (round 4).  A strip whose draws are disjoint row bands in canvas order - a vertical
-// strip, index.js:1522-1538 - is rendered band by band: image k goes up in 32 MiB pieces on the staging stream (Stager::upload_big), band k is
-// launched behind it, and its rows - with any background rows above them - go down into the pinned result on the aux stream while image
-// k + 1 goes up.  Upload-all, launch, download-all costs 8.1 + 7.5 ms for nine 12 MP images; overlapped the two directions hold 48 GB/s
-// each (tools/exp/duplex2.cpp).  An earlier banded attempt (round 2) sent the uploads as 4 MiB chunks on four streams, which collapses
-// to 12.7 GB/s each way as soon as downloads are in flight (tools/exp/duplex.cpp) - the piece size was the problem, not the idea.
-// *done = false: not applicable (small stitch, overlapping or side-by-side draws), nothing was queued and the caller takes the one-shot path.
+// The host path with both directions of PCIe busy (round 4).  The canvas is cut into row bands (ist_shard_row_cuts: ~40 MB each, cuts on
+// multiples of 8 rows); band b is the whole op list clipped to its rows, and ist_shard_parts (IST_SPLIT_ROWS) names the source rows it
+// samples.  Band by band: the rows not yet on the device go up in 32 MiB pieces on the staging stream (Stager::upload_big), the band is
+// launched behind them, and its rows go down into the pinned result on the aux stream while the next band's sources go up.  Any layout
+// shards this way - a vertical strip (index.js:1522-1538) sends image after image, a horizontal one (1540-1553) a slice of every image
+// per band.  Upload-all, launch, download-all costs 8.1 + 7.5 ms for nine 12 MP images; overlapped the two directions hold 48 GB/s each
+// (tools/exp/duplex2.cpp).  An earlier banded attempt (round 2) sent the uploads as 4 MiB chunks on four streams, which collapses to
+// 12.7 GB/s each way as soon as downloads are in flight (tools/exp/duplex.cpp) - the piece size was the problem, not the idea.
+// *done = false: not applicable (a small stitch, an op list the row cut refuses), nothing was queued and the caller takes the one-shot path.
 static int stitch_banded_duplex(ist_ctx* ctx, const ist_plan* plan, const ist_op* ops, int n_ops, const ist_image_desc* images,
                                 const uint8_t* const* src, const size_t* src_pitch, int n_images, int filter, uint8_t** out_pixels, bool* done) {
   *done = false;
   static const bool off = tuning_mode() && std::getenv("IST_HOST_DUPLEX") && std::atoi(std::getenv("IST_HOST_DUPLEX")) == 0;
   const int64_t cw = plan->canvas_w, ch = plan->canvas_h;
   const size_t row = static_cast<size_t>(cw) * 4, total = row * static_cast<size_t>(ch);
-  if (off || total < (32u << 20) || n_images < 2) return IST_OK;
+  if (off || total < (32u << 20) || n_images < 1) return IST_OK;
   static const uint8_t transparent[4] = {0, 0, 0, 0};
   static const bool print = std::getenv("IST_TIMING") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) { if (print) std::fprintf(stderr, "[ist timing] host stitch: %-34s at %7.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count()); };
-  BandedJobs bj;
-  int rc = compile_banded(ctx, cw, ch, transparent, ops, n_ops, images, n_images, filter, &bj);
-  if (rc) return rc;
-  if (!bj.ok) return IST_OK;
+  const int nb = static_cast<int>(std::min<size_t>(16, std::max<size_t>(2, total / (40u << 20))));
+  std::vector<int32_t> cuts(static_cast<size_t>(nb) + 1, 0);
+  std::vector<ist_part> parts(static_cast<size_t>(std::max(1, n_ops)) * static_cast<size_t>(nb) + 8);
+  int n_parts = 0;
+  {
+    const std::string keep_msg = g_last_error;
+    const int keep_code = g_last_code;
+    if (ist_shard_row_cuts(ch, nb, cuts.data()) != IST_OK ||
+        ist_shard_parts(ops, n_ops, cw, ch, images, n_images, filter, nb, IST_SPLIT_ROWS, parts.data(), static_cast<int>(parts.size()), &n_parts) != IST_OK) {
+      g_last_error = keep_msg; g_last_code = keep_code;          // not an error of the call: the one-shot path takes it
+      return IST_OK;
+    }
+  }
+  parts.resize(static_cast<size_t>(n_parts));
+  struct Jobs { std::vector<ist_job*> j; ~Jobs() { for (ist_job* q : j) if (q) ist_job_destroy(q); } } band;
+  band.j.assign(static_cast<size_t>(nb), nullptr);
+  for (int b = 0; b < nb; ++b) {
+    if (cuts[static_cast<size_t>(b)] >= cuts[static_cast<size_t>(b) + 1]) continue;
+    const ist_region clip{0, cuts[static_cast<size_t>(b)], static_cast<int32_t>(cw), cuts[static_cast<size_t>(b) + 1] - cuts[static_cast<size_t>(b)]};
+    band.j[static_cast<size_t>(b)] = ist_job_create(ctx, cw, ch, transparent, ops, n_ops, images, n_images, filter, &clip);
+    if (!band.j[static_cast<size_t>(b)]) return g_last_code ? g_last_code : IST_E_INVALID;
+  }
   lap("band jobs compiled");
-  const size_t nb = bj.parts.size();
-  for (size_t k = 0; k + 1 < nb; ++k) if (bj.parts[k].Y1 > bj.parts[k + 1].Y0) return IST_OK;      // (side by side, or interleaved: one shot)
-  // device scratch: the images the bands draw, and the canvas
+  // device scratch: the images the bands draw (whole allocations, filled row range by row range), and the canvas
   auto bw = [&](int i) { return static_cast<size_t>(images[i].bmp_width > 0 ? images[i].bmp_width : images[i].width); };
-  auto bh = [&](int i) { return static_cast<size_t>(images[i].bmp_height > 0 ? images[i].bmp_height : images[i].height); };
+  auto bh = [&](int i) { return static_cast<int64_t>(images[i].bmp_height > 0 ? images[i].bmp_height : images[i].height); };
   std::vector<size_t> at(static_cast<size_t>(n_images), 0);
-  std::vector<char> used(static_cast<size_t>(n_images), 0), up(static_cast<size_t>(n_images), 0);
-  for (const ist_part& p : bj.parts) used[static_cast<size_t>(p.image)] = 1;
+  std::vector<char> used(static_cast<size_t>(n_images), 0);
+  std::vector<int64_t> lo(static_cast<size_t>(n_images), -1), hi(static_cast<size_t>(n_images), -1);      // rows of image i already sent: [lo, hi)
+  for (const ist_part& p : parts) if (p.image >= 0 && p.image < n_images) used[static_cast<size_t>(p.image)] = 1;
   size_t src_bytes = 0;
   for (int i = 0; i < n_images; ++i) {
     if (!used[static_cast<size_t>(i)]) continue;
     if (!src || !src[i]) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常");
+    if (bw(i) < 1 || bh(i) < 1) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常");
     if (src_pitch && src_pitch[i] < bw(i) * 4) return fail(IST_E_INVALID, "src_pitch too small");
     at[static_cast<size_t>(i)] = src_bytes;
-    src_bytes += (bw(i) * 4 * bh(i) + 255) & ~static_cast<size_t>(255);
+    src_bytes += (bw(i) * 4 * static_cast<size_t>(bh(i)) + 255 + 256) & ~static_cast<size_t>(255);       // (+ a vector load's reach past the last row sent)
   }
-  rc = grow_device(&ctx->scratch_src, &ctx->scratch_src_bytes, src_bytes ? src_bytes : 256);
+  int rc = grow_device(&ctx->scratch_src, &ctx->scratch_src_bytes, src_bytes ? src_bytes : 256);
   if (rc) return rc;
   rc = grow_device(&ctx->scratch_dst, &ctx->scratch_dst_bytes, total);
   if (rc) return rc;
@@ -1362,7 +1382,7 @@ static int stitch_banded_duplex(ist_ctx* ctx, const ist_plan* plan, const ist_op
   uint8_t* canvas = static_cast<uint8_t*>(ctx->scratch_dst);
   uint8_t* host = static_cast<uint8_t*>(pool_take(total));
   if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
-  std::vector<hipEvent_t> ev(nb, nullptr);
+  std::vector<hipEvent_t> ev(static_cast<size_t>(nb), nullptr);
   hipStream_t R = ctx->stream, D = ctx->aux;
   // (whatever happens below, the streams are idle before the pinned block or the jobs' tables are given back)
   auto finish = [&](int code) {
@@ -1372,28 +1392,39 @@ static int stitch_banded_duplex(ist_ctx* ctx, const ist_plan* plan, const ist_op
     return code;
   };
   lap("scratch, pinned result");
-  rc = ist_job_launch(bj.bg, dsrc.data(), dpitch.data(), n_images, canvas, row, R);
-  if (rc) return finish(rc);
-  int64_t prev_end = 0;
-  for (size_t k = 0; k < nb; ++k) {
-    const ist_part& p = bj.parts[k];
-    const int i = p.image;
-    if (!up[static_cast<size_t>(i)]) {
-      const std::vector<RowsCopy> one{RowsCopy{const_cast<void*>(dsrc[static_cast<size_t>(i)]), src[i], nullptr, src_pitch ? src_pitch[i] : bw(i) * 4, bw(i) * 4, bh(i)}};
-      rc = stager_of(ctx).upload_big(one, R, ctx->workers.get());
-      if (rc) return finish(rc);
-      up[static_cast<size_t>(i)] = 1;
+  std::vector<RowsCopy> items;
+  for (int b = 0; b < nb; ++b) {
+    const int64_t y0 = cuts[static_cast<size_t>(b)], y1 = cuts[static_cast<size_t>(b) + 1];
+    if (y0 >= y1) continue;
+    items.clear();
+    auto send = [&](int i, int64_t r0, int64_t r1) {            // rows [r0, r1) of image i
+      if (r1 <= r0) return;
+      const size_t hp = src_pitch ? src_pitch[i] : bw(i) * 4;
+      items.push_back(RowsCopy{static_cast<uint8_t*>(const_cast<void*>(dsrc[static_cast<size_t>(i)])) + static_cast<size_t>(r0) * bw(i) * 4,
+                               src[i] + static_cast<size_t>(r0) * hp, nullptr, hp, bw(i) * 4, static_cast<size_t>(r1 - r0)});
+    };
+    for (const ist_part& p : parts) {
+      if (p.slot != b || p.image < 0) continue;
+      const int i = p.image;
+      const int64_t a = std::max<int64_t>(0, p.sy0), e = std::min<int64_t>(bh(i), p.sy1);
+      if (e <= a) continue;
+      int64_t& L0 = lo[static_cast<size_t>(i)]; int64_t& H0 = hi[static_cast<size_t>(i)];
+      if (L0 < 0) { send(i, a, e); L0 = a; H0 = e; }
+      else {                                                     // keep ONE interval per image: a band further down extends it (rows between are sent too)
+        if (a < L0) { send(i, a, L0); L0 = a; }
+        if (e > H0) { send(i, H0, e); H0 = e; }
+      }
     }
-    rc = ist_job_launch(bj.band[k], dsrc.data(), dpitch.data(), n_images, canvas, row, R);
+    if (!items.empty()) { rc = stager_of(ctx).upload_big(items, R, ctx->workers.get()); if (rc) return finish(rc); }
+    rc = ist_job_launch(band.j[static_cast<size_t>(b)], dsrc.data(), dpitch.data(), n_images, canvas, row, R);
     if (rc) return finish(rc);
-    const int64_t y_end = k + 1 < nb ? p.Y1 : ch;        // rows above band k that no band owns were painted by the background launch, earlier on R
-    if (hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[k], R) != hipSuccess || hipStreamWaitEvent(D, ev[k], 0) != hipSuccess ||
-        hipMemcpyAsync(host + static_cast<size_t>(prev_end) * row, canvas + static_cast<size_t>(prev_end) * row, static_cast<size_t>(y_end - prev_end) * row, hipMemcpyDeviceToHost, D) != hipSuccess) {
+    hipEvent_t& e = ev[static_cast<size_t>(b)];
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, R) != hipSuccess || hipStreamWaitEvent(D, e, 0) != hipSuccess ||
+        hipMemcpyAsync(host + static_cast<size_t>(y0) * row, canvas + static_cast<size_t>(y0) * row, static_cast<size_t>(y1 - y0) * row, hipMemcpyDeviceToHost, D) != hipSuccess) {
       (void)hipGetLastError();
       return finish(fail(IST_E_HIP, "queueing a band's readback failed"));
     }
-    prev_end = y_end;
-    if (k == 0) lap("first band queued");
+    if (b == 0) lap("first band queued");
   }
   lap("last band queued");
   if (hipStreamSynchronize(D) != hipSuccess || hipStreamSynchronize(R) != hipSuccess) { (void)hipGetLastError(); return finish(fail(IST_E_HIP, "result readback failed")); }

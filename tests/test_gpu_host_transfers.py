@@ -146,23 +146,33 @@ def test_two_threads_on_two_contexts():
         assert got.shape == ref.shape and U.max_abs_diff(got, ref) <= tol, (tid, it)
 
 
-def test_a_vertical_strip_goes_up_and_comes_down_at_the_same_time():
-    """ist_stitch_rgba8, round 4: a strip of disjoint row bands (>= 32 MB) is rendered band by band, image k + 1 going up in 32 MiB pieces
-    while band k comes down (ist_debug_duplex_stitches counts them); side-by-side bands and small stitches take the one-shot path.  Same
-    pixels either way: gaps, mixed widths (resampled bands), a pitched source, translucent pixels over the white fill."""
+def test_a_large_stitch_goes_up_and_comes_down_at_the_same_time():
+    """ist_stitch_rgba8, round 4: a stitch of 32 MB or more is cut into row bands; the source rows band b + 1 samples go up in 32 MiB pieces while
+    band b comes down (ist_debug_duplex_stitches counts such calls); small stitches take the one-shot path.  Same pixels either way: vertical
+    and horizontal strips, gaps, mixed sizes (resampled bands with tap rows across band cuts), a pitched source, translucent pixels over the
+    white fill, quarter-turned and mirrored images (whose bands need other rows than their own)."""
     from imagestitching_amd import _lib as L
     sizes = [(2000, 1500), (1800, 1400), (2000, 1600), (1500, 1100)]
     px = [U.rand_image(300 + i, h, w, opaque=(i != 2)) for i, (w, h) in enumerate(sizes)]
-    for opts in ({"filter": "nearest", "gap": 9, "mode": "max"}, {"filter": "bilinear", "gap": 0, "mode": "min"}, {"filter": "nearest", "gap": 3, "mode": "original"}):
-        ref, pd, _ = U.oracle_stitch(px, "vertical", opts)
+    for direction in ("vertical", "horizontal"):
+        for opts in ({"filter": "nearest", "gap": 9, "mode": "max"}, {"filter": "bilinear", "gap": 0, "mode": "min"}, {"filter": "nearest", "gap": 3, "mode": "original"}):
+            ref, pd, _ = U.oracle_stitch(px, direction, opts)
+            before = L.lib.ist_debug_duplex_stitches()
+            got = ist.stitch(U.hip_images(px), direction, opts)
+            assert L.lib.ist_debug_duplex_stitches() - before == (1 if ref.size >= (32 << 20) else 0), (direction, opts, ref.size)
+            assert got["data"].shape == ref.shape and U.max_abs_diff(got["data"], ref) <= (0 if opts["filter"] == "nearest" else 1), (direction, opts)
+    # orientations: the rows a band needs are not the band's own rows
+    ori = [6, 3, 2, 8]
+    for direction in ("vertical", "horizontal"):
+        ref, _, _ = U.oracle_stitch(px, direction, {"filter": "nearest", "mode": "max"}, orientations=ori)
         before = L.lib.ist_debug_duplex_stitches()
-        got = ist.stitch(U.hip_images(px), "vertical", opts)
-        assert L.lib.ist_debug_duplex_stitches() - before == (1 if ref.size >= (32 << 20) else 0), opts
-        assert got["data"].shape == ref.shape and U.max_abs_diff(got["data"], ref) <= (0 if opts["filter"] == "nearest" else 1), opts
-    ref, _, _ = U.oracle_stitch(px, "horizontal", {"filter": "nearest", "mode": "max"})
+        got = ist.stitch(U.hip_images(px, ori), direction, {"filter": "nearest", "mode": "max"})
+        assert L.lib.ist_debug_duplex_stitches() - before == (1 if ref.size >= (32 << 20) else 0)
+        assert np.array_equal(got["data"], ref), direction
+    small = [U.rand_image(320 + i, 300, 400) for i in range(3)]
     before = L.lib.ist_debug_duplex_stitches()
-    got = ist.stitch(U.hip_images(px), "horizontal", {"filter": "nearest", "mode": "max"})
-    assert L.lib.ist_debug_duplex_stitches() == before and np.array_equal(got["data"], ref)          # bands side by side: one shot
+    got = ist.stitch(U.hip_images(small), "vertical", {"filter": "nearest"})
+    assert L.lib.ist_debug_duplex_stitches() == before and np.array_equal(got["data"], U.oracle_stitch(small, "vertical", {"filter": "nearest"})[0])
     # a pitched source (a view into a wider buffer) through the big pieces
     wide = np.zeros((1500, 2100, 4), np.uint8)
     wide[:, :2000] = px[0]
