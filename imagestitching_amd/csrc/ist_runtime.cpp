@@ -449,6 +449,11 @@ int ist_render_rgba8(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uin
   return stager_of(ctx).download(down, ctx->stream);
 }
 
+// (below, behind RowBands) the same band by band: band b + 1's source rows go up while the encoder compresses band b and sends its slabs down
+static int render_png_banded(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,
+                             const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch, int n_images, int filter,
+                             uint8_t** out_png, int64_t* out_len);
+
 // PNG of a rendered op list: the canvas never leaves the device, only the PNG bytes cross PCIe
 int ist_render_png(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops,
                    int n_ops, const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch,
@@ -458,7 +463,9 @@ int ist_render_png(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8
   *out_png = nullptr; *out_len = 0;
   std::lock_guard<std::mutex> lock(ctx->mu);
   DeviceGuard g(ctx->device);
-  int rc = render_to_scratch(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, src, src_pitch, n_images, filter, nullptr, nullptr, nullptr);
+  int rc = render_png_banded(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, src, src_pitch, n_images, filter, out_png, out_len);
+  if (rc != 1) return rc;                      // (1: not applicable, nothing queued)
+  rc = render_to_scratch(ctx, canvas_w, canvas_h, clear_rgba, ops, n_ops, images, src, src_pitch, n_images, filter, nullptr, nullptr, nullptr);
   if (rc) return rc;
   return png_to_host(ctx, ctx->scratch_dst, static_cast<size_t>(canvas_w) * 4, canvas_w, canvas_h, nullptr, out_png, out_len);
 }
@@ -1309,93 +1316,96 @@ int ist_png_encode_rgba8(ist_ctx* ctx, const uint8_t* pixels, size_t pitch, int6
   return png_to_host(ctx, ctx->scratch_dst, row, w, h, nullptr, out_png, out_len);
 }
 
-// The host path with both directions of PCIe busy (round 4).  The canvas is cut into row bands (ist_shard_row_cuts: ~40 MB each, cuts on
+// The host paths with both directions of PCIe busy (round 4).  The canvas is cut into row bands (ist_shard_row_cuts: ~40 MB each, cuts on
 // multiples of 8 rows); band b is the whole op list clipped to its rows, and ist_shard_parts (IST_SPLIT_ROWS) names the source rows it
 // samples.  Band by band: the rows not yet on the device go up in 32 MiB pieces on the staging stream (Stager::upload_big), the band is
-// launched behind them, and its rows go down into the pinned result on the aux stream while the next band's sources go up.  Any layout
-// shards this way - a vertical strip (index.js:1522-1538) sends image after image, a horizontal one (1540-1553) a slice of every image
-// per band.  Upload-all, launch, download-all costs 8.1 + 7.5 ms for nine 12 MP images; overlapped the two directions hold 48 GB/s each
-// (tools/exp/duplex2.cpp).  An earlier banded attempt (round 2) sent the uploads as 4 MiB chunks on four streams, which collapses to
-// 12.7 GB/s each way as soon as downloads are in flight (tools/exp/duplex.cpp) - the piece size was the problem, not the idea.
-// *done = false: not applicable (a small stitch, an op list the row cut refuses), nothing was queued and the caller takes the one-shot path.
-static int stitch_banded_duplex(ist_ctx* ctx, const ist_plan* plan, const ist_op* ops, int n_ops, const ist_image_desc* images,
-                                const uint8_t* const* src, const size_t* src_pitch, int n_images, int filter, uint8_t** out_pixels, bool* done) {
-  *done = false;
-  static const bool off = tuning_mode() && std::getenv("IST_HOST_DUPLEX") && std::atoi(std::getenv("IST_HOST_DUPLEX")) == 0;
-  const int64_t cw = plan->canvas_w, ch = plan->canvas_h;
-  const size_t row = static_cast<size_t>(cw) * 4, total = row * static_cast<size_t>(ch);
-  if (off || total < (32u << 20) || n_images < 1) return IST_OK;
-  static const uint8_t transparent[4] = {0, 0, 0, 0};
-  static const bool print = std::getenv("IST_TIMING") != nullptr;
-  const auto t_start = std::chrono::steady_clock::now();
-  auto lap = [&](const char* what) { if (print) std::fprintf(stderr, "[ist timing] host stitch: %-34s at %7.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count()); };
-  const int nb = static_cast<int>(std::min<size_t>(16, std::max<size_t>(2, total / (40u << 20))));
-  std::vector<int32_t> cuts(static_cast<size_t>(nb) + 1, 0);
-  std::vector<ist_part> parts(static_cast<size_t>(std::max(1, n_ops)) * static_cast<size_t>(nb) + 8);
-  int n_parts = 0;
-  {
-    const std::string keep_msg = g_last_error;
-    const int keep_code = g_last_code;
-    if (ist_shard_row_cuts(ch, nb, cuts.data()) != IST_OK ||
-        ist_shard_parts(ops, n_ops, cw, ch, images, n_images, filter, nb, IST_SPLIT_ROWS, parts.data(), static_cast<int>(parts.size()), &n_parts) != IST_OK) {
-      g_last_error = keep_msg; g_last_code = keep_code;          // not an error of the call: the one-shot path takes it
-      return IST_OK;
-    }
-  }
-  parts.resize(static_cast<size_t>(n_parts));
-  struct Jobs { std::vector<ist_job*> j; ~Jobs() { for (ist_job* q : j) if (q) ist_job_destroy(q); } } band;
-  band.j.assign(static_cast<size_t>(nb), nullptr);
-  for (int b = 0; b < nb; ++b) {
-    if (cuts[static_cast<size_t>(b)] >= cuts[static_cast<size_t>(b) + 1]) continue;
-    const ist_region clip{0, cuts[static_cast<size_t>(b)], static_cast<int32_t>(cw), cuts[static_cast<size_t>(b) + 1] - cuts[static_cast<size_t>(b)]};
-    band.j[static_cast<size_t>(b)] = ist_job_create(ctx, cw, ch, transparent, ops, n_ops, images, n_images, filter, &clip);
-    if (!band.j[static_cast<size_t>(b)]) return g_last_code ? g_last_code : IST_E_INVALID;
-  }
-  lap("band jobs compiled");
-  // device scratch: the images the bands draw (whole allocations, filled row range by row range), and the canvas
-  auto bw = [&](int i) { return static_cast<size_t>(images[i].bmp_width > 0 ? images[i].bmp_width : images[i].width); };
-  auto bh = [&](int i) { return static_cast<int64_t>(images[i].bmp_height > 0 ? images[i].bmp_height : images[i].height); };
-  std::vector<size_t> at(static_cast<size_t>(n_images), 0);
-  std::vector<char> used(static_cast<size_t>(n_images), 0);
-  std::vector<int64_t> lo(static_cast<size_t>(n_images), -1), hi(static_cast<size_t>(n_images), -1);      // rows of image i already sent: [lo, hi)
-  for (const ist_part& p : parts) if (p.image >= 0 && p.image < n_images) used[static_cast<size_t>(p.image)] = 1;
-  size_t src_bytes = 0;
-  for (int i = 0; i < n_images; ++i) {
-    if (!used[static_cast<size_t>(i)]) continue;
-    if (!src || !src[i]) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常");
-    if (bw(i) < 1 || bh(i) < 1) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常");
-    if (src_pitch && src_pitch[i] < bw(i) * 4) return fail(IST_E_INVALID, "src_pitch too small");
-    at[static_cast<size_t>(i)] = src_bytes;
-    src_bytes += (bw(i) * 4 * static_cast<size_t>(bh(i)) + 255 + 256) & ~static_cast<size_t>(255);       // (+ a vector load's reach past the last row sent)
-  }
-  int rc = grow_device(&ctx->scratch_src, &ctx->scratch_src_bytes, src_bytes ? src_bytes : 256);
-  if (rc) return rc;
-  rc = grow_device(&ctx->scratch_dst, &ctx->scratch_dst_bytes, total);
-  if (rc) return rc;
-  rc = ensure_aux(ctx);
-  if (rc) return rc;
-  if (!ctx->workers) ctx->workers.reset(new WorkerPool());
-  std::vector<const void*> dsrc(static_cast<size_t>(n_images), nullptr);
-  std::vector<size_t> dpitch(static_cast<size_t>(n_images), 0);
-  for (int i = 0; i < n_images; ++i)
-    if (used[static_cast<size_t>(i)]) { dsrc[static_cast<size_t>(i)] = static_cast<uint8_t*>(ctx->scratch_src) + at[static_cast<size_t>(i)]; dpitch[static_cast<size_t>(i)] = bw(i) * 4; }
-  uint8_t* canvas = static_cast<uint8_t*>(ctx->scratch_dst);
-  uint8_t* host = static_cast<uint8_t*>(pool_take(total));
-  if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
-  std::vector<hipEvent_t> ev(static_cast<size_t>(nb), nullptr);
-  hipStream_t R = ctx->stream, D = ctx->aux;
-  // (whatever happens below, the streams are idle before the pinned block or the jobs' tables are given back)
-  auto finish = [&](int code) {
-    (void)hipStreamSynchronize(R); (void)hipStreamSynchronize(D); (void)stager_of(ctx).sync();
-    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-    if (code != IST_OK) pool_give(host);
-    return code;
-  };
-  lap("scratch, pinned result");
+// launched behind them, and - ist_stitch_rgba8 - its rows go down into the pinned result on the aux stream while the next band's sources go
+// up, or - ist_render_png / ist_stitch_png - the PNG encoder compresses it and sends its slabs down meanwhile.  Any layout shards this way: a
+// vertical strip (index.js:1522-1538) sends image after image, a horizontal one (1540-1553) a slice of every image per band.  Upload-all,
+// launch, download-all costs 8.1 + 7.5 ms for nine 12 MP images; overlapped the two directions hold 48 GB/s each (tools/exp/duplex2.cpp).
+// An earlier banded attempt (round 2) sent the uploads as 4 MiB chunks on four streams, which collapses to 12.7 GB/s each way as soon as
+// downloads are in flight (tools/exp/duplex.cpp) - the piece size was the problem, not the idea.
+extern "C++" {
+namespace {
+struct RowBands {
+  ist_ctx* ctx = nullptr;
+  bool ok = false;                        // false after prepare(): not applicable (a small canvas, an op list the row cut refuses); nothing was queued
+  int nb = 0, n_images = 0;
+  int64_t cw = 0, ch = 0;
+  size_t row = 0, total = 0;
+  const ist_image_desc* images = nullptr;
+  const uint8_t* const* src = nullptr;
+  const size_t* src_pitch = nullptr;
+  std::vector<int32_t> cuts;
+  std::vector<ist_part> parts;
+  std::vector<ist_job*> jobs;
+  std::vector<const void*> dsrc;
+  std::vector<size_t> dpitch;
+  std::vector<int64_t> lo, hi;            // rows of image i already sent: [lo, hi)
   std::vector<RowsCopy> items;
-  for (int b = 0; b < nb; ++b) {
-    const int64_t y0 = cuts[static_cast<size_t>(b)], y1 = cuts[static_cast<size_t>(b) + 1];
-    if (y0 >= y1) continue;
+  uint8_t* canvas = nullptr;
+  ~RowBands() { for (ist_job* q : jobs) if (q) ist_job_destroy(q); }
+  size_t bw(int i) const { return static_cast<size_t>(images[i].bmp_width > 0 ? images[i].bmp_width : images[i].width); }
+  int64_t bh(int i) const { return static_cast<int64_t>(images[i].bmp_height > 0 ? images[i].bmp_height : images[i].height); }
+  int64_t y0(int b) const { return cuts[static_cast<size_t>(b)]; }
+  int64_t y1(int b) const { return cuts[static_cast<size_t>(b) + 1]; }
+
+  int prepare(ist_ctx* c, int64_t canvas_w, int64_t canvas_h, const uint8_t clear[4], const ist_op* ops, int n_ops, const ist_image_desc* imgs,
+              const uint8_t* const* s, const size_t* sp, int n, int filter) {
+    static const bool off = tuning_mode() && std::getenv("IST_HOST_DUPLEX") && std::atoi(std::getenv("IST_HOST_DUPLEX")) == 0;
+    ctx = c; cw = canvas_w; ch = canvas_h; images = imgs; src = s; src_pitch = sp; n_images = n;
+    row = static_cast<size_t>(cw) * 4; total = row * static_cast<size_t>(ch);
+    if (off || total < (32u << 20) || n_images < 1) return IST_OK;
+    nb = static_cast<int>(std::min<size_t>(16, std::max<size_t>(2, total / (40u << 20))));
+    cuts.assign(static_cast<size_t>(nb) + 1, 0);
+    parts.resize(static_cast<size_t>(std::max(1, n_ops)) * static_cast<size_t>(nb) + 8);
+    int n_parts = 0;
+    {
+      const std::string keep_msg = g_last_error;
+      const int keep_code = g_last_code;
+      if (ist_shard_row_cuts(ch, nb, cuts.data()) != IST_OK ||
+          ist_shard_parts(ops, n_ops, cw, ch, images, n_images, filter, nb, IST_SPLIT_ROWS, parts.data(), static_cast<int>(parts.size()), &n_parts) != IST_OK) {
+        g_last_error = keep_msg; g_last_code = keep_code;          // not an error of the call: the one-shot path takes it
+        return IST_OK;
+      }
+    }
+    parts.resize(static_cast<size_t>(n_parts));
+    jobs.assign(static_cast<size_t>(nb), nullptr);
+    for (int b = 0; b < nb; ++b) {
+      if (y0(b) >= y1(b)) continue;
+      const ist_region clip{0, static_cast<int32_t>(y0(b)), static_cast<int32_t>(cw), static_cast<int32_t>(y1(b) - y0(b))};
+      jobs[static_cast<size_t>(b)] = ist_job_create(ctx, cw, ch, clear, ops, n_ops, images, n_images, filter, &clip);
+      if (!jobs[static_cast<size_t>(b)]) return g_last_code ? g_last_code : IST_E_INVALID;
+    }
+    // device scratch: the images the bands draw (whole allocations, filled row range by row range), and the canvas
+    std::vector<size_t> at(static_cast<size_t>(n_images), 0);
+    std::vector<char> used(static_cast<size_t>(n_images), 0);
+    lo.assign(static_cast<size_t>(n_images), -1); hi.assign(static_cast<size_t>(n_images), -1);
+    for (const ist_part& p : parts) if (p.image >= 0 && p.image < n_images) used[static_cast<size_t>(p.image)] = 1;
+    size_t src_bytes = 0;
+    for (int i = 0; i < n_images; ++i) {
+      if (!used[static_cast<size_t>(i)]) continue;
+      if (!src || !src[i] || bw(i) < 1 || bh(i) < 1) return fail(IST_E_DECODE, "图片" + std::to_string(i) + "解码异常");
+      if (src_pitch && src_pitch[i] < bw(i) * 4) return fail(IST_E_INVALID, "src_pitch too small");
+      at[static_cast<size_t>(i)] = src_bytes;
+      src_bytes += (bw(i) * 4 * static_cast<size_t>(bh(i)) + 255 + 256) & ~static_cast<size_t>(255);       // (+ a vector load's reach past the last row sent)
+    }
+    int rc = grow_device(&ctx->scratch_src, &ctx->scratch_src_bytes, src_bytes ? src_bytes : 256);
+    if (rc) return rc;
+    rc = grow_device(&ctx->scratch_dst, &ctx->scratch_dst_bytes, total);
+    if (rc) return rc;
+    if (!ctx->workers) ctx->workers.reset(new WorkerPool());
+    dsrc.assign(static_cast<size_t>(n_images), nullptr);
+    dpitch.assign(static_cast<size_t>(n_images), 0);
+    for (int i = 0; i < n_images; ++i)
+      if (used[static_cast<size_t>(i)]) { dsrc[static_cast<size_t>(i)] = static_cast<uint8_t*>(ctx->scratch_src) + at[static_cast<size_t>(i)]; dpitch[static_cast<size_t>(i)] = bw(i) * 4; }
+    canvas = static_cast<uint8_t*>(ctx->scratch_dst);
+    ok = true;
+    return IST_OK;
+  }
+
+  // sends what band b still needs and launches it, all ordered on R
+  int submit(int b, hipStream_t R) {
     items.clear();
     auto send = [&](int i, int64_t r0, int64_t r1) {            // rows [r0, r1) of image i
       if (r1 <= r0) return;
@@ -1415,16 +1425,52 @@ static int stitch_banded_duplex(ist_ctx* ctx, const ist_plan* plan, const ist_op
         if (e > H0) { send(i, H0, e); H0 = e; }
       }
     }
-    if (!items.empty()) { rc = stager_of(ctx).upload_big(items, R, ctx->workers.get()); if (rc) return finish(rc); }
-    rc = ist_job_launch(band.j[static_cast<size_t>(b)], dsrc.data(), dpitch.data(), n_images, canvas, row, R);
+    if (!items.empty()) { const int rc = stager_of(ctx).upload_big(items, R, ctx->workers.get()); if (rc) return rc; }
+    return ist_job_launch(jobs[static_cast<size_t>(b)], dsrc.data(), dpitch.data(), n_images, canvas, row, R);
+  }
+};
+}  // namespace
+}  // extern "C++"
+
+// *done = false: not applicable, nothing was queued and the caller takes the one-shot path.
+static int stitch_banded_duplex(ist_ctx* ctx, const ist_plan* plan, const ist_op* ops, int n_ops, const ist_image_desc* images,
+                                const uint8_t* const* src, const size_t* src_pitch, int n_images, int filter, uint8_t** out_pixels, bool* done) {
+  *done = false;
+  static const uint8_t transparent[4] = {0, 0, 0, 0};
+  static const bool print = std::getenv("IST_TIMING") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) { if (print) std::fprintf(stderr, "[ist timing] host stitch: %-34s at %7.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count()); };
+  RowBands rb;
+  int rc = rb.prepare(ctx, plan->canvas_w, plan->canvas_h, transparent, ops, n_ops, images, src, src_pitch, n_images, filter);
+  if (rc) return rc;
+  if (!rb.ok) return IST_OK;
+  rc = ensure_aux(ctx);
+  if (rc) return rc;
+  lap("band jobs compiled, scratch");
+  uint8_t* host = static_cast<uint8_t*>(pool_take(rb.total));
+  if (!host) return fail(IST_E_NOMEM, "out of pinned host memory for the result");
+  std::vector<hipEvent_t> ev(static_cast<size_t>(rb.nb), nullptr);
+  hipStream_t R = ctx->stream, D = ctx->aux;
+  // (whatever happens below, the streams are idle before the pinned block or the jobs' tables are given back)
+  auto finish = [&](int code) {
+    (void)hipStreamSynchronize(R); (void)hipStreamSynchronize(D); (void)stager_of(ctx).sync();
+    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    if (code != IST_OK) pool_give(host);
+    return code;
+  };
+  bool first = true;
+  for (int b = 0; b < rb.nb; ++b) {
+    const int64_t y0 = rb.y0(b), y1 = rb.y1(b);
+    if (y0 >= y1) continue;
+    rc = rb.submit(b, R);
     if (rc) return finish(rc);
     hipEvent_t& e = ev[static_cast<size_t>(b)];
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, R) != hipSuccess || hipStreamWaitEvent(D, e, 0) != hipSuccess ||
-        hipMemcpyAsync(host + static_cast<size_t>(y0) * row, canvas + static_cast<size_t>(y0) * row, static_cast<size_t>(y1 - y0) * row, hipMemcpyDeviceToHost, D) != hipSuccess) {
+        hipMemcpyAsync(host + static_cast<size_t>(y0) * rb.row, rb.canvas + static_cast<size_t>(y0) * rb.row, static_cast<size_t>(y1 - y0) * rb.row, hipMemcpyDeviceToHost, D) != hipSuccess) {
       (void)hipGetLastError();
       return finish(fail(IST_E_HIP, "queueing a band's readback failed"));
     }
-    if (b == 0) lap("first band queued");
+    if (first) { lap("first band queued"); first = false; }
   }
   lap("last band queued");
   if (hipStreamSynchronize(D) != hipSuccess || hipStreamSynchronize(R) != hipSuccess) { (void)hipGetLastError(); return finish(fail(IST_E_HIP, "result readback failed")); }
@@ -1433,6 +1479,52 @@ static int stitch_banded_duplex(ist_ctx* ctx, const ist_plan* plan, const ist_op
   *out_pixels = host;
   *done = true;
   return finish(IST_OK);
+}
+
+static int render_png_banded(ist_ctx* ctx, int64_t canvas_w, int64_t canvas_h, const uint8_t clear_rgba[4], const ist_op* ops, int n_ops,
+                             const ist_image_desc* images, const uint8_t* const* src, const size_t* src_pitch, int n_images, int filter,
+                             uint8_t** out_png, int64_t* out_len) {
+  static const uint8_t transparent[4] = {0, 0, 0, 0};
+  RowBands rb;
+  int rc = rb.prepare(ctx, canvas_w, canvas_h, clear_rgba ? clear_rgba : transparent, ops, n_ops, images, src, src_pitch, n_images, filter);
+  if (rc) return rc;
+  if (!rb.ok) return 1;
+  if (!ctx->render) {                                  // (high priority: its short kernels should not queue behind the encoder's thousands of workgroups)
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&ctx->render, hipStreamNonBlocking, hi) != hipSuccess) { (void)hipGetLastError(); ctx->render = nullptr; return fail(IST_E_HIP, "hipStreamCreate failed"); }
+  }
+  hipStream_t R = ctx->render;
+  std::vector<hipEvent_t> ev(static_cast<size_t>(rb.nb), nullptr);
+  int next = 0, failed = IST_OK;
+  // the encoder is about to read canvas rows [0, y_end) on `reader`: submit the bands they lie in, order the reader behind the last of them
+  auto need_rows = [&](int64_t y_end, void* reader_) -> int {
+    hipStream_t reader = static_cast<hipStream_t>(reader_);
+    int last = -1;
+    for (int b = 0; b < rb.nb; ++b) {
+      if (rb.y0(b) >= rb.y1(b)) continue;
+      if (rb.y0(b) >= y_end) break;
+      if (b >= next) {
+        const int rc2 = rb.submit(b, R);
+        if (rc2) { failed = rc2; return rc2; }
+        if (hipEventCreateWithFlags(&ev[static_cast<size_t>(b)], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[static_cast<size_t>(b)], R) != hipSuccess) {
+          (void)hipGetLastError(); failed = IST_E_HIP; return fail(IST_E_HIP, "hipEventRecord failed");
+        }
+        next = b + 1;
+      }
+      last = b;
+    }
+    if (last >= 0 && hipStreamWaitEvent(reader, ev[static_cast<size_t>(last)], 0) != hipSuccess) { (void)hipGetLastError(); failed = IST_E_HIP; return fail(IST_E_HIP, "ordering the export behind the render failed"); }
+    return IST_OK;
+  };
+  int64_t hint = 0;
+  for (int b = 0; b < rb.nb; ++b) hint = std::max<int64_t>(hint, rb.y1(b) - rb.y0(b));
+  rc = png_to_host(ctx, rb.canvas, rb.row, canvas_w, canvas_h, nullptr, out_png, out_len, need_rows, hint);
+  (void)hipStreamSynchronize(R); (void)stager_of(ctx).sync(); (void)hipStreamSynchronize(ctx->stream);
+  for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+  if (rc == IST_OK) g_duplex_stitches.fetch_add(1, std::memory_order_relaxed);
+  (void)failed;
+  return rc;
 }
 
 int64_t ist_debug_duplex_stitches(void) { return g_duplex_stitches.load(); }
