@@ -195,6 +195,17 @@ int Stager::upload_big(const std::vector<RowsCopy>& items, hipStream_t after, Wo
   if (rc) return rc;
   for (const RowsCopy& it : items) {
     if (it.row == 0 || it.rows == 0 || it.row > kBigPiece) continue;
+    // caller memory that IS page-locked (a host that keeps its images in pinned blocks; nothing is registered here) and has dense rows
+    // needs no staging: one copy straight from it
+    if (it.host_pitch == it.row) {
+      hipPointerAttribute_t attr;
+      std::memset(&attr, 0, sizeof(attr));
+      if (hipPointerGetAttributes(&attr, it.host_src) == hipSuccess && attr.type == hipMemoryTypeHost) {
+        if (hipMemcpyAsync(it.dev, it.host_src, it.rows * it.row, hipMemcpyHostToDevice, big_.stream) != hipSuccess) { (void)hipGetLastError(); return fail(IST_E_HIP, "host-to-device copy failed"); }
+        continue;
+      }
+      (void)hipGetLastError();                  // (ordinary memory: the query fails, which is the answer)
+    }
     const size_t per = std::max<size_t>(1, kBigPiece / it.row);
     for (size_t r0 = 0; r0 < it.rows; r0 += per) {
       const size_t nr = std::min(per, it.rows - r0);

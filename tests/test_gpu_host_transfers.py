@@ -181,3 +181,16 @@ def test_a_large_stitch_goes_up_and_comes_down_at_the_same_time():
     ref, _, _ = U.oracle_stitch(px, "vertical", {"filter": "nearest", "mode": "max"})
     got = ist.stitch(imgs, "vertical", {"filter": "nearest", "mode": "max"})
     assert np.array_equal(got["data"], ref)
+
+
+def test_page_locked_caller_memory_goes_up_without_staging():
+    """a host that keeps its images in pinned blocks (here: torch pinned tensors seen as numpy): the band uploads copy straight from them"""
+    import torch
+    sizes = [(2000, 1500), (2000, 1400), (2000, 1600), (2000, 1100)]
+    px = [U.rand_image(340 + i, h, w) for i, (w, h) in enumerate(sizes)]
+    pinned = [torch.from_numpy(a).pin_memory() for a in px]
+    imgs = [{"width": a.shape[1], "height": a.shape[0], "data": t.numpy()} for a, t in zip(px, pinned)]
+    for direction in ("vertical", "horizontal"):
+        ref, _, _ = U.oracle_stitch(px, direction, {"filter": "nearest", "mode": "max"})
+        got = ist.stitch(imgs, direction, {"filter": "nearest", "mode": "max"})
+        assert np.array_equal(got["data"], ref), direction

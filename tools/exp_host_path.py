@@ -31,6 +31,21 @@ for name, im, direction in (("9 x 4032x3024 vertical", imgs, "vertical"), ("9 x 
     print("%-36s %6.2f ms per stitch  (%.1f GB/s of payload, in + out)  %s" % (name, t * 1e3, (sum(a.nbytes for a in (px if im is imgs else mixed)) + nbytes) / t / 1e9,
           "bands, both directions busy" if L.lib.ist_debug_duplex_stitches() > before else "upload all, launch, download all"), flush=True)
 
+# the same nine images kept in page-locked memory by the host (torch pinned tensors): no staging, one copy per band and image
+import torch  # noqa: E402
+
+pinned = [torch.from_numpy(a).pin_memory() for a in px]
+pimgs = [{"width": 4032, "height": 3024, "data": t.numpy(), "opaque": True} for t in pinned]
+for direction in ("vertical", "horizontal"):
+    ist.stitch(pimgs, direction, {"filter": "bilinear"})
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        r = ist.stitch(pimgs, direction, {"filter": "bilinear"})
+        ts.append(time.perf_counter() - t0)
+        del r
+    print("9 x 4032x3024 %-10s from page-locked memory: %6.2f ms per stitch" % (direction, sorted(ts)[3] * 1e3), flush=True)
+
 # photo-like images to a PNG file in host memory (ist_stitch_png, called through ctypes so that no Python copy of the file is timed):
 # the next band's rows go up while the encoder compresses the last one and its slabs come down
 import ctypes as C  # noqa: E402
