@@ -492,7 +492,7 @@ def host_path_leg(ist, np, reps=4):
         del r
     t = sorted(ts)[len(ts) // 2]
     return {"ms_per_stitch": round(t * 1e3, 2), "MPs": round(109.734912 / t, 1), "pcie_payload_GBs": round(2 * 438.939648e6 / t / 1e9, 2),
-            "what": "PCIe-inclusive: pageable numpy in -> plan -> per image: packed into 32 MiB pinned pieces, H2D, its band launched, the band's rows D2H into a pooled pinned block while the next image goes up (never `value`)"}
+            "what": "PCIe-inclusive: pageable numpy in -> plan -> row bands of ~40 MB: the source rows a band samples are packed into 32 MiB pinned pieces and sent up, the band is launched, its rows come down into a pooled pinned block while the next band's rows go up (never `value`)"}
 
 
 def file_pipeline_leg(ist, reps=5):
